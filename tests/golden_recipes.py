@@ -1,0 +1,44 @@
+"""Program / input recipes shared by tests/golden/make_goldens.py (which runs the compiled reference
+on them) and the parity tests (which re-create the same programs and inputs on the GPU box, where
+the reference does not exist).  Pure numpy; nothing here touches the oracle or the reference."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from avdsp_amd import progbuilder as pb
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def is_float_samples(fmt: int) -> bool:
+    return fmt in (5, 6)
+
+
+def make_program(recipe: dict) -> np.ndarray:
+    kind = recipe["kind"]
+    if kind == "file":
+        return np.fromfile(os.path.join(GOLDEN_DIR, recipe["name"]), dtype=np.uint32)
+    if kind == "synth":
+        return pb.synth_program(recipe["fmt"], recipe["channels"], recipe["sections"],
+                                recipe.get("taps", 0), recipe.get("fmin", pb.F48000),
+                                recipe.get("fmax", pb.F48000), recipe.get("gain", 1.0))
+    raise ValueError(kind)
+
+
+def make_input(recipe: dict, fmt: int) -> np.ndarray:
+    fl = is_float_samples(fmt)
+    frames, ch = recipe["frames"], recipe["channels"]
+    kind = recipe["kind"]
+    if kind == "lcg":
+        return pb.lcg_input(frames, ch, fl, seed=recipe.get("seed", 12345))
+    if kind == "fullscale":            # +/- (almost) full scale square-ish pattern: drives every saturator
+        t = np.arange(frames * ch).reshape(frames, ch)
+        sq = np.sign(np.sin(t * 0.37))
+        return (sq * 0.999).astype(np.float32) if fl else (sq * 2147483000).astype(np.int32)
+    if kind == "impulse":
+        x = np.zeros((frames, ch), dtype=np.float32 if fl else np.int32)
+        x[0, :] = recipe["value_f"] if fl else recipe["value_i"]
+        return x
+    raise ValueError(kind)

@@ -1,0 +1,89 @@
+"""The oracle (oracle/avdsp_oracle.c) against the golden vectors produced by the compiled reference.
+
+CPU only.  This is what pins the oracle: every case in tests/golden/manifest.json was executed by the
+reference runtime itself (tests/golden/make_goldens.py); the oracle must reproduce outputs AND the
+final state area bit for bit, in every arithmetic model (DSP_FORMAT 2..6)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from tests.golden_recipes import GOLDEN_DIR, make_input, make_program
+
+with open(os.path.join(GOLDEN_DIR, "manifest.json")) as _f:
+    MANIFEST = json.load(_f)
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize("case", MANIFEST["cases"], ids=lambda c: c["name"])
+def test_oracle_reproduces_reference(case):
+    prog = make_program(case["program"])
+    x = make_input(case["input"], case["fmt"])
+    assert sha(prog) == case["prog_sha"], "program recipe drifted from the one the golden was made with"
+    assert sha(x) == case["in_sha"]
+    o = po.OracleProgram(case["fmt"], prog, fs=case["fs"], random=case["random"], dither=case["dither"])
+    assert o.rc == case["init_rc"]
+    out = o.run_block(x, case["out_stride"], case["in_base"], case["out_base"],
+                      scratch_len=case["scratch"], block=case["block"])
+    g = np.load(os.path.join(GOLDEN_DIR, case["name"] + ".npz"))
+    assert (out[:16].view(np.uint32) == g["head"].view(np.uint32)).all()
+    assert (out[-16:].view(np.uint32) == g["tail"].view(np.uint32)).all()
+    if case["full"]:
+        assert (out.view(np.uint32) == g["out"].view(np.uint32)).all()
+        assert (o.state == g["state"]).all()
+    assert sha(out) == case["out_sha"]
+    assert sha(o.state) == case["state_sha"]
+
+
+@pytest.mark.parametrize("neg", MANIFEST["init_return_codes"], ids=lambda n: n["case"])
+def test_init_return_codes(neg):
+    """dspRuntimeInit / dspRuntimeReset error codes (dsp_runtime.c:119-125,159-194) as the reference returned them."""
+    from avdsp_amd import progbuilder as pb
+    good = pb.synth_program(2, 2, 2)
+    prog, fs, max_size = good, 48000, None
+    c = neg["case"]
+    if c == "bad_checksum":
+        prog = good.copy(); prog[3] ^= 1
+    elif c in ("unsupported_fs", "fs_out_of_range"):
+        fs = neg["fs"]
+    elif c == "buffer_too_small":
+        max_size = neg["max_size"]
+    elif c == "no_header":
+        prog = good.copy(); prog[0] = (2 << 16) | 12
+    elif c == "opcode_too_new":
+        prog = good.copy(); prog[6] = (62 << 16) | (int(prog[6]) & 0xFFFF)
+    o = po.OracleProgram(2, prog, fs=fs, max_size=max_size)
+    assert o.rc == neg["rc"]
+
+
+def test_kernel_vectors():
+    """Arithmetic helpers against outputs of the reference's own (unmodified) headers."""
+    L = po.lib()
+    k = np.load(os.path.join(GOLDEN_DIR, "kernel_vectors.npz"))
+    a, b = k["a"], k["b"]
+    got = np.array([L.oracle_mul_float_double(float(p), float(q)) for p, q in zip(a, b)])
+    assert (got.view(np.uint64) == k["mul_float_double"].view(np.uint64)).all()
+    got = np.array([L.oracle_mul_float_float(float(p), float(q)) for p, q in zip(a, b)], dtype=np.float32)
+    finite = np.abs(a.astype(np.float64) * b.astype(np.float64)) < 3.0e38   # exponent overflow is a signed-shift UB in the reference
+    assert (got.view(np.uint32) == k["mul_float_float"].view(np.uint32))[finite].all()
+    iv = k["iv"]
+    got = np.array([L.oracle_int_to_float_scaled(int(v), 31) for v in iv], dtype=np.float32)
+    assert (got.view(np.uint32) == k["int_to_float_scaled"].view(np.uint32)).all()
+    got = np.array([L.oracle_int_to_double_scaled(int(v), 31) for v in iv])
+    assert (got.view(np.uint64) == k["int_to_double_scaled"].view(np.uint64)).all()
+    dv = k["dv"]
+    defined = (np.abs(dv) >= 2.0 ** -42) | (dv == 0)       # below that the reference shifts by >= 64 bits (UB)
+    got = np.array([L.oracle_s31_from_double(float(v)) for v in dv], dtype=np.int32)
+    assert (got[defined] == k["s31_from_double"][defined]).all()
+    got = np.array([L.oracle_saturate_double(float(v)) for v in dv])
+    assert (got.view(np.uint64) == k["saturate_double"].view(np.uint64)).all()
+    got = np.array([L.oracle_truncate_double(float(v), 24) for v in dv])
+    assert (got.view(np.uint64) == k["truncate_double_24"].view(np.uint64)).all()
+    got = np.array([L.oracle_saturate64_031(int(v), 28) for v in k["lv"]], dtype=np.int64)
+    assert (got == k["saturate64_031"]).all()
