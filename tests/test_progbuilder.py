@@ -59,4 +59,4 @@ def test_fir_program_layout():
         off = int(np.int32(w[p + 1]))
         assert int(w[p + off]) == 7                    # length word, hi16 == 0
         assert (p + off) & 1                           # odd index, taps 8-byte aligned
-    assert int(w[2]) == 2 * (6 + 8)                    # 6 biquad words + 7 taps rounded to even, per channel
+    assert int(w[2]) == 27                             # 6+7, pad to even, 6+7 (addDataSpaceAligned8, dsp_encoder.c:141-144)
