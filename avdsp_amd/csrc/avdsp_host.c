@@ -1,0 +1,506 @@
+/*
+ * avdsp_host.c -- host side of the MI355X-native AVDSP runtime, plain C99.
+ *
+ * Implements the reference's C API (module_avdsp/runtime/dsp_runtime.h:160-164) on top of the thin
+ * HIP ABI in include/avdsp_hip.h.  This file owns: program validation (dspRuntimeInit,
+ * dsp_runtime.c:150-195), sample-rate selection and state reset (dspRuntimeReset, :116-145), core
+ * lookup (:42-77) and the *lowering* of a core's opcode stream into channel chains for the device.
+ * It contains no signal arithmetic: every sample is computed by the gfx950 kernels.  A core that
+ * is not a set of independent  LOAD|LOAD_GAIN -> BIQUADS* -> [FIR] -> [SAT0DB] -> STORE+  chains
+ * is refused with an error (no CPU fallback).
+ */
+#include "avdsp_runtime.h"
+#include "avdsp_hip.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---- exported data of the reference runtime (dsp_runtime.c:36-38) ---- */
+dspHeader_t *dspHeaderPtr = 0;
+int          dspBiquadFreqSkip = 0;
+int          dspMantissa = DSP_MANT;
+
+/* dsp_header.c:10-73 (the leading newlines on four entries are the reference's) */
+const char *dspOpcodeText[DSP_MAX_OPCODE] = {
+    "DSP_END_OF_CODE", "\nDSP_HEADER", "DSP_NOP", "\nDSP_CORE", "\nDSP_PARAM", "\nDSP_PARAM_NUM",
+    "DSP_SERIAL", "DSP_TPDF_CALC", "DSP_TPDF", "DSP_WHITE", "DSP_CLRXY", "DSP_SWAPXY", "DSP_COPYXY",
+    "DSP_COPYYX", "DSP_ADDXY", "DSP_ADDYX", "DSP_SUBXY", "DSP_SUBYX", "DSP_MULXY", "DSP_DIVXY",
+    "DSP_DIVYX", "DSP_AVGXY", "DSP_AVGYX", "DSP_NEGX", "DSP_NEGY", "DSP_SQRTX", "DSP_SHIFT",
+    "DSP_VALUE", "DSP_VALUE_INT", "DSP_MUL_VALUE", "DSP_MUL_VALUE_INT", "DSP_DIV_VALUE",
+    "DSP_DIV_VALUE_INT", "DSP_AND_VALUE_INT", "DSP_LOAD", "DSP_LOAD_GAIN", "DSP_LOAD_MUX",
+    "DSP_STORE", "DSP_LOAD_STORE", "DSP_LOAD_MEM", "DSP_STORE_MEM", "DSP_GAIN", "DSP_SAT0DB",
+    "DSP_SAT0DB_TPDF", "DSP_SAT0DB_GAIN", "DSP_SAT0DB_TPDF_GAIN", "DSP_DELAY_1", "DSP_DELAY",
+    "DSP_DELAY_DP", "DSP_DATA_TABLE", "DSP_BIQUADS", "DSP_FIR", "DSP_RMS", "DSP_DCBLOCK",
+    "DSP_DITHER", "DSP_DITHER_NS2", "DSP_DISTRIB", "DSP_DIRAC", "DSP_SQUAREWAVE", "DSP_CLIP",
+    "DSP_LOAD_MEM_DATA", "DSP_SINE"
+};
+
+/* dsp_header.h:276-285 + dsp_header.c:75-85: saturating double -> Qn.m */
+long long dspQNM(double x, int n, int m)
+{
+    int b = n + m;
+    if (m >= b || b > 64 || m < 1) return 0;
+    double lim = (double)(1ull << (b - m - 1));
+    if (x >= lim) return b >= 64 ? 9223372036854775807ll : (long long)((1ull << (b - 1)) - 1);
+    if (-x > lim) return b >= 64 ? (-9223372036854775807ll - 1) : (long long)(1ull << (b - 1));
+    if (b >= 33) return (long long)(x * (double)(1ll << m));
+    return (long long)(int)(x * (double)(1l << m));
+}
+long long dspQM64(double x, int m) { return dspQNM(x, 64 - m, m); }
+int       dspQM32(double x, int m) { return (int)dspQNM(x, 32 - m, m); }
+
+/* ---- the one loaded program (the reference keeps the same things in file-scope statics) ---- */
+typedef struct {
+    opcode_t   *core;            /* key: the pointer the host passes (after dspFindCoreBegin) */
+    int         format;
+    int         plan_id;         /* id inside the device program, < 0 = lowering failed */
+    int         nchains, max_sections, max_taps;
+} core_plan;
+
+#define MAX_CORE_PLANS 64
+
+static struct {
+    opcode_t       *code;
+    int             total_words;         /* totalLength + dataSize */
+    int             have_rate;
+    int             freq_index, num_freq, biquad_offset;
+    int             dither, store_mask;
+    avdsp_hip_prog *dev;
+    int             dev_state_valid;     /* device mirror holds the authoritative state */
+    core_plan       plans[MAX_CORE_PLANS];
+    int             nplans;
+    int             opt_fir_impl, opt_biquad_impl, opt_device;
+    int             device_selected;
+} G = { .opt_fir_impl = 1, .opt_biquad_impl = 1, .opt_device = -1 };
+
+static char g_err[512];
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+const char *dspRuntimeLastError(void) { return g_err; }
+
+static void drop_device(void)
+{
+    if (G.dev) avdsp_hip_prog_destroy(G.dev);
+    G.dev = 0;
+    G.nplans = 0;
+    G.dev_state_valid = 0;
+}
+
+void dspRuntimeRelease(void)
+{
+    drop_device();
+    G.code = 0;
+    dspHeaderPtr = 0;
+    G.have_rate = 0;
+}
+
+int dspRuntimeSetOption(const char *key, int value)
+{
+    if (!strcmp(key, "fir_impl"))    { G.opt_fir_impl = value; return 0; }
+    if (!strcmp(key, "biquad_impl")) { G.opt_biquad_impl = value; return 0; }
+    if (!strcmp(key, "device"))      { G.opt_device = value; G.device_selected = 0; return 0; }
+    return fail(-1, "unknown option '%s'", key);
+}
+
+int dspRuntimeGetOption(const char *key)
+{
+    if (!strcmp(key, "fir_impl"))    return G.opt_fir_impl;
+    if (!strcmp(key, "biquad_impl")) return G.opt_biquad_impl;
+    if (!strcmp(key, "device"))      return G.opt_device;
+    return -1;
+}
+
+/* ---- dsp_runtime.c:42-59 ---- */
+opcode_t *dspFindCore(opcode_t *codePtr, const int numCore)
+{
+    if (codePtr->op.opcode != DSP_HEADER) return 0;
+    opcode_t *p = codePtr;
+    int seen = 0;
+    for (;;) {
+        unsigned skip = p->op.skip;
+        if (skip == 0) return seen == 0 ? codePtr : 0;
+        if (p->op.opcode == DSP_CORE && ++seen == numCore) return p;
+        p += skip;
+    }
+}
+
+/* ---- dsp_runtime.c:62-77 ---- */
+opcode_t *dspFindCoreBegin(opcode_t *p)
+{
+    if (p && p->op.opcode == DSP_CORE)
+        for (;;) {
+            unsigned skip = p->op.skip;
+            int op = p->op.opcode;
+            if (skip == 0) return p;
+            if (op == DSP_CORE || op == DSP_NOP || op == DSP_PARAM || op == DSP_PARAM_NUM) p += skip;
+            else break;
+        }
+    return p;
+}
+
+/* ---- dsp_runtime.c:116-145 ---- */
+int dspRuntimeReset(const int fs, int random, int defaultDither)
+{
+    (void)random;                        /* seeds the TPDF generator; no TPDF opcode is lowered yet */
+    if (!dspHeaderPtr) return fail(-1, "dspRuntimeReset before dspRuntimeInit");
+    int idx = dspConvertFrequencyToIndex(fs);
+    if (idx >= FMAXpos) return fail(-1, "sampling frequency %d not supported", fs);
+    int mn = dspHeaderPtr->freqMin, mx = dspHeaderPtr->freqMax;
+    if (idx < mn || idx > mx) return fail(-2, "sampling frequency %d outside the program's range", fs);
+    G.freq_index = idx - mn;
+    G.num_freq = mx - mn + 1;
+    dspBiquadFreqSkip = 2 + 6 * G.num_freq;
+    G.biquad_offset = 5 + 6 * G.freq_index;
+    G.have_rate = 1;
+    G.dither = defaultDither;
+    /* dsp_tpdf.h:55-59: mask = -1 << (32 - dither) */
+    G.store_mask = (int)(0xFFFFFFFFu << ((32 - defaultDither) & 31));
+    int *data = (int *)dspHeaderPtr + dspHeaderPtr->totalLength;
+    memset(data, 0, (size_t)dspHeaderPtr->dataSize * sizeof(int));
+    /* plans embed the rate-dependent coefficient addresses and the store mask: rebuild lazily */
+    drop_device();
+    return 0;
+}
+
+/* ---- dsp_runtime.c:150-195 ---- */
+int dspRuntimeInit(opcode_t *codePtr, int maxSize, const int fs, int random, int defaultDither)
+{
+    drop_device();
+    G.have_rate = 0;
+    dspHeaderPtr = (dspHeader_t *)codePtr;
+    G.code = codePtr;
+    if (codePtr->op.opcode != DSP_HEADER) return fail(-1, "no dsp header in this program");
+    int length = dspHeaderPtr->totalLength, size = dspHeaderPtr->dataSize;
+    if (size + length > maxSize)
+        return fail(-6, "program+data = %d words exceeds the buffer (%d)", size + length, maxSize);
+    unsigned sum; int cores;
+    avdspChecksumWalk(codePtr, (unsigned)length, &sum, &cores);
+    if (cores < 1) return fail(-3, "no cores defined in the program");
+    if (sum != dspHeaderPtr->checkSum) return fail(-4, "checksum problem with the program");
+    if (dspHeaderPtr->maxOpcode >= DSP_MAX_OPCODE)
+        return fail(-5, "program uses opcodes newer than this runtime");
+    dspMantissa = DSP_MANT;
+    if (dspHeaderPtr->format != 0 && dspHeaderPtr->format != DSP_MANT)
+        return fail(-7, "integer encoding with %d mantissa bits: only Q%d programs are accepted "
+                        "(dspChangeFormat is not carried over, see DESIGN.md)", dspHeaderPtr->format, DSP_MANT);
+    G.total_words = length + size;
+    if (fs) { int r = dspRuntimeReset(fs, random, defaultDither); if (r) return r; }
+    return length;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * lowering: opcode stream of one core -> chains
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    avdsp_chain *chains; int nchains, cap_chains;
+    int32_t *coef_word, *state_word; int nsec, cap_sec;
+} lowered;
+
+static void lowered_free(lowered *L) { free(L->chains); free(L->coef_word); free(L->state_word); memset(L, 0, sizeof *L); }
+
+static int push_chain(lowered *L, const avdsp_chain *c)
+{
+    if (L->nchains == L->cap_chains) {
+        int n = L->cap_chains ? 2 * L->cap_chains : 64;
+        avdsp_chain *p = (avdsp_chain *)realloc(L->chains, (size_t)n * sizeof *p);
+        if (!p) return -1;
+        L->chains = p; L->cap_chains = n;
+    }
+    L->chains[L->nchains++] = *c;
+    return 0;
+}
+
+static int push_section(lowered *L, int coef, int state)
+{
+    if (L->nsec == L->cap_sec) {
+        int n = L->cap_sec ? 2 * L->cap_sec : 1024;
+        int32_t *a = (int32_t *)realloc(L->coef_word, (size_t)n * 4);
+        int32_t *b = (int32_t *)realloc(L->state_word, (size_t)n * 4);
+        if (!a || !b) { if (a) L->coef_word = a; if (b) L->state_word = b; return -1; }
+        L->coef_word = a; L->state_word = b; L->cap_sec = n;
+    }
+    L->coef_word[L->nsec] = coef;
+    L->state_word[L->nsec] = state;
+    L->nsec++;
+    return 0;
+}
+
+static int cmp_int(const void *a, const void *b) { int x = *(const int *)a, y = *(const int *)b; return (x > y) - (x < y); }
+
+/* Chains of one core run concurrently on the device, so the sequential reading of the opcode
+ * stream must not create a dependency between them: no chain may load an IO that another chain
+ * of the same core stores, and no IO may be stored twice.                                       */
+static int check_independent(const lowered *L)
+{
+    int nout = 0;
+    for (int i = 0; i < L->nchains; i++) nout += L->chains[i].n_out;
+    int *outs = (int *)malloc((size_t)(nout ? nout : 1) * sizeof(int));
+    if (!outs) return fail(-9, "out of memory");
+    int k = 0;
+    for (int i = 0; i < L->nchains; i++)
+        for (int j = 0; j < L->chains[i].n_out; j++) outs[k++] = L->chains[i].out_io[j];
+    qsort(outs, (size_t)nout, sizeof(int), cmp_int);
+    int rc = 0;
+    for (int i = 1; i < nout && !rc; i++)
+        if (outs[i] == outs[i - 1]) rc = fail(-8, "IO %d is stored by more than one chain of the core", outs[i]);
+    for (int i = 0; i < L->nchains && !rc; i++)
+        if (bsearch(&L->chains[i].in_io, outs, (size_t)nout, sizeof(int), cmp_int))
+            rc = fail(-8, "IO %d is both loaded and stored inside one core (cross-chain dependency)", L->chains[i].in_io);
+    free(outs);
+    return rc;
+}
+
+static int lower_core(int format, opcode_t *core, lowered *L)
+{
+    const int float_alu = (format != DSP_FORMAT_INT64);
+    const int prog_words = dspHeaderPtr->totalLength;
+    opcode_t *p = dspFindCoreBegin(core);
+    avdsp_chain cur;
+    int open = 0;
+    memset(&cur, 0, sizeof cur);
+    memset(L, 0, sizeof *L);
+
+    if ((format == DSP_FORMAT_INT64) != (dspHeaderPtr->format != 0))
+        return fail(-7, "program is %s-encoded but dspRuntime_%d was called: the reference's "
+                        "dspChangeFormat conversion is not provided", dspHeaderPtr->format ? "Q28" : "float", format);
+
+    for (;;) {
+        const int op = p->op.opcode;
+        const unsigned skip = p->op.skip;
+        const int *a = (const int *)p + 1;
+        const int at = (int)(p - G.code);
+        if (skip == 0 || op == DSP_CORE) break;              /* dsp_runtime.c:321-331 */
+        switch (op) {
+        case DSP_NOP: case DSP_PARAM: case DSP_PARAM_NUM: case DSP_SERIAL:
+            break;
+        case DSP_LOAD:                                        /* :565-583 */
+        case DSP_LOAD_GAIN:                                   /* :586-607 */
+            if (open) {
+                if (cur.n_out == 0)
+                    return fail(-8, "word %d: value replaced before any STORE (X/Y tricks are not lowered)", at);
+                if (push_chain(L, &cur)) return fail(-9, "out of memory");
+            }
+            memset(&cur, 0, sizeof cur);
+            open = 1;
+            cur.in_io = a[0];
+            cur.sec_base = L->nsec;
+            if (op == DSP_LOAD_GAIN) {
+                cur.load_mode = AVDSP_LOAD_GAIN;
+                cur.gain_bits = p[a[1]].u32;
+            }
+            break;
+        case DSP_BIQUADS: {                                   /* :827-849 */
+            if (!open || cur.n_out || cur.sat || cur.fir_taps)
+                return fail(-8, "word %d: BIQUADS outside the supported LOAD->BIQUADS->FIR->SAT0DB->STORE order", at);
+            const opcode_t *bank = p + a[1];
+            int num = (short)bank[0].i32;                     /* callee takes `short num` */
+            if (bank[1].i32 != 0)                             /* 0 = bypass, :837 */
+                for (int s = 0; s < num; s++)
+                    if (push_section(L, (int)(bank - G.code) + G.biquad_offset + s * dspBiquadFreqSkip,
+                                     prog_words + a[0] + 6 * s))
+                        return fail(-9, "out of memory");
+            cur.nsec = L->nsec - cur.sec_base;
+            break; }
+        case DSP_FIR: {                                       /* :928-969 */
+            if (!open || cur.n_out || cur.sat)
+                return fail(-8, "word %d: FIR outside the supported chain order", at);
+            if (!float_alu)
+                return fail(-8, "word %d: DSP_FIR in int64 mode is undefined behaviour in the reference "
+                                "(dsp_firSTD.h:8-35) and is not provided", at);
+            int off = a[G.freq_index];
+            if (off) {
+                const opcode_t *imp = p + off;
+                int length = imp[0].i32;
+                if (length >> 16)
+                    return fail(-8, "word %d: FIR pure-delay variant is not lowered yet", at);
+                if (length > 0) {
+                    if (cur.fir_taps) return fail(-8, "word %d: more than one FIR per chain", at);
+                    cur.fir_taps = length;
+                    cur.fir_coef_word = (int)(imp - G.code) + 1;
+                    cur.fir_state_word = prog_words + a[G.num_freq];
+                }
+            }
+            break; }
+        case DSP_SAT0DB:                                      /* :464-475 */
+            if (!open || cur.n_out) return fail(-8, "word %d: SAT0DB outside the supported chain order", at);
+            cur.sat = 1;
+            break;
+        case DSP_STORE:                                       /* :610-633 */
+            if (!open) return fail(-8, "word %d: STORE without a LOAD", at);
+            if (cur.n_out == AVDSP_MAX_STORES) return fail(-8, "word %d: more than %d STOREs in a chain", at, AVDSP_MAX_STORES);
+            cur.out_io[cur.n_out++] = a[0];
+            break;
+        default:
+            return fail(-8, "word %d: opcode %d (%s) is not lowered to the HIP path", at, op,
+                        (op >= 0 && op < DSP_MAX_OPCODE) ? dspOpcodeText[op] + (dspOpcodeText[op][0] == '\n') : "?");
+        }
+        p += skip;
+    }
+    if (open) {
+        if (cur.n_out == 0) return fail(-8, "core ends with a chain that is never stored");
+        if (push_chain(L, &cur)) return fail(-9, "out of memory");
+    }
+    if (L->nchains == 0) return fail(-8, "core contains no LOAD..STORE chain");
+    return check_independent(L);
+}
+
+static int select_device(void)
+{
+    if (G.device_selected) return 0;
+    int n = avdsp_hip_device_count();
+    if (n <= 0) return fail(-10, "no HIP device: %s", avdsp_hip_last_error());
+    int want = G.opt_device;
+    if (want < 0) {
+        const char *e = getenv("LOCAL_RANK");
+        want = e ? atoi(e) % n : 0;
+    }
+    if (avdsp_hip_set_device(want)) return fail(-10, "%s", avdsp_hip_last_error());
+    G.device_selected = 1;
+    return 0;
+}
+
+/* find or build the device plan of (core, format) */
+static core_plan *get_plan(int format, opcode_t *core)
+{
+    if (!dspHeaderPtr || !G.code) { fail(-1, "no program loaded"); return 0; }
+    if (!G.have_rate) { fail(-1, "dspRuntimeReset(fs) has not selected a sample rate yet"); return 0; }
+    if (format != 2 && format != 4 && format != 6) { fail(-1, "DSP_FORMAT %d has no device path (2, 4, 6 do)", format); return 0; }
+    for (int i = 0; i < G.nplans; i++)
+        if (G.plans[i].core == core && G.plans[i].format == format) {
+            if (G.plans[i].plan_id < 0) { fail(-8, "core was refused earlier"); return 0; }
+            return &G.plans[i];
+        }
+    if (G.nplans == MAX_CORE_PLANS) { fail(-9, "too many cores"); return 0; }
+    if (core < G.code || core >= G.code + dspHeaderPtr->totalLength) { fail(-1, "core pointer outside the loaded program"); return 0; }
+
+    lowered L;
+    if (lower_core(format, core, &L)) { lowered_free(&L); return 0; }
+
+    if (select_device()) { lowered_free(&L); return 0; }
+    if (!G.dev) {
+        G.dev = avdsp_hip_prog_create(G.total_words);
+        if (!G.dev) { fail(-10, "%s", avdsp_hip_last_error()); lowered_free(&L); return 0; }
+        if (avdsp_hip_upload_words(G.dev, (const int32_t *)G.code, 0, G.total_words)) {
+            fail(-10, "%s", avdsp_hip_last_error()); lowered_free(&L); drop_device(); return 0;
+        }
+        G.dev_state_valid = 1;
+    }
+    avdsp_plan_desc d;
+    memset(&d, 0, sizeof d);
+    d.format = format;
+    d.nchains = L.nchains; d.chains = L.chains;
+    d.nsections = L.nsec; d.sec_coef_word = L.coef_word; d.sec_state_word = L.state_word;
+    d.store_mask = G.store_mask;
+    int id = avdsp_hip_prog_add_plan(G.dev, &d);
+    core_plan *cp = &G.plans[G.nplans];
+    cp->core = core; cp->format = format; cp->plan_id = id;
+    cp->nchains = L.nchains; cp->max_sections = 0; cp->max_taps = 0;
+    for (int i = 0; i < L.nchains; i++) {
+        if (L.chains[i].nsec > cp->max_sections) cp->max_sections = L.chains[i].nsec;
+        if (L.chains[i].fir_taps > cp->max_taps) cp->max_taps = L.chains[i].fir_taps;
+    }
+    lowered_free(&L);
+    if (id < 0) { fail(-10, "%s", avdsp_hip_last_error()); return 0; }
+    G.nplans++;
+    return cp;
+}
+
+int dspRuntimeCoreInfo(int format, opcode_t *core, int *nchains, int *max_sections, int *max_taps)
+{
+    core_plan *cp = get_plan(format, core);
+    if (!cp) return -8;
+    if (nchains) *nchains = cp->nchains;
+    if (max_sections) *max_sections = cp->max_sections;
+    if (max_taps) *max_taps = cp->max_taps;
+    return 0;
+}
+
+static int check_rundata(const int *rundata)
+{
+    if (rundata != (const int *)G.code + dspHeaderPtr->totalLength)
+        return fail(-1, "rundata must be code + dspRuntimeInit() result (the state area of the loaded buffer)");
+    return 0;
+}
+
+int dspRuntimeBlockDevice(int format, opcode_t *core, int *rundata,
+                          const void *d_in, int in_stride, int in_io_base,
+                          void *d_out, int out_stride, int out_io_base, int nframes, void *stream)
+{
+    core_plan *cp = get_plan(format, core);
+    if (!cp) return -8;
+    if (check_rundata(rundata)) return -1;
+    if (nframes <= 0) return 0;
+    if (avdsp_hip_run_block(G.dev, cp->plan_id, d_in, in_stride, in_io_base, d_out, out_stride, out_io_base,
+                            nframes, G.opt_fir_impl, G.opt_biquad_impl, stream))
+        return fail(-10, "%s", avdsp_hip_last_error());
+    return 0;
+}
+
+static int block_host(int format, opcode_t *core, int *rundata, const void *in, int in_stride, int in_io_base,
+                      void *out, int out_stride, int out_io_base, int nframes)
+{
+    core_plan *cp = get_plan(format, core);
+    if (!cp) return -8;
+    if (check_rundata(rundata)) return -1;
+    if (nframes <= 0) return 0;
+    if (avdsp_hip_run_block_host(G.dev, cp->plan_id, in, in_stride, in_io_base, out, out_stride, out_io_base,
+                                 nframes, G.opt_fir_impl, G.opt_biquad_impl))
+        return fail(-10, "%s", avdsp_hip_last_error());
+    return 0;
+}
+
+int dspRuntimeBlock_2(opcode_t *core, int *rundata, const int *in, int in_stride, int in_io_base,
+                      int *out, int out_stride, int out_io_base, int nframes)
+{ return block_host(2, core, rundata, in, in_stride, in_io_base, out, out_stride, out_io_base, nframes); }
+
+int dspRuntimeBlock_4(opcode_t *core, int *rundata, const int *in, int in_stride, int in_io_base,
+                      int *out, int out_stride, int out_io_base, int nframes)
+{ return block_host(4, core, rundata, in, in_stride, in_io_base, out, out_stride, out_io_base, nframes); }
+
+int dspRuntimeBlock_6(opcode_t *core, int *rundata, const float *in, int in_stride, int in_io_base,
+                      float *out, int out_stride, int out_io_base, int nframes)
+{ return block_host(6, core, rundata, in, in_stride, in_io_base, out, out_stride, out_io_base, nframes); }
+
+/* One frame = a block of one frame whose input and output windows are both the caller's samples[]
+ * array (IO numbers index it directly).  The window is the span of IO numbers the core touches. */
+static int one_frame(int format, opcode_t *core, int *rundata, void *samples)
+{
+    core_plan *cp = get_plan(format, core);
+    if (!cp) return -8;
+    /* the device side knows the IO span of the plan: stride 0 asks it to use that span */
+    return block_host(format, core, rundata, samples, 0, 0, samples, 0, 0, 1);
+}
+
+int dspRuntime_2(opcode_t *core, int *rundata, int *samples)   { return one_frame(2, core, rundata, samples); }
+int dspRuntime_4(opcode_t *core, int *rundata, int *samples)   { return one_frame(4, core, rundata, samples); }
+int dspRuntime_6(opcode_t *core, int *rundata, float *samples) { return one_frame(6, core, rundata, samples); }
+
+int dspRuntimeSyncState(int *rundata)
+{
+    if (!dspHeaderPtr) return fail(-1, "no program loaded");
+    if (check_rundata(rundata)) return -1;
+    if (!G.dev || !G.dev_state_valid) return 0;              /* nothing ran yet: host copy is current */
+    if (avdsp_hip_download_words(G.dev, (int32_t *)G.code, dspHeaderPtr->totalLength, dspHeaderPtr->dataSize))
+        return fail(-10, "%s", avdsp_hip_last_error());
+    return 0;
+}
+
+int dspRuntimeUploadState(const int *rundata)
+{
+    if (!dspHeaderPtr) return fail(-1, "no program loaded");
+    if (check_rundata(rundata)) return -1;
+    if (!G.dev) return 0;                                     /* uploaded with the whole buffer at first use */
+    if (avdsp_hip_upload_words(G.dev, (const int32_t *)G.code, dspHeaderPtr->totalLength, dspHeaderPtr->dataSize))
+        return fail(-10, "%s", avdsp_hip_last_error());
+    return 0;
+}

@@ -1,0 +1,824 @@
+/*
+ * avdsp_kernels.hip -- hand-written gfx950 (MI355X / CDNA4) kernels for the AVDSP hot path and the
+ * implementation of the thin C ABI in include/avdsp_hip.h.
+ *
+ * What runs here (reference file:line of the semantics each kernel reproduces):
+ *   load stage      DSP_LOAD / DSP_LOAD_GAIN        dsp_runtime.c:565-607, dsp_fpmath.h:66-80,
+ *                                                   dsp_ieee754.h:204-298,377-410
+ *   biquad cascade  DSP_BIQUADS                     dsp_runtime.c:827-849, dsp_biquadSTD.h:25-119
+ *   FIR             DSP_FIR (float accumulators)    dsp_runtime.c:928-969, dsp_firSTD.h:38-52
+ *   store stage     DSP_SAT0DB / DSP_STORE          dsp_runtime.c:464-475,610-633, dsp_fpmath.h:84-98,
+ *                                                   dsp_ieee754.h:85-107,187-199
+ *
+ * Data layout in HBM: the device keeps a word-for-word mirror of the caller's buffer (program words,
+ * then the state area), so coefficient and state addresses are the program's own word offsets and a
+ * checkpoint is a plain copy.  Samples are frame-interleaved [frame][channel] 32-bit words exactly
+ * as the reference host hands them over (linux/avdsp_plugin.c:103-139).
+ *
+ * Kernels:
+ *   biquad_pipe<FMT,P>  one lane per (channel, section): the cascade is a systolic pipeline across
+ *                       the lanes of a 16-lane DPP row (section s works on frame t-s), which is
+ *                       exact because every lane performs the reference's operations in the
+ *                       reference's order; only independent work is overlapped.  State and
+ *                       coefficients live in registers for the whole block.
+ *   biquad_simple<FMT>  one lane per channel, sections in a loop, state in memory (cross-check path)
+ *   fir_mfma<FMT>       one workgroup per channel; taps and the input window staged in LDS; the
+ *                       block's outputs are a dense (16 x K) x (K x 16) contraction per 256-frame
+ *                       tile on v_mfma_f64_16x16x4_f64: Y[i][a] = sum_m h[m+i] * x[16a-m].
+ *                       Products of two floats are exact in f64 and the K index ascends with the
+ *                       tap index, i.e. the reference's summation order.
+ *   fir_plain<FMT>      same staging, sequential v_fma_f64 tap loop per output (reference order)
+ *   passthrough<FMT>    chains without filters
+ */
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include <algorithm>
+
+#include "avdsp_hip.h"
+
+namespace {
+
+thread_local char g_err[512];
+
+int set_err(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return -1;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) return set_err("%s: %s", #expr, hipGetErrorString(e_));          \
+    } while (0)
+
+constexpr int kFirChunk   = 1024;     /* frames per launch: 4 MFMA tiles of 256 frames */
+constexpr int kTileFrames = 256;
+constexpr int kBlock      = 256;
+
+/* ------------------------------------------------------------------------------------------
+ * device helpers: arithmetic of the load / store stages
+ * ---------------------------------------------------------------------------------------- */
+
+/* An operand whose biased exponent is 0 counts as +0 in the reference's float products
+ * (dspMulFloatDouble, dsp_ieee754.h:383-386).                                               */
+__device__ __forceinline__ float flush_f32(float v)
+{
+    return (__float_as_uint(v) & 0x7F800000u) ? v : 0.0f;
+}
+__device__ __forceinline__ double mulop(float v) { return (double)flush_f32(v); }
+
+/* dsp_ieee754.h:204-250: int -> float, magnitude TRUNCATED to 24 bits, times 2^-31.  INT_MIN leaves
+ * the reference's 7-step normaliser one step short: mantissa 0, exponent 126, i.e. -0.5.       */
+__device__ __forceinline__ float int_to_float_scaled31(int x)
+{
+    if (x == 0) return 0.0f;
+    unsigned sign = x < 0 ? 0x80000000u : 0u;
+    unsigned mag = x < 0 ? 0u - (unsigned)x : (unsigned)x;
+    if (mag == 0x80000000u) return __uint_as_float(sign | (126u << 23));
+    int p = 31 - __clz((int)mag);
+    mag = p > 23 ? mag >> (p - 23) : mag << (23 - p);
+    return __uint_as_float(sign | ((unsigned)(127 + p - 31) << 23) | (mag & 0x7FFFFFu));
+}
+
+/* dsp_ieee754.h:253-298: exact x * 2^-31; INT_MIN mirrors the value the reference's -Ofast build
+ * returns after negating INT_MIN (signed overflow): -2^-8.                                      */
+__device__ __forceinline__ double int_to_double_scaled31(int x)
+{
+    if (x == (int)0x80000000u) return -0.00390625;
+    return (double)x * 4.656612873077392578125e-10;      /* 2^-31, exact scaling */
+}
+
+/* dsp_ieee754.h:187-199 */
+__device__ __forceinline__ double saturate_double_0db(double d)
+{
+    int e = (int)(__double_as_longlong(d) >> 52);
+    if (e >= 1023) return 1.0;
+    if (e < 0 && e >= -1025) return -1.0;
+    return d;
+}
+
+/* dsp_ieee754.h:85-107: truncate toward zero to s.31, |d| >= 1 -> +/-0x7FFFFFFF.  The reference is
+ * undefined for |d| < 2^-42 (shift count >= 64); 0 is produced there, as in the oracle.        */
+__device__ __forceinline__ int s31_from_double(double d)
+{
+    long long u = __double_as_longlong(d);
+    int e = (int)((u >> 52) & 2047);
+    if (e == 0) return 0;
+    long long m = (u & 0xFFFFFFFFFFFFFll) | (1ll << 52);
+    int n = 1044 - e;
+    if (n > 21) m = n < 64 ? (m >> n) : 0;
+    else m = 0x7FFFFFFF;
+    if (u < 0) m = -m;
+    return (int)m;
+}
+
+/* dsp_fpmath.h:84-98 with mant = 28 */
+__device__ __forceinline__ long long saturate64_031(long long a)
+{
+    const long long pos = 1ll << 59;
+    if (a >= pos) return 0x7FFFFFFFll;
+    if (a < -pos) return (long long)0xFFFFFFFF80000000ull;
+    return a >> 28;
+}
+
+/* Accumulator type per arithmetic model */
+template <int FMT> struct Alu { using type = double; };
+template <> struct Alu<2> { using type = long long; };
+
+/* DSP_LOAD / DSP_LOAD_GAIN on one raw 32-bit sample word */
+template <int FMT>
+__device__ __forceinline__ typename Alu<FMT>::type load_stage(unsigned raw, int mode, unsigned gain_bits)
+{
+    if constexpr (FMT == 2) {
+        long long s = (int)raw;
+        return mode == AVDSP_LOAD_GAIN ? s * (long long)(int)gain_bits : s;          /* :571, :593 */
+    } else if constexpr (FMT == 4) {
+        if (mode == AVDSP_LOAD_GAIN)                                                  /* :596-598 */
+            return mulop(int_to_float_scaled31((int)raw)) * mulop(__uint_as_float(gain_bits));
+        return int_to_double_scaled31((int)raw);                                      /* :575 */
+    } else {
+        double x = (double)__uint_as_float(raw);                                      /* :580, :603-604 */
+        return mode == AVDSP_LOAD_GAIN ? x * (double)__uint_as_float(gain_bits) : x;
+    }
+}
+
+/* What BIQUADS / FIR take from the accumulator: (int)(X >> 28) or (float)X */
+template <int FMT>
+__device__ __forceinline__ unsigned narrow_stage(typename Alu<FMT>::type X)
+{
+    if constexpr (FMT == 2) return (unsigned)(int)(X >> 28);                          /* dspShiftInt, :831 */
+    else return __float_as_uint((float)X);
+}
+
+/* [DSP_SAT0DB] + DSP_STORE -> raw 32-bit sample word */
+template <int FMT>
+__device__ __forceinline__ unsigned store_stage(typename Alu<FMT>::type X, int sat, int mask)
+{
+    if constexpr (FMT == 2) {
+        if (sat) X = saturate64_031(X);
+        return (unsigned)((int)X & mask);                                             /* :616-618 */
+    } else {
+        if (sat) X = saturate_double_0db(X);
+        if constexpr (FMT == 4) return (unsigned)(s31_from_double(X) & mask);         /* :622-627 */
+        else return __float_as_uint((float)X);                                        /* :629-630 */
+    }
+}
+
+/* XCD-aware block index: hardware deals consecutive workgroups round-robin over the 8 XCDs, so
+ * giving XCD x the x-th contiguous eighth of the work keeps neighbouring channels (which share
+ * 128-byte lines of the interleaved sample block) in the same L2.  Speed only, never correctness. */
+__device__ __forceinline__ int xcd_remap(int b, int per_xcd) { return (b & 7) * per_xcd + (b >> 3); }
+
+struct BlockIO {
+    const unsigned *in;  int in_stride,  in_base;
+    unsigned       *out; int out_stride, out_base;
+    int nframes;
+    int store_mask;
+};
+
+/* final stores of one chain for frame n */
+__device__ __forceinline__ void emit_out(const BlockIO &io, const avdsp_chain &c, int n, unsigned word)
+{
+#pragma unroll
+    for (int k = 0; k < AVDSP_MAX_STORES; k++)          /* static indices keep the chain record in registers */
+        if (k < c.n_out) io.out[(size_t)n * io.out_stride + (c.out_io[k] - io.out_base)] = word;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * biquad cascade, section-pipelined
+ * ---------------------------------------------------------------------------------------- */
+template <int P>
+__device__ __forceinline__ unsigned from_prev_lane(unsigned v)
+{
+    if constexpr (P <= 16)          /* row_shr:1 inside a 16-lane DPP row; lane 0 of a row keeps v */
+        return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x111, 0xF, 0xF, false);
+    else
+        return (unsigned)__shfl_up((int)v, 1, 64);
+}
+
+struct BiquadArgs {
+    int            *buf;            /* device mirror of the caller's buffer */
+    const avdsp_chain *chains;
+    const int      *sec_coef, *sec_state;
+    const int      *group;          /* chain ids handled by this launch */
+    int             ngroup;
+    float          *xmid;           /* planar [chain][xmid_stride] hand-off to the FIR kernel */
+    int             xmid_stride;
+    int             per_xcd;
+    BlockIO         io;
+};
+
+template <int FMT, int P>
+__global__ __launch_bounds__(kBlock) void biquad_pipe(const BiquadArgs a)
+{
+    using alu_t = typename Alu<FMT>::type;
+    constexpr int CPB = kBlock / P;                     /* chains per block */
+    const int blk = xcd_remap(blockIdx.x, a.per_xcd);
+    const int slot = blk * CPB + (int)threadIdx.x / P;
+    const int s = (int)threadIdx.x % P;
+    const bool have_chain = slot < a.ngroup;
+    const int cid = have_chain ? a.group[slot] : 0;
+    const avdsp_chain c = a.chains[cid];
+    const bool lane_on = have_chain && s < c.nsec;
+    const bool first = lane_on && s == 0;
+    const bool last = lane_on && s == c.nsec - 1;
+    const int B = a.io.nframes;
+
+    /* coefficients and the 6 state words of this (chain, section) stay in registers */
+    int sw = 0;
+    alu_t acc = 0;
+    unsigned x1 = 0, x2 = 0, y1 = 0, y2 = 0;            /* raw state words: int32 or float bits */
+    [[maybe_unused]] int    ci[5] = {0, 0, 0, 0, 0};
+    [[maybe_unused]] double cd[5] = {0, 0, 0, 0, 0};
+    [[maybe_unused]] double dx1 = 0, dx2 = 0, dy1 = 0, dy2 = 0;
+    if (lane_on) {
+        const int cw = a.sec_coef[c.sec_base + s];
+        sw = a.sec_state[c.sec_base + s];
+        const int *st = a.buf + sw;
+        if constexpr (FMT == 2) {
+            acc = (long long)(((unsigned long long)(unsigned)st[1] << 32) | (unsigned)st[0]);
+            for (int k = 0; k < 5; k++) ci[k] = a.buf[cw + k];
+        } else {
+            acc = __longlong_as_double((long long)(((unsigned long long)(unsigned)st[1] << 32) | (unsigned)st[0]));
+            for (int k = 0; k < 5; k++) cd[k] = mulop(__int_as_float(a.buf[cw + k]));
+        }
+        x1 = (unsigned)st[2]; x2 = (unsigned)st[3]; y1 = (unsigned)st[4]; y2 = (unsigned)st[5];
+        if constexpr (FMT != 2) {
+            dx1 = mulop(__uint_as_float(x1)); dx2 = mulop(__uint_as_float(x2));
+            dy1 = mulop(__uint_as_float(y1)); dy2 = mulop(__uint_as_float(y2));
+        }
+    }
+
+    const unsigned *inp = a.io.in + (c.in_io - a.io.in_base);
+    constexpr int U = 16;                               /* input prefetch depth = unroll */
+    unsigned cur[U], nxt[U];
+#pragma unroll
+    for (int i = 0; i < U; i++) {
+        cur[i] = 0;
+        if (first && i < B) cur[i] = inp[(size_t)i * a.io.in_stride];
+    }
+
+    unsigned yprev = 0;                                 /* what this lane hands to section s+1 */
+    const int steps = B + P - 1;
+    for (int t0 = 0; t0 < steps; t0 += U) {
+#pragma unroll
+        for (int i = 0; i < U; i++) {                   /* samples of the NEXT group, in flight now */
+            const int n = t0 + U + i;
+            nxt[i] = 0;
+            if (first && n < B) nxt[i] = inp[(size_t)n * a.io.in_stride];
+        }
+#pragma unroll
+        for (int i = 0; i < U; i++) {
+            const int t = t0 + i;
+            const int n = t - s;                        /* frame this section works on */
+            unsigned xin = from_prev_lane<P>(yprev);
+            if (first) xin = narrow_stage<FMT>(load_stage<FMT>(cur[i], c.load_mode, c.gain_bits));
+            if (lane_on && n >= 0 && n < B) {
+                if constexpr (FMT == 2) {
+                    /* dsp_biquadSTD.h:37-74: five 32x32 MACs onto the previous full-precision
+                     * output, saturate on the high word, keep acc, y = acc >> 28              */
+                    unsigned long long u = (unsigned long long)acc;
+                    u += (unsigned long long)((long long)(int)xin * ci[0]);
+                    u += (unsigned long long)((long long)(int)x1 * ci[1]);
+                    u += (unsigned long long)((long long)(int)x2 * ci[2]);
+                    u += (unsigned long long)((long long)(int)y1 * ci[3]);
+                    u += (unsigned long long)((long long)(int)y2 * ci[4]);
+                    acc = (long long)u;
+                    const int hi = (int)(acc >> 32);
+                    if (hi >= (1 << 27)) acc = (1ll << 59) - 1;
+                    else if (hi <= 1 - (1 << 27)) acc = -(1ll << 59);
+                    x2 = x1; x1 = xin; y2 = y1;
+                    y1 = (unsigned)(int)(acc >> 28);
+                } else {
+                    /* dsp_biquadSTD.h:87-117: exact float x float products, five sequential f64 adds */
+                    const double dxin = mulop(__uint_as_float(xin));
+                    acc = __builtin_fma(dxin, cd[0], acc);
+                    acc = __builtin_fma(dx1, cd[1], acc);
+                    acc = __builtin_fma(dx2, cd[2], acc);
+                    acc = __builtin_fma(dy1, cd[3], acc);
+                    acc = __builtin_fma(dy2, cd[4], acc);
+                    const float yn = (float)acc;
+                    x2 = x1; x1 = xin; y2 = y1; y1 = __float_as_uint(yn);
+                    dx2 = dx1; dx1 = dxin; dy2 = dy1; dy1 = mulop(yn);
+                }
+                yprev = y1;
+                if (last) {
+                    if (c.fir_taps) a.xmid[(size_t)cid * a.xmid_stride + n] = __uint_as_float(narrow_stage<FMT>(acc));
+                    else emit_out(a.io, c, n, store_stage<FMT>(acc, c.sat, a.io.store_mask));
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < U; i++) cur[i] = nxt[i];
+    }
+
+    if (lane_on) {
+        int *st = a.buf + sw;
+        unsigned long long bits;
+        if constexpr (FMT == 2) bits = (unsigned long long)acc;
+        else bits = (unsigned long long)__double_as_longlong(acc);
+        st[0] = (int)(unsigned)bits; st[1] = (int)(unsigned)(bits >> 32);
+        st[2] = (int)x1; st[3] = (int)x2; st[4] = (int)y1; st[5] = (int)y2;
+    }
+}
+
+/* lane per chain, state in memory: slow, obviously sequential, used as a cross-check and for
+ * cascades longer than 64 sections                                                             */
+template <int FMT>
+__global__ __launch_bounds__(64) void biquad_simple(const BiquadArgs a)
+{
+    using alu_t = typename Alu<FMT>::type;
+    const int slot = blockIdx.x * 64 + threadIdx.x;
+    if (slot >= a.ngroup) return;
+    const int cid = a.group[slot];
+    const avdsp_chain c = a.chains[cid];
+    const unsigned *inp = a.io.in + (c.in_io - a.io.in_base);
+    for (int n = 0; n < a.io.nframes; n++) {
+        alu_t X = load_stage<FMT>(inp[(size_t)n * a.io.in_stride], c.load_mode, c.gain_bits);
+        unsigned xin = narrow_stage<FMT>(X);
+        for (int s = 0; s < c.nsec; s++) {
+            const int *co = a.buf + a.sec_coef[c.sec_base + s];
+            int *st = a.buf + a.sec_state[c.sec_base + s];
+            const unsigned long long raw = ((unsigned long long)(unsigned)st[1] << 32) | (unsigned)st[0];
+            const unsigned x1 = (unsigned)st[2], x2 = (unsigned)st[3], y1 = (unsigned)st[4], y2 = (unsigned)st[5];
+            unsigned yn;
+            unsigned long long keep;
+            if constexpr (FMT == 2) {
+                unsigned long long u = raw;
+                u += (unsigned long long)((long long)(int)xin * co[0]);
+                u += (unsigned long long)((long long)(int)x1 * co[1]);
+                u += (unsigned long long)((long long)(int)x2 * co[2]);
+                u += (unsigned long long)((long long)(int)y1 * co[3]);
+                u += (unsigned long long)((long long)(int)y2 * co[4]);
+                long long acc = (long long)u;
+                const int hi = (int)(acc >> 32);
+                if (hi >= (1 << 27)) acc = (1ll << 59) - 1;
+                else if (hi <= 1 - (1 << 27)) acc = -(1ll << 59);
+                X = acc; keep = (unsigned long long)acc;
+                yn = (unsigned)(int)(acc >> 28);
+            } else {
+                double acc = __longlong_as_double((long long)raw);
+                acc = __builtin_fma(mulop(__uint_as_float(xin)), mulop(__int_as_float(co[0])), acc);
+                acc = __builtin_fma(mulop(__uint_as_float(x1)), mulop(__int_as_float(co[1])), acc);
+                acc = __builtin_fma(mulop(__uint_as_float(x2)), mulop(__int_as_float(co[2])), acc);
+                acc = __builtin_fma(mulop(__uint_as_float(y1)), mulop(__int_as_float(co[3])), acc);
+                acc = __builtin_fma(mulop(__uint_as_float(y2)), mulop(__int_as_float(co[4])), acc);
+                X = acc; keep = (unsigned long long)__double_as_longlong(acc);
+                yn = __float_as_uint((float)acc);
+            }
+            st[0] = (int)(unsigned)keep; st[1] = (int)(unsigned)(keep >> 32);
+            st[2] = (int)xin; st[3] = (int)x1; st[4] = (int)yn; st[5] = (int)y1;
+            xin = yn;
+        }
+        if (c.fir_taps) a.xmid[(size_t)cid * a.xmid_stride + n] = __uint_as_float(narrow_stage<FMT>(X));
+        else emit_out(a.io, c, n, store_stage<FMT>(X, c.sat, a.io.store_mask));
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * FIR
+ * ---------------------------------------------------------------------------------------- */
+struct FirArgs {
+    int            *buf;
+    const avdsp_chain *chains;
+    const int      *group;
+    int             ngroup;
+    const float    *xmid;
+    int             xmid_stride;
+    int             per_xcd;
+    int             hs_cap;          /* floats reserved for the taps image */
+    BlockIO         io;
+};
+
+/* LDS images (floats).  Taps: hs[t + 16] for t in [-16, T+24), zero outside [0,T).
+ * Window: position w = q + T + 8 for sample index q (q < 0: history, st[i] <-> q = -1-i;
+ * 0 <= q < B: this block; everything else zero); stored at w + (w >> 4) so that the MFMA B
+ * operand (16 lanes striding 16 samples) hits 16 different banks.                              */
+__device__ __forceinline__ int win_pos(int w) { return w + (w >> 4); }
+constexpr int kWinOff = 8, kTapPad = 40;
+
+template <int FMT>
+__device__ __forceinline__ void fir_stage_lds(const FirArgs &a, const avdsp_chain &c, int cid,
+                                              float *hs, float *xs, int frames_pad)
+{
+    const int T = c.fir_taps, B = a.io.nframes;
+    const float *taps = reinterpret_cast<const float *>(a.buf + c.fir_coef_word);
+    const float *hist = reinterpret_cast<const float *>(a.buf + c.fir_state_word);
+    for (int u = threadIdx.x; u < T + kTapPad; u += blockDim.x) {
+        const int t = u - 16;
+        hs[u] = (t >= 0 && t < T) ? flush_f32(taps[t]) : 0.0f;
+    }
+    const int W = T + kWinOff + frames_pad + 16;
+    const unsigned *inp = a.io.in + (c.in_io - a.io.in_base);
+    for (int w = threadIdx.x; w < W; w += blockDim.x) {
+        const int q = w - (T + kWinOff);
+        float v = 0.0f;
+        if (q >= -T && q < 0) v = hist[-1 - q];
+        else if (q >= 0 && q < B) {
+            if (c.nsec) v = a.xmid[(size_t)cid * a.xmid_stride + q];
+            else v = __uint_as_float(narrow_stage<FMT>(load_stage<FMT>(inp[(size_t)q * a.io.in_stride], c.load_mode, c.gain_bits)));
+        }
+        xs[win_pos(w)] = v;                             /* raw: the delay line keeps subnormals */
+    }
+}
+
+/* new delay line: st[i] = x[B-1-i] (dsp_firSTD.h:45-50 applied B times) */
+__device__ __forceinline__ void fir_write_state(const FirArgs &a, const avdsp_chain &c, const float *xs)
+{
+    const int T = c.fir_taps, B = a.io.nframes;
+    float *hist = reinterpret_cast<float *>(a.buf + c.fir_state_word);
+    for (int i = threadIdx.x; i < T; i += blockDim.x)
+        hist[i] = xs[win_pos(B - 1 - i + T + kWinOff)];
+}
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+template <int FMT>
+__global__ __launch_bounds__(kBlock) void fir_mfma(const FirArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int slot = xcd_remap(blockIdx.x, a.per_xcd);
+    if (slot >= a.ngroup) return;
+    const int cid = a.group[slot];
+    const avdsp_chain c = a.chains[cid];
+    float *hs = lds, *xs = lds + a.hs_cap;
+    const int tiles = blockDim.x >> 6;                  /* one wave per 256-frame tile */
+    fir_stage_lds<FMT>(a, c, cid, hs, xs, tiles * kTileFrames);
+    __syncthreads();
+
+    const int T = c.fir_taps, B = a.io.nframes;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ij = lane & 15, k = lane >> 4;
+    /* Y[i][col] = y[16*(a0+col) + i] = sum_m A[i][m] * Bm[m][col],  A[i][m] = h[m+i],
+     * Bm[m][col] = x[16*(a0+col) - m],  m = -15 .. T-1 (4 per MFMA, ascending = tap order) */
+    const int a0 = wave * 16;
+    const int nsteps = (T + 15 + 3) >> 2;
+    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+    int ha = 16 + (-15) + k + ij;                       /* hs index of h[m + k + i] at m = -15 */
+    int wq = 16 * (a0 + ij) + 15 - k + (T + kWinOff);         /* window position of x[16(a0+j) - m - k] */
+    float hv = hs[ha];
+    float xv = xs[win_pos(wq)];
+    for (int st = 0; st < nsteps; st++) {
+        const double da = (double)hv;                   /* taps were flushed while staging */
+        const double db = mulop(xv);
+        ha += 4; wq -= 4;
+        hv = hs[ha];                                    /* next step's operands (zero padded, in range) */
+        xv = xs[win_pos(wq)];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(da, db, acc, 0, 0, 0);
+    }
+    /* C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg */
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int n = 16 * (a0 + ij) + k + 4 * r;
+        if (n < B) emit_out(a.io, c, n, store_stage<FMT>(acc[r], c.sat, a.io.store_mask));
+    }
+    fir_write_state(a, c, xs);
+}
+
+template <int FMT>
+__global__ __launch_bounds__(kBlock) void fir_plain(const FirArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int slot = xcd_remap(blockIdx.x, a.per_xcd);
+    if (slot >= a.ngroup) return;
+    const int cid = a.group[slot];
+    const avdsp_chain c = a.chains[cid];
+    float *hs = lds, *xs = lds + a.hs_cap;
+    const int tiles = blockDim.x >> 6;
+    fir_stage_lds<FMT>(a, c, cid, hs, xs, tiles * kTileFrames);
+    __syncthreads();
+    const int T = c.fir_taps, B = a.io.nframes;
+    for (int n = threadIdx.x; n < B; n += blockDim.x) {
+        double acc = 0.0;                               /* dsp_firSTD.h:43-50: taps in ascending order */
+        const int w0 = n + T + kWinOff;
+        for (int t = 0; t < T; t++)
+            acc = __builtin_fma(mulop(xs[win_pos(w0 - t)]), (double)hs[16 + t], acc);
+        emit_out(a.io, c, n, store_stage<FMT>(acc, c.sat, a.io.store_mask));
+    }
+    fir_write_state(a, c, xs);
+}
+
+/* chains with neither biquads nor FIR: LOAD -> [SAT0DB] -> STORE */
+struct PassArgs {
+    const avdsp_chain *chains;
+    const int *group;
+    int ngroup;
+    BlockIO io;
+};
+
+template <int FMT>
+__global__ __launch_bounds__(kBlock) void passthrough(const PassArgs a)
+{
+    const long long total = (long long)a.ngroup * a.io.nframes;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+        const int slot = (int)(g % a.ngroup), n = (int)(g / a.ngroup);
+        const avdsp_chain c = a.chains[a.group[slot]];
+        auto X = load_stage<FMT>(a.io.in[(size_t)n * a.io.in_stride + (c.in_io - a.io.in_base)], c.load_mode, c.gain_bits);
+        emit_out(a.io, c, n, store_stage<FMT>(X, c.sat, a.io.store_mask));
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * host side of the thin ABI
+ * ---------------------------------------------------------------------------------------- */
+struct Plan {
+    int format = 0, nchains = 0, store_mask = -1;
+    avdsp_chain *d_chains = nullptr;
+    int *d_sec_coef = nullptr, *d_sec_state = nullptr;
+    /* launch groups (device arrays of chain ids) */
+    struct Group { int P; int n; int *d_ids; };
+    std::vector<Group> bq;            /* biquad chains grouped by lanes-per-chain */
+    int *d_fir_ids = nullptr;  int n_fir = 0, max_taps = 0;
+    int *d_pass_ids = nullptr; int n_pass = 0;
+    bool need_xmid = false;
+    int io_in_min = 0, io_in_max = -1, io_out_min = 0, io_out_max = -1;
+};
+
+}  // namespace
+
+struct avdsp_hip_prog {
+    int total_words = 0;
+    int *d_buf = nullptr;
+    std::vector<Plan> plans;
+    float *d_xmid = nullptr; size_t xmid_chains = 0;
+    unsigned *d_in = nullptr, *d_out = nullptr; size_t in_cap = 0, out_cap = 0;   /* host-call staging */
+};
+
+namespace {
+
+int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+template <typename T>
+int upload_vec(T **dst, const std::vector<T> &v)
+{
+    *dst = nullptr;
+    if (v.empty()) return 0;
+    HIP_TRY(hipMalloc((void **)dst, v.size() * sizeof(T)));
+    HIP_TRY(hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+void free_plan(Plan &p)
+{
+    (void)hipFree(p.d_chains); (void)hipFree(p.d_sec_coef); (void)hipFree(p.d_sec_state);
+    for (auto &g : p.bq) (void)hipFree(g.d_ids);
+    (void)hipFree(p.d_fir_ids); (void)hipFree(p.d_pass_ids);
+}
+
+size_t fir_lds_bytes(int max_taps, int tiles, int *hs_cap)
+{
+    const int hs = max_taps + kTapPad;
+    const int W = max_taps + kWinOff + tiles * kTileFrames + 16;
+    *hs_cap = (hs + 3) & ~3;
+    return (size_t)(*hs_cap + W + (W >> 4) + 4) * sizeof(float);
+}
+
+template <int FMT>
+int launch_all(avdsp_hip_prog *prog, Plan &pl, BlockIO io, int fir_impl, int biquad_impl, hipStream_t stream)
+{
+    for (auto &g : pl.bq) {
+        BiquadArgs a{};
+        a.buf = prog->d_buf; a.chains = pl.d_chains; a.sec_coef = pl.d_sec_coef; a.sec_state = pl.d_sec_state;
+        a.group = g.d_ids; a.ngroup = g.n; a.xmid = prog->d_xmid; a.xmid_stride = kFirChunk; a.io = io;
+        if (biquad_impl == 0 || g.P > 64) {
+            hipLaunchKernelGGL(biquad_simple<FMT>, dim3((g.n + 63) / 64), dim3(64), 0, stream, a);
+        } else {
+            const int cpb = kBlock / g.P;
+            const int nblk = (g.n + cpb - 1) / cpb;
+            a.per_xcd = (nblk + 7) / 8;
+            const dim3 grid(a.per_xcd * 8), block(kBlock);
+            switch (g.P) {
+            case 1:  hipLaunchKernelGGL((biquad_pipe<FMT, 1>),  grid, block, 0, stream, a); break;
+            case 2:  hipLaunchKernelGGL((biquad_pipe<FMT, 2>),  grid, block, 0, stream, a); break;
+            case 4:  hipLaunchKernelGGL((biquad_pipe<FMT, 4>),  grid, block, 0, stream, a); break;
+            case 8:  hipLaunchKernelGGL((biquad_pipe<FMT, 8>),  grid, block, 0, stream, a); break;
+            case 16: hipLaunchKernelGGL((biquad_pipe<FMT, 16>), grid, block, 0, stream, a); break;
+            case 32: hipLaunchKernelGGL((biquad_pipe<FMT, 32>), grid, block, 0, stream, a); break;
+            default: hipLaunchKernelGGL((biquad_pipe<FMT, 64>), grid, block, 0, stream, a); break;
+            }
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    if constexpr (FMT != 2) {
+        if (pl.n_fir) {
+            FirArgs a{};
+            a.buf = prog->d_buf; a.chains = pl.d_chains; a.group = pl.d_fir_ids; a.ngroup = pl.n_fir;
+            a.xmid = prog->d_xmid; a.xmid_stride = kFirChunk; a.io = io;
+            a.per_xcd = (pl.n_fir + 7) / 8;
+            const int tiles = (io.nframes + kTileFrames - 1) / kTileFrames;
+            const size_t lds = fir_lds_bytes(pl.max_taps, tiles, &a.hs_cap);
+            if (lds > 160 * 1024) return set_err("FIR of %d taps needs %zu bytes of LDS (limit 160 KiB)", pl.max_taps, lds);
+            auto kern = fir_impl ? fir_mfma<FMT> : fir_plain<FMT>;
+            HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3(a.per_xcd * 8), dim3(64 * tiles), lds, stream, a);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    if (pl.n_pass) {
+        PassArgs a{pl.d_chains, pl.d_pass_ids, pl.n_pass, io};
+        const long long total = (long long)pl.n_pass * io.nframes;
+        const int grid = (int)std::min<long long>((total + kBlock - 1) / kBlock, 2048);
+        hipLaunchKernelGGL(passthrough<FMT>, dim3(grid), dim3(kBlock), 0, stream, a);
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *avdsp_hip_last_error(void) { return g_err; }
+
+int avdsp_hip_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { set_err("hipGetDeviceCount: %s", hipGetErrorString(e)); return 0; }
+    return n;
+}
+
+int avdsp_hip_set_device(int ordinal)
+{
+    HIP_TRY(hipSetDevice(ordinal));
+    return 0;
+}
+
+avdsp_hip_prog *avdsp_hip_prog_create(int total_words)
+{
+    auto *p = new avdsp_hip_prog();
+    p->total_words = total_words;
+    hipError_t e = hipMalloc((void **)&p->d_buf, (size_t)(total_words > 0 ? total_words : 1) * sizeof(int));
+    if (e != hipSuccess) { set_err("hipMalloc(mirror, %d words): %s", total_words, hipGetErrorString(e)); delete p; return nullptr; }
+    return p;
+}
+
+void avdsp_hip_prog_destroy(avdsp_hip_prog *p)
+{
+    if (!p) return;
+    (void)hipDeviceSynchronize();
+    for (auto &pl : p->plans) free_plan(pl);
+    (void)hipFree(p->d_buf); (void)hipFree(p->d_xmid); (void)hipFree(p->d_in); (void)hipFree(p->d_out);
+    delete p;
+}
+
+int avdsp_hip_prog_add_plan(avdsp_hip_prog *prog, const avdsp_plan_desc *d)
+{
+    if (d->format != 2 && d->format != 4 && d->format != 6) return set_err("format %d has no device kernels", d->format);
+    Plan pl;
+    pl.format = d->format; pl.nchains = d->nchains; pl.store_mask = d->store_mask;
+    std::vector<avdsp_chain> chains(d->chains, d->chains + d->nchains);
+    std::vector<int> coef(d->sec_coef_word, d->sec_coef_word + d->nsections);
+    std::vector<int> state(d->sec_state_word, d->sec_state_word + d->nsections);
+    /* every word index the kernels will touch must lie inside the mirror */
+    for (int i = 0; i < d->nsections; i++)
+        if (coef[i] < 0 || coef[i] + 5 > prog->total_words || state[i] < 0 || state[i] + 6 > prog->total_words || (state[i] & 1))
+            return set_err("section %d addresses words outside the loaded buffer", i);
+    std::vector<std::vector<int>> byP(8);
+    std::vector<int> fir, pass;
+    pl.io_in_min = pl.io_out_min = 0x7FFFFFFF; pl.io_in_max = pl.io_out_max = -1;
+    for (int i = 0; i < d->nchains; i++) {
+        const avdsp_chain &c = chains[i];
+        if (c.sec_base < 0 || c.nsec < 0 || c.sec_base + c.nsec > d->nsections) return set_err("chain %d: bad section range", i);
+        if (c.n_out < 1 || c.n_out > AVDSP_MAX_STORES || c.in_io < 0) return set_err("chain %d: bad IO", i);
+        pl.io_in_min = std::min(pl.io_in_min, c.in_io); pl.io_in_max = std::max(pl.io_in_max, c.in_io);
+        for (int k = 0; k < c.n_out; k++) {
+            if (c.out_io[k] < 0) return set_err("chain %d: bad IO", i);
+            pl.io_out_min = std::min(pl.io_out_min, c.out_io[k]); pl.io_out_max = std::max(pl.io_out_max, c.out_io[k]);
+        }
+        if (c.fir_taps) {
+            if (d->format == 2) return set_err("chain %d: FIR has no int64 definition", i);
+            if (c.fir_coef_word < 0 || c.fir_coef_word + c.fir_taps > prog->total_words ||
+                c.fir_state_word < 0 || c.fir_state_word + c.fir_taps > prog->total_words)
+                return set_err("chain %d: FIR addresses words outside the loaded buffer", i);
+            fir.push_back(i);
+            pl.max_taps = std::max(pl.max_taps, c.fir_taps);
+            if (c.nsec) pl.need_xmid = true;
+        }
+        if (c.nsec) {
+            int P = pow2ceil(c.nsec), idx = 0;
+            while ((1 << idx) < P) idx++;
+            if (idx > 7) idx = 7;                        /* > 64 sections: biquad_simple */
+            byP[idx].push_back(i);
+        } else if (!c.fir_taps) pass.push_back(i);
+    }
+    if (upload_vec(&pl.d_chains, chains) || upload_vec(&pl.d_sec_coef, coef) || upload_vec(&pl.d_sec_state, state)) { free_plan(pl); return -1; }
+    for (int idx = 0; idx < 8; idx++)
+        if (!byP[idx].empty()) {
+            Plan::Group g{idx == 7 ? 128 : (1 << idx), (int)byP[idx].size(), nullptr};
+            if (upload_vec(&g.d_ids, byP[idx])) { free_plan(pl); return -1; }
+            pl.bq.push_back(g);
+        }
+    pl.n_fir = (int)fir.size(); pl.n_pass = (int)pass.size();
+    if (upload_vec(&pl.d_fir_ids, fir) || upload_vec(&pl.d_pass_ids, pass)) { free_plan(pl); return -1; }
+    if (pl.need_xmid && prog->xmid_chains < (size_t)d->nchains) {
+        (void)hipFree(prog->d_xmid); prog->d_xmid = nullptr; prog->xmid_chains = 0;
+        hipError_t e = hipMalloc((void **)&prog->d_xmid, (size_t)d->nchains * kFirChunk * sizeof(float));
+        if (e != hipSuccess) { free_plan(pl); return set_err("hipMalloc(xmid): %s", hipGetErrorString(e)); }
+        prog->xmid_chains = (size_t)d->nchains;
+    }
+    prog->plans.push_back(pl);
+    return (int)prog->plans.size() - 1;
+}
+
+static int check_range(avdsp_hip_prog *p, int first, int n)
+{
+    if (first < 0 || n < 0 || first + n > p->total_words) return set_err("word range [%d,%d) outside the mirror (%d words)", first, first + n, p->total_words);
+    return 0;
+}
+
+int avdsp_hip_upload_words(avdsp_hip_prog *p, const int32_t *host_buf, int first, int n)
+{
+    if (check_range(p, first, n)) return -1;
+    if (n) HIP_TRY(hipMemcpy(p->d_buf + first, host_buf + first, (size_t)n * 4, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int avdsp_hip_download_words(avdsp_hip_prog *p, int32_t *host_buf, int first, int n)
+{
+    if (check_range(p, first, n)) return -1;
+    HIP_TRY(hipDeviceSynchronize());
+    if (n) HIP_TRY(hipMemcpy(host_buf + first, p->d_buf + first, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int avdsp_hip_zero_words(avdsp_hip_prog *p, int first, int n)
+{
+    if (check_range(p, first, n)) return -1;
+    if (n) HIP_TRY(hipMemset(p->d_buf + first, 0, (size_t)n * 4));
+    return 0;
+}
+
+int avdsp_hip_run_block(avdsp_hip_prog *prog, int plan, const void *d_in, int in_stride, int in_io_base,
+                        void *d_out, int out_stride, int out_io_base, int nframes,
+                        int fir_impl, int biquad_impl, void *stream)
+{
+    if (plan < 0 || plan >= (int)prog->plans.size()) return set_err("bad plan id %d", plan);
+    Plan &pl = prog->plans[plan];
+    if (nframes <= 0) return 0;
+    /* the kernels index the sample blocks with the chains' IO numbers: check the windows once here */
+    if (pl.io_in_min < in_io_base || pl.io_in_max >= in_io_base + in_stride)
+        return set_err("input window IO [%d,%d) does not cover the IOs the core loads [%d,%d]", in_io_base, in_io_base + in_stride, pl.io_in_min, pl.io_in_max);
+    if (pl.io_out_min < out_io_base || pl.io_out_max >= out_io_base + out_stride)
+        return set_err("output window IO [%d,%d) does not cover the IOs the core stores [%d,%d]", out_io_base, out_io_base + out_stride, pl.io_out_min, pl.io_out_max);
+    for (int f0 = 0; f0 < nframes; f0 += kFirChunk) {
+        BlockIO io;
+        io.in = (const unsigned *)d_in + (size_t)f0 * in_stride;  io.in_stride = in_stride;   io.in_base = in_io_base;
+        io.out = (unsigned *)d_out + (size_t)f0 * out_stride;     io.out_stride = out_stride; io.out_base = out_io_base;
+        io.nframes = std::min(kFirChunk, nframes - f0);
+        io.store_mask = pl.store_mask;
+        int rc;
+        switch (pl.format) {
+        case 2:  rc = launch_all<2>(prog, pl, io, fir_impl, biquad_impl, (hipStream_t)stream); break;
+        case 4:  rc = launch_all<4>(prog, pl, io, fir_impl, biquad_impl, (hipStream_t)stream); break;
+        default: rc = launch_all<6>(prog, pl, io, fir_impl, biquad_impl, (hipStream_t)stream); break;
+        }
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int avdsp_hip_run_block_host(avdsp_hip_prog *prog, int plan, const void *h_in, int in_stride, int in_io_base,
+                             void *h_out, int out_stride, int out_io_base, int nframes,
+                             int fir_impl, int biquad_impl)
+{
+    if (plan < 0 || plan >= (int)prog->plans.size()) return set_err("bad plan id %d", plan);
+    Plan &pl = prog->plans[plan];
+    if (in_stride == 0 && out_stride == 0) {
+        /* single-frame dspRuntime_N(): both windows are the caller's samples[] array, IO 0 .. span */
+        in_stride = out_stride = std::max(pl.io_in_max, pl.io_out_max) + 1;
+        in_io_base = out_io_base = 0;
+    }
+    const size_t in_words = (size_t)nframes * in_stride, out_words = (size_t)nframes * out_stride;
+    if (prog->in_cap < in_words) {
+        (void)hipFree(prog->d_in); prog->d_in = nullptr; prog->in_cap = 0;
+        HIP_TRY(hipMalloc((void **)&prog->d_in, in_words * 4)); prog->in_cap = in_words;
+    }
+    if (prog->out_cap < out_words) {
+        (void)hipFree(prog->d_out); prog->d_out = nullptr; prog->out_cap = 0;
+        HIP_TRY(hipMalloc((void **)&prog->d_out, out_words * 4)); prog->out_cap = out_words;
+    }
+    HIP_TRY(hipMemcpy(prog->d_in, h_in, in_words * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(prog->d_out, h_out, out_words * 4, hipMemcpyHostToDevice));   /* unstored slots keep their content */
+    if (avdsp_hip_run_block(prog, plan, prog->d_in, in_stride, in_io_base, prog->d_out, out_stride, out_io_base,
+                            nframes, fir_impl, biquad_impl, nullptr)) return -1;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(h_out, prog->d_out, out_words * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int avdsp_hip_synchronize(void *stream)
+{
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,189 @@
+"""Python mirror of the AVDSP runtime interface over the C-ABI library libavdsp_mi355x.so.
+
+Same names, argument meaning and error behaviour as the reference's C API
+(module_avdsp/runtime/dsp_runtime.h:160-164; host call sequence linux/avdsp_plugin.c:309-356,
+linux/dsprun.c:85-132): dspRuntimeInit -> dspFindCore/dspFindCoreBegin -> dspRuntimeReset ->
+dspRuntime_N per frame, plus the block extension declared in include/avdsp_runtime.h.
+
+There is no CPU execution path here.  If the HIP library has not been built, or no GPU is visible,
+the calls raise / return the library's negative error codes -- they never fall back to the oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libavdsp_mi355x.so")
+CSRC = os.path.join(HERE, "csrc")
+
+EXPORTED = [
+    # reference API
+    "dspFindCore", "dspFindCoreBegin", "dspRuntimeReset", "dspRuntimeInit",
+    "dspRuntime_2", "dspRuntime_4", "dspRuntime_6",
+    "dspHeaderPtr", "dspBiquadFreqSkip", "dspMantissa", "dspOpcodeText", "dspQNM", "dspQM64", "dspQM32",
+    # block extension (include/avdsp_runtime.h)
+    "dspRuntimeBlock_2", "dspRuntimeBlock_4", "dspRuntimeBlock_6", "dspRuntimeBlockDevice",
+    "dspRuntimeSyncState", "dspRuntimeUploadState", "dspRuntimeSetOption", "dspRuntimeGetOption",
+    "dspRuntimeCoreInfo", "dspRuntimeLastError", "dspRuntimeRelease",
+    # thin HIP ABI (include/avdsp_hip.h)
+    "avdsp_hip_device_count", "avdsp_hip_set_device", "avdsp_hip_prog_create", "avdsp_hip_prog_destroy",
+    "avdsp_hip_prog_add_plan", "avdsp_hip_upload_words", "avdsp_hip_download_words", "avdsp_hip_zero_words",
+    "avdsp_hip_run_block", "avdsp_hip_run_block_host", "avdsp_hip_synchronize", "avdsp_hip_last_error",
+]
+
+
+class AvdspError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"[{code}] {msg}")
+        self.code = code
+
+
+def build(force: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 + gcc via avdsp_amd/csrc/Makefile (cross-compiles without a GPU)."""
+    args = ["make", "-C", CSRC]
+    if force:
+        subprocess.check_call(args + ["clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load the C-ABI library; raises if it is missing (there is no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(
+                f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or make -C avdsp_amd/csrc).  The product path has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        vp, i32 = C.c_void_p, C.c_int
+        L.dspFindCore.restype = vp; L.dspFindCore.argtypes = [vp, i32]
+        L.dspFindCoreBegin.restype = vp; L.dspFindCoreBegin.argtypes = [vp]
+        L.dspRuntimeReset.restype = i32; L.dspRuntimeReset.argtypes = [i32, i32, i32]
+        L.dspRuntimeInit.restype = i32; L.dspRuntimeInit.argtypes = [vp, i32, i32, i32, i32]
+        for n in ("dspRuntime_2", "dspRuntime_4", "dspRuntime_6"):
+            f = getattr(L, n); f.restype = i32; f.argtypes = [vp, vp, vp]
+        for n in ("dspRuntimeBlock_2", "dspRuntimeBlock_4", "dspRuntimeBlock_6"):
+            f = getattr(L, n); f.restype = i32; f.argtypes = [vp, vp, vp, i32, i32, vp, i32, i32, i32]
+        L.dspRuntimeBlockDevice.restype = i32
+        L.dspRuntimeBlockDevice.argtypes = [i32, vp, vp, vp, i32, i32, vp, i32, i32, i32, vp]
+        L.dspRuntimeSyncState.restype = i32; L.dspRuntimeSyncState.argtypes = [vp]
+        L.dspRuntimeUploadState.restype = i32; L.dspRuntimeUploadState.argtypes = [vp]
+        L.dspRuntimeSetOption.restype = i32; L.dspRuntimeSetOption.argtypes = [C.c_char_p, i32]
+        L.dspRuntimeGetOption.restype = i32; L.dspRuntimeGetOption.argtypes = [C.c_char_p]
+        L.dspRuntimeCoreInfo.restype = i32
+        L.dspRuntimeCoreInfo.argtypes = [i32, vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+        L.dspRuntimeLastError.restype = C.c_char_p
+        L.dspRuntimeRelease.restype = None
+        L.dspQNM.restype = C.c_longlong; L.dspQNM.argtypes = [C.c_double, i32, i32]
+        L.dspQM64.restype = C.c_longlong; L.dspQM64.argtypes = [C.c_double, i32]
+        L.dspQM32.restype = i32; L.dspQM32.argtypes = [C.c_double, i32]
+        L.avdsp_hip_device_count.restype = i32
+        L.avdsp_hip_last_error.restype = C.c_char_p
+        L.avdsp_hip_synchronize.restype = i32; L.avdsp_hip_synchronize.argtypes = [vp]
+        _lib = L
+    return _lib
+
+
+def sample_dtype(fmt: int):
+    return np.float32 if fmt == 6 else np.int32
+
+
+class Runtime:
+    """One loaded program (the library, like the reference, holds one program per process).
+
+    `buf` is the caller-owned contiguous int32 buffer: program words then the state area."""
+
+    def __init__(self, fmt: int, prog_words: np.ndarray, fs: int = 48000, random: int = 0,
+                 dither: int = 31, max_size: int | None = None):
+        if fmt not in (2, 4, 6):
+            raise ValueError("device entry points exist for DSP_FORMAT 2, 4 and 6")
+        self.L = lib()
+        self.fmt = fmt
+        n = int(prog_words[1]) + max(int(np.int32(prog_words[2])), 0)
+        self.buf = np.zeros(max(n, len(prog_words)) + 64, dtype=np.uint32)
+        self.buf[:len(prog_words)] = prog_words
+        self.rc = self.L.dspRuntimeInit(self.buf.ctypes.data, n if max_size is None else max_size,
+                                        fs, random, dither)
+        self.cores = []
+        if self.rc >= 0:
+            self.rundata = self.buf.ctypes.data + 4 * self.rc
+            k = 1
+            while True:
+                p = self.L.dspFindCore(self.buf.ctypes.data, k)
+                if not p:
+                    break
+                self.cores.append(self.L.dspFindCoreBegin(p))
+                k += 1
+
+    # -- helpers ---------------------------------------------------------------------------
+    def last_error(self) -> str:
+        return self.L.dspRuntimeLastError().decode()
+
+    def _check(self, rc: int) -> int:
+        if rc < 0:
+            raise AvdspError(rc, self.last_error())
+        return rc
+
+    @property
+    def state(self) -> np.ndarray:
+        return self.buf[self.rc:self.rc + int(self.buf[2])]
+
+    def reset(self, fs: int, random: int = 0, dither: int = 31) -> int:
+        return self.L.dspRuntimeReset(fs, random, dither)
+
+    def set_option(self, key: str, value: int):
+        self._check(self.L.dspRuntimeSetOption(key.encode(), value))
+
+    def core_info(self, core_index: int = 0):
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        self._check(self.L.dspRuntimeCoreInfo(self.fmt, self.cores[core_index], C.byref(a), C.byref(b), C.byref(c)))
+        return dict(chains=a.value, max_sections=b.value, max_taps=c.value)
+
+    # -- execution -------------------------------------------------------------------------
+    def run_frame(self, samples: np.ndarray, core_index: int = 0) -> int:
+        """dspRuntime_N: one frame, samples[] indexed by IO number, updated in place."""
+        assert samples.dtype == sample_dtype(self.fmt) and samples.flags.c_contiguous
+        f = getattr(self.L, f"dspRuntime_{self.fmt}")
+        return self._check(f(self.cores[core_index], self.rundata, samples.ctypes.data))
+
+    def run_block(self, x: np.ndarray, out_stride: int, in_io_base: int, out_io_base: int = 0,
+                  out: np.ndarray | None = None, block: int | None = None) -> np.ndarray:
+        """dspRuntimeBlock_N over host buffers; cores outer, frames inner per block of `block` frames."""
+        x = np.ascontiguousarray(x, dtype=sample_dtype(self.fmt))
+        nframes, in_stride = x.shape
+        if out is None:
+            out = np.zeros((nframes, out_stride), dtype=sample_dtype(self.fmt))
+        f = getattr(self.L, f"dspRuntimeBlock_{self.fmt}")
+        block = block or nframes
+        for b0 in range(0, nframes, block):
+            b1 = min(b0 + block, nframes)
+            for core in self.cores:
+                self._check(f(core, self.rundata, x[b0:b1].ctypes.data, in_stride, in_io_base,
+                              out[b0:b1].ctypes.data, out_stride, out_io_base, b1 - b0))
+        return out
+
+    def run_block_device(self, d_in_ptr: int, in_stride: int, in_io_base: int, d_out_ptr: int,
+                         out_stride: int, out_io_base: int, nframes: int, stream: int = 0,
+                         core_index: int = 0) -> int:
+        """dspRuntimeBlockDevice: in/out already in HBM (raw device pointers, e.g. tensor.data_ptr())."""
+        return self._check(self.L.dspRuntimeBlockDevice(
+            self.fmt, self.cores[core_index], self.rundata, d_in_ptr, in_stride, in_io_base,
+            d_out_ptr, out_stride, out_io_base, nframes, stream))
+
+    def sync_state(self) -> np.ndarray:
+        self._check(self.L.dspRuntimeSyncState(self.rundata))
+        return self.state
+
+    def upload_state(self):
+        self._check(self.L.dspRuntimeUploadState(self.rundata))
+
+    def release(self):
+        self.L.dspRuntimeRelease()

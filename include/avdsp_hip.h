@@ -1,0 +1,89 @@
+/*
+ * avdsp_hip.h -- the thin C ABI between the C host runtime (avdsp_amd/csrc/avdsp_host.c) and the
+ * hand-written gfx950 kernels (avdsp_amd/csrc/avdsp_kernels.hip).  Plain pointers and sizes only.
+ *
+ * The host side lowers one DSP core (dsp_runtime.c:302-1314 restricted to channel-independent
+ * chains) into an avdsp_plan_desc; the device side keeps a mirror of the caller's buffer
+ * (program words + state area, same word layout as on the host) and runs
+ *
+ *     LOAD | LOAD_GAIN  ->  BIQUADS cascade  ->  [FIR]  ->  [SAT0DB]  ->  STORE
+ *     (dsp_runtime.c:565-607, 827-849 + dsp_biquadSTD.h:25-119, 928-969 + dsp_firSTD.h:38-52,
+ *      464-475, 610-633)
+ *
+ * for every chain of the core over a block of frame-interleaved samples.
+ */
+#ifndef AVDSP_HIP_H_
+#define AVDSP_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AVDSP_MAX_STORES 4
+
+/* how the accumulator is loaded at the head of a chain */
+enum { AVDSP_LOAD_PLAIN = 0, AVDSP_LOAD_GAIN = 1 };
+
+/* One channel chain.  All *_word fields are absolute word indices into the caller's buffer
+ * (program words first, state area from word `totalLength`).                                    */
+typedef struct avdsp_chain {
+    int32_t  in_io;                  /* IO number read by LOAD / LOAD_GAIN                       */
+    int32_t  load_mode;              /* AVDSP_LOAD_*                                             */
+    uint32_t gain_bits;              /* Q4.28 int or float bits of the LOAD_GAIN parameter       */
+    int32_t  nsec;                   /* biquad sections in cascade order (banks concatenated)    */
+    int32_t  sec_base;               /* first entry of this chain in sec_coef_word/sec_state_word */
+    int32_t  fir_taps;               /* 0 = no FIR                                               */
+    int32_t  fir_coef_word;          /* first tap (the word after the length word)               */
+    int32_t  fir_state_word;         /* FIR delay line, fir_taps words, st[i] = x[n-1-i]         */
+    int32_t  sat;                    /* SAT0DB in front of the stores                            */
+    int32_t  n_out;                  /* number of STOREs (same value to each)                    */
+    int32_t  out_io[AVDSP_MAX_STORES];
+} avdsp_chain;
+
+typedef struct avdsp_plan_desc {
+    int32_t  format;                 /* 2, 4 or 6                                                */
+    int32_t  nchains;
+    const avdsp_chain *chains;
+    int32_t  nsections;              /* total over chains                                        */
+    const int32_t *sec_coef_word;    /* per section: word index of b0 for the CURRENT sample rate */
+    const int32_t *sec_state_word;   /* per section: word index of its 6 state words             */
+    int32_t  store_mask;             /* tpdf mask applied by STORE in int-sample formats         */
+} avdsp_plan_desc;
+
+/* A loaded program on the device: the mirror of the caller's buffer plus one plan per lowered core */
+typedef struct avdsp_hip_prog avdsp_hip_prog;
+
+/* all functions: 0 / non-NULL / id >= 0 on success; on failure a negative code / NULL and a message
+ * in avdsp_hip_last_error()                                                                     */
+int             avdsp_hip_device_count(void);
+int             avdsp_hip_set_device(int ordinal);
+avdsp_hip_prog *avdsp_hip_prog_create(int total_words);
+void            avdsp_hip_prog_destroy(avdsp_hip_prog *prog);
+int             avdsp_hip_prog_add_plan(avdsp_hip_prog *prog, const avdsp_plan_desc *desc);   /* plan id */
+
+/* mirror maintenance: word ranges of the caller's buffer */
+int avdsp_hip_upload_words(avdsp_hip_prog *prog, const int32_t *host_buf, int first_word, int nwords);
+int avdsp_hip_download_words(avdsp_hip_prog *prog, int32_t *host_buf, int first_word, int nwords);
+int avdsp_hip_zero_words(avdsp_hip_prog *prog, int first_word, int nwords);
+
+/* one block; d_in/d_out are device pointers to frame-interleaved 32-bit samples; asynchronous on
+ * `stream` (hipStream_t as void*).  fir_impl / biquad_impl: see dspRuntimeSetOption.            */
+int avdsp_hip_run_block(avdsp_hip_prog *prog, int plan, const void *d_in, int in_stride, int in_io_base,
+                        void *d_out, int out_stride, int out_io_base, int nframes,
+                        int fir_impl, int biquad_impl, void *stream);
+
+/* host-buffer convenience: stages in/out through device scratch and synchronises               */
+int avdsp_hip_run_block_host(avdsp_hip_prog *prog, int plan, const void *h_in, int in_stride, int in_io_base,
+                             void *h_out, int out_stride, int out_io_base, int nframes,
+                             int fir_impl, int biquad_impl);
+
+int avdsp_hip_synchronize(void *stream);
+const char *avdsp_hip_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AVDSP_HIP_H_ */

@@ -1,0 +1,103 @@
+/*
+ * avdsp_runtime.h -- C ABI of the MI355X-native AVDSP runtime (libavdsp_mi355x.so).
+ *
+ * Drop-in boundary: the five functions and the exported data below are exactly what the reference
+ * runtime exports (module_avdsp/runtime/dsp_runtime.h:160-164, dsp_runtime.c:36-38,
+ * dsp_header.c:10-86), so the reference hosts (linux/avdsp_plugin.c:126,178,316,328,336,
+ * linux/dsprun.c:92,104,112,166, osx/dsprunosx.c:61,72,73,91) link against it unchanged.
+ * The reference builds one library per DSP_FORMAT; this library carries the _2, _4 and _6 entry
+ * points side by side (int64 / double+int samples / double+float samples).
+ *
+ * Everything that computes runs on the GPU (hand-written gfx950 kernels behind avdsp_hip.h).
+ * There is NO CPU execution path in this library: a core that cannot be lowered to the device
+ * kernels, a missing GPU, or a HIP error makes the call return a negative code and leaves a message
+ * in dspRuntimeLastError().  (A CPU restatement exists under oracle/ -- test infrastructure only.)
+ *
+ * Ownership is the reference's: the caller owns ONE contiguous int32 buffer holding the program
+ * followed by the state ("data") area, dspRuntimeInit returns the program length so that
+ * rundata = (int*)code + return value.  The device keeps a mirror of that buffer; state lives on
+ * the device between blocks and is copied back by dspRuntimeSyncState() (checkpoint) or pushed by
+ * dspRuntimeUploadState() (restore).
+ */
+#ifndef AVDSP_RUNTIME_H_
+#define AVDSP_RUNTIME_H_
+
+#include "avdsp_format.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------- reference API (names, arguments, return codes unchanged) ---------------- */
+
+/* dsp_runtime.c:42-59  -- numCore counts from 1; returns the DSP_CORE word (or the program start
+ * when the program has no DSP_CORE and numCore... == first lookup), NULL when not found.          */
+opcode_t *dspFindCore(opcode_t *codePtr, const int numCore);
+
+/* dsp_runtime.c:62-77  -- skips CORE/NOP/PARAM/PARAM_NUM words in front of the executable part.   */
+opcode_t *dspFindCoreBegin(opcode_t *ptr);
+
+/* dsp_runtime.c:116-145 -- selects the sample-rate column, zeroes the state area (host mirror and
+ * device), seeds dither.  0 ok, -1 unsupported fs, -2 fs outside the program's range.            */
+int dspRuntimeReset(const int fs, int random, int defaultDither);
+
+/* dsp_runtime.c:150-195 -- validates header, size, checksum, opcode level.  >= 0: program length in
+ * words; -1 no header, -3 no cores, -4 checksum, -5 opcode too new, -6 buffer too small, or Reset's
+ * code when fs != 0.  Extension: -7 when the program's encoding (header.format: 28 = Q28 integer,
+ * 0 = float) would need dspChangeFormat for the entry point used later.          */
+int dspRuntimeInit(opcode_t *codePtr, int maxSize, const int fs, int random, int defaultDither);
+
+/* dsp_runtime.c:302-1314 -- one frame: samples[] is indexed by the program's IO numbers and is
+ * read and written in place.  Returns 0 like the reference on success; negative on failure
+ * (the reference cannot fail here; this implementation can: no GPU, core not lowerable).         */
+int dspRuntime_2(opcode_t *core, int *rundata, int   *samples);   /* DSP_FORMAT_INT64        */
+int dspRuntime_4(opcode_t *core, int *rundata, int   *samples);   /* DSP_FORMAT_DOUBLE       */
+int dspRuntime_6(opcode_t *core, int *rundata, float *samples);   /* DSP_FORMAT_DOUBLE_FLOAT */
+
+extern dspHeader_t *dspHeaderPtr;           /* dsp_runtime.c:36 */
+extern int          dspBiquadFreqSkip;      /* dsp_runtime.c:37 */
+extern int          dspMantissa;            /* dsp_runtime.c:38 */
+extern const char  *dspOpcodeText[DSP_MAX_OPCODE];                 /* dsp_header.c:10-73 */
+long long dspQNM(double x, int n, int m);   /* dsp_header.c:75-77 */
+long long dspQM64(double x, int m);         /* dsp_header.c:79-81 */
+int       dspQM32(double x, int m);         /* dsp_header.c:83-85 */
+
+/* ---------------- block extension (not in the reference) ----------------
+ * Semantics: exactly nframes successive dspRuntime_N() calls over frame-interleaved buffers, i.e.
+ * the host loop of linux/avdsp_plugin.c:98-141 for 32-bit samples:
+ *     samples[in_io_base + k]  = in[n*in_stride + k]          k in [0, in_stride)
+ *     dspRuntime_N(core, rundata, samples)
+ *     out[n*out_stride + k]    = samples[out_io_base + k]     k in [0, out_stride)
+ * Output slots the core never stores are left untouched.  in/out are HOST pointers here.         */
+int dspRuntimeBlock_2(opcode_t *core, int *rundata, const int *in, int in_stride, int in_io_base,
+                      int *out, int out_stride, int out_io_base, int nframes);
+int dspRuntimeBlock_4(opcode_t *core, int *rundata, const int *in, int in_stride, int in_io_base,
+                      int *out, int out_stride, int out_io_base, int nframes);
+int dspRuntimeBlock_6(opcode_t *core, int *rundata, const float *in, int in_stride, int in_io_base,
+                      float *out, int out_stride, int out_io_base, int nframes);
+
+/* Same, with in/out resident in HBM (device pointers) and the work enqueued on `stream`
+ * (a hipStream_t passed as void*, NULL = default stream).  Asynchronous: returns after enqueue. */
+int dspRuntimeBlockDevice(int format, opcode_t *core, int *rundata,
+                          const void *d_in, int in_stride, int in_io_base,
+                          void *d_out, int out_stride, int out_io_base, int nframes, void *stream);
+
+/* device state -> rundata (the buffer stays the checkpoint) / rundata -> device state (restore) */
+int dspRuntimeSyncState(int *rundata);
+int dspRuntimeUploadState(const int *rundata);
+
+/* Tunables: "fir_impl" 0 = plain tap loop, 1 = MFMA (default); "biquad_impl" 0 = lane per channel,
+ * 1 = section-pipelined (default); "device" = HIP device ordinal (before the first block).      */
+int dspRuntimeSetOption(const char *key, int value);
+int dspRuntimeGetOption(const char *key);
+
+/* Introspection of the lowered core (what the device plan contains); negative when not lowerable. */
+int dspRuntimeCoreInfo(int format, opcode_t *core, int *nchains, int *max_sections, int *max_taps);
+
+const char *dspRuntimeLastError(void);
+void        dspRuntimeRelease(void);        /* frees device memory; the next Init starts clean */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AVDSP_RUNTIME_H_ */

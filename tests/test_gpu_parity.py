@@ -1,0 +1,323 @@
+"""Parity of the HIP path (through the C-ABI library) against
+  (1) the golden vectors the compiled reference produced (tests/golden/), and
+  (2) the oracle (oracle/liboracle.so) on the same seeded inputs at other shapes.
+
+Bar: bit-exact for DSP_FORMAT 2 (int64 fixed point) outputs AND state; for the float models
+(4, 6) the north-star tolerance is 1e-6 relative (to the block's peak magnitude) -- the tests assert
+that tolerance everywhere and, where the kernel performs the reference's operations in the
+reference's order (biquad cascade, plain FIR, and the MFMA FIR whose K index ascends with the tap
+index), additionally assert bit equality."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from avdsp_amd import progbuilder as pb
+from avdsp_amd import runtime as rt
+from oracle import pyoracle as po
+from tests.golden_recipes import GOLDEN_DIR, make_input, make_program
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-6          # north_star: "within 1e-6 relative in its float mode"
+
+with open(os.path.join(GOLDEN_DIR, "manifest.json")) as _f:
+    MANIFEST = json.load(_f)
+
+DEVICE_CASES = [c for c in MANIFEST["cases"] if c["fmt"] in (2, 4, 6) and c["program"]["kind"] == "synth"]
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def assert_close(got, want, fmt, exact=True, what="output"):
+    g, w = got.view(np.uint32), want.view(np.uint32)
+    if fmt == 2:
+        assert (g == w).all(), f"{what}: int64 mode must be bit-exact ({np.count_nonzero(g != w)} words differ)"
+        return
+    if fmt == 4:
+        # int32 samples out of a double accumulator: 1 LSB of s.31 is far below 1e-6 relative
+        d = np.abs(got.astype(np.int64) - want.astype(np.int64)).max()
+        peak = max(np.abs(want.astype(np.int64)).max(), 1)
+        assert d <= REL_TOL * peak, f"{what}: max abs diff {d} vs peak {peak}"
+    else:
+        d = np.abs(got.astype(np.float64) - want.astype(np.float64)).max()
+        peak = max(np.abs(want.astype(np.float64)).max(), 1e-30)
+        assert d <= REL_TOL * peak, f"{what}: max abs diff {d} vs peak {peak}"
+    if exact:
+        assert (g == w).all(), f"{what}: expected bit-exact, {np.count_nonzero(g != w)} words differ"
+
+
+@pytest.fixture(autouse=True)
+def _release():
+    yield
+    rt.lib().dspRuntimeRelease()
+
+
+@pytest.mark.parametrize("case", DEVICE_CASES, ids=lambda c: c["name"])
+@pytest.mark.parametrize("impl", ["default", "simple_plain"])
+def test_golden(case, impl):
+    fmt = case["fmt"]
+    prog = make_program(case["program"])
+    x = make_input(case["input"], fmt)
+    r = rt.Runtime(fmt, prog, fs=case["fs"], random=case["random"], dither=case["dither"])
+    assert r.rc == case["init_rc"]
+    if impl == "simple_plain":
+        r.set_option("biquad_impl", 0)
+        r.set_option("fir_impl", 0)
+    else:
+        r.set_option("biquad_impl", 1)
+        r.set_option("fir_impl", 1)
+    out = r.run_block(x, case["out_stride"], case["in_base"], case["out_base"], block=case["block"])
+    g = np.load(os.path.join(GOLDEN_DIR, case["name"] + ".npz"))
+    assert_close(out[:16], g["head"], fmt, what="head")
+    assert_close(out[-16:], g["tail"], fmt, what="tail")
+    state = r.sync_state()
+    if case["full"]:
+        assert_close(out, g["out"], fmt)
+        assert (state == g["state"]).all(), "state area differs from the reference's"
+    assert sha(out) == case["out_sha"]
+    assert sha(state) == case["state_sha"]
+
+
+def _oracle_vs_device(fmt, prog, x, out_stride, in_base, blocks, fs=48000, dither=31, opts=None, exact=True):
+    o = po.OracleProgram(fmt, prog, fs=fs, dither=dither)
+    r = rt.Runtime(fmt, prog, fs=fs, dither=dither)
+    assert r.rc == o.rc
+    for k, v in (opts or {}).items():
+        r.set_option(k, v)
+    pos = 0
+    for b in blocks:
+        xo = x[pos:pos + b]
+        want = o.run_block(xo, out_stride, in_base)
+        got = r.run_block(xo, out_stride, in_base)
+        assert_close(got, want, fmt, exact=exact, what=f"block at frame {pos}")
+        pos += b
+    assert (r.sync_state() == o.state).all(), "state differs after the last block"
+    return r
+
+
+@pytest.mark.parametrize("fmt", [2, 4, 6])
+@pytest.mark.parametrize("channels,sections", [(1, 1), (3, 2), (8, 8), (37, 5), (64, 16), (5, 16), (2, 24), (2, 40)])
+def test_biquad_vs_oracle_ragged_blocks(fmt, channels, sections):
+    """State must carry across blocks of uneven size (1-frame, odd, > prefetch depth)."""
+    prog = pb.synth_program(fmt, channels, sections)
+    blocks = [1, 7, 16, 100, 33, 1, 2]
+    x = pb.lcg_input(sum(blocks), channels, fmt == 6, seed=99 + channels)
+    _oracle_vs_device(fmt, prog, x, channels, channels, blocks)
+
+
+@pytest.mark.parametrize("fmt", [4, 6])
+@pytest.mark.parametrize("taps", [1, 2, 7, 64, 255, 300, 1025])
+@pytest.mark.parametrize("fir_impl", [0, 1])
+def test_fir_vs_oracle_ragged_blocks(fmt, taps, fir_impl):
+    prog = pb.synth_program(fmt, 3, 0, taps)
+    blocks = [1, 5, 256, 257, 40, 1030]
+    x = pb.lcg_input(sum(blocks), 3, fmt == 6, seed=5 + taps)
+    _oracle_vs_device(fmt, prog, x, 3, 3, blocks, opts={"fir_impl": fir_impl})
+
+
+@pytest.mark.parametrize("fmt", [4, 6])
+def test_mixed_chain_vs_oracle(fmt):
+    prog = pb.synth_program(fmt, 6, 4, 129)
+    blocks = [300, 1, 64, 700]
+    x = pb.lcg_input(sum(blocks), 6, fmt == 6, seed=77)
+    _oracle_vs_device(fmt, prog, x, 6, 6, blocks)
+
+
+@pytest.mark.parametrize("fmt", [2, 4, 6])
+def test_saturation_and_fullscale(fmt):
+    prog = pb.synth_program(fmt, 8, 8, gain=7.5)
+    x = make_input(dict(kind="fullscale", frames=300, channels=8), fmt)
+    _oracle_vs_device(fmt, prog, x, 8, 8, [300])
+
+
+@pytest.mark.parametrize("fmt", [2, 4, 6])
+def test_single_frame_entry_point(fmt):
+    """dspRuntime_N(core, rundata, samples): one frame, samples[] indexed by IO number, in place."""
+    C, S = 4, 3
+    prog = pb.synth_program(fmt, C, S)
+    o = po.OracleProgram(fmt, prog)
+    r = rt.Runtime(fmt, prog)
+    x = pb.lcg_input(12, C, fmt == 6, seed=3)
+    for n in range(12):
+        frame_o = np.zeros(2 * C, dtype=rt.sample_dtype(fmt)); frame_o[C:] = x[n]
+        frame_d = frame_o.copy()
+        po.lib().oracle_run(o.ctx, o.cores[0], o.data_ptr, frame_o.ctypes.data)
+        assert r.run_frame(frame_d) == 0
+        assert_close(frame_d, frame_o, fmt, what=f"frame {n}")
+    assert (r.sync_state() == o.state).all()
+
+
+@pytest.mark.parametrize("fmt", [2, 6])
+def test_checkpoint_restore(fmt):
+    """The caller's buffer is the checkpoint: sync, copy, reload elsewhere, continue -> same stream."""
+    prog = pb.synth_program(fmt, 5, 4, 0 if fmt == 2 else 33)
+    x = pb.lcg_input(400, 5, fmt == 6, seed=11)
+    r = rt.Runtime(fmt, prog)
+    first = r.run_block(x[:150], 5, 5)
+    saved = r.sync_state().copy()
+    rest = r.run_block(x[150:], 5, 5)
+    r.release()
+    r2 = rt.Runtime(fmt, prog)
+    r2.state[:] = saved
+    r2.upload_state()
+    rest2 = r2.run_block(x[150:], 5, 5)
+    assert (rest.view(np.uint32) == rest2.view(np.uint32)).all()
+    assert first.shape == (150, 5)
+
+
+def test_bypass_and_multi_bank_and_plain_load():
+    """LOAD (no gain), two banks in one chain (second bypassed), two STOREs of one value."""
+    fmt = 6
+    pw = pb.ProgramWriter(fmt)
+    pw.core()
+    pw.param()
+    b1 = pw.biquad_bank(pb.synth_sections(0, 2, pb.F48000, pb.F48000))
+    pw.param()
+    b2 = pw.biquad_bank(pb.synth_sections(1, 3, pb.F48000, pb.F48000), bypass=0)
+    pw.param()
+    b3 = pw.biquad_bank(pb.synth_sections(2, 1, pb.F48000, pb.F48000))
+    pw.load(4)
+    pw.biquads(b1, 2)
+    pw.biquads(b2, 3)
+    pw.biquads(b3, 1)
+    pw.sat0db()
+    pw.store(0)
+    pw.store(2)
+    pw.load_gain_fixed(5, 0.5)
+    pw.store(1)
+    prog = pw.end_of_code()
+    x = pb.lcg_input(200, 2, True, seed=8)
+    o = po.OracleProgram(fmt, prog)
+    r = rt.Runtime(fmt, prog)
+    want = o.run_block(x, 4, 4)
+    got = r.run_block(x, 4, 4)
+    assert_close(got, want, fmt)
+    assert (got[:, 3] == 0).all()           # IO 3 is never stored: untouched
+    assert (r.sync_state() == o.state).all()
+    assert r.core_info() == dict(chains=2, max_sections=3, max_taps=0)
+
+
+def test_refuses_cores_it_cannot_lower():
+    """No CPU fallback: opcodes outside the hot path make the block call fail loudly."""
+    prog = np.fromfile(os.path.join(GOLDEN_DIR, "crossoverLV6.bin"), dtype=np.uint32)
+    r = rt.Runtime(2, prog, fs=48000, dither=24)
+    assert r.rc == 288 and len(r.cores) == 2
+    x = np.zeros((4, 16), dtype=np.int32)
+    with pytest.raises(rt.AvdspError) as e:
+        r.run_block(x, 32, 8)
+    assert e.value.code == -8 and "not lowered" in str(e.value)
+    # int64 FIR is undefined behaviour in the reference: refused, not guessed
+    prog = pb.synth_program(2, 2, 1, 9)
+    r = rt.Runtime(2, prog)
+    with pytest.raises(rt.AvdspError) as e:
+        r.run_block(np.zeros((4, 2), dtype=np.int32), 2, 2)
+    assert e.value.code == -8
+    # float-encoded program through the int64 entry point
+    r = rt.Runtime(2, pb.synth_program(6, 2, 1))
+    with pytest.raises(rt.AvdspError) as e:
+        r.run_block(np.zeros((4, 2), dtype=np.int32), 2, 2)
+    assert e.value.code == -7
+
+
+@pytest.mark.parametrize("neg", MANIFEST["init_return_codes"], ids=lambda n: n["case"])
+def test_init_return_codes_match_reference(neg):
+    good = pb.synth_program(2, 2, 2)
+    prog, fs, max_size = good, 48000, None
+    c = neg["case"]
+    if c == "bad_checksum":
+        prog = good.copy(); prog[3] ^= 1
+    elif c in ("unsupported_fs", "fs_out_of_range"):
+        fs = neg["fs"]
+    elif c == "buffer_too_small":
+        max_size = neg["max_size"]
+    elif c == "no_header":
+        prog = good.copy(); prog[0] = (2 << 16) | 12
+    elif c == "opcode_too_new":
+        prog = good.copy(); prog[6] = (62 << 16) | (int(prog[6]) & 0xFFFF)
+    assert rt.Runtime(2, prog, fs=fs, max_size=max_size).rc == neg["rc"]
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json full sizes: size-independent properties (the oracle would take minutes here)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("fmt", [2, 6])
+def test_full_size_biquad_reblocking_and_sampled_oracle(fmt):
+    """cfg3: 4096 ch x 16 biquads x 1024 frames.  (a) one 1024-frame block == 4 blocks of 256 ==
+    ragged blocks, bit for bit (the recurrence has no block-size dependence); (b) 16 sampled
+    channels equal the oracle run on those channels alone (channels are independent)."""
+    C, S, B = 4096, 16, 1024
+    prog = pb.synth_program(fmt, C, S)
+    x = pb.lcg_input(B, C, fmt == 6)
+    r = rt.Runtime(fmt, prog)
+    whole = r.run_block(x, C, C)
+    st_whole = r.sync_state().copy()
+    r.release()
+    r = rt.Runtime(fmt, prog)
+    parts = np.concatenate([r.run_block(x[a:b], C, C) for a, b in [(0, 256), (256, 512), (512, 513), (513, 1000), (1000, 1024)]])
+    assert (whole.view(np.uint32) == parts.view(np.uint32)).all()
+    assert (r.sync_state() == st_whole).all()
+    pick = [0, 1, 63, 64, 97, 1000, 2047, 2048, 4095, 777, 3333, 15, 16, 17, 255, 256]
+    for c in pick:
+        sub = pb.ProgramWriter(fmt)
+        sub.core(); sub.param()
+        bank = sub.biquad_bank(pb.synth_sections(c, S, pb.F48000, pb.F48000))
+        sub.load_gain_fixed(1, 1.0); sub.biquads(bank, S); sub.sat0db(); sub.store(0)
+        o = po.OracleProgram(fmt, sub.end_of_code())
+        want = o.run_block(np.ascontiguousarray(x[:, c:c + 1]), 1, 1)
+        assert_close(np.ascontiguousarray(whole[:, c:c + 1]), want, fmt, what=f"channel {c}")
+
+
+@pytest.mark.parametrize("fir_impl", [1, 0])
+def test_full_size_fir_impulse_and_reblocking(fir_impl):
+    """cfg4: 256 ch x 4096 taps x 1024 frames, format 6.  (a) an impulse of 2^-2 returns the taps
+    scaled by exactly 2^-2 (one non-zero product per output: exact in any summation order);
+    (b) re-blocking invariance; (c) linearity in exact arithmetic: doubling the input doubles the
+    output bit for bit (power-of-two scaling commutes with every rounding)."""
+    C, T, B = 256, 4096, 1024
+    taps = pb.lcg_taps_all(C, T)
+    prog = pb.synth_program(6, C, 0, T, taps=taps)
+    r = rt.Runtime(6, prog)
+    r.set_option("fir_impl", fir_impl)
+    imp = np.zeros((5 * B, C), dtype=np.float32)
+    imp[3, :] = 0.25
+    y = np.concatenate([r.run_block(imp[k * B:(k + 1) * B], C, C) for k in range(5)])
+    assert (y[:3] == 0).all()
+    assert (y[3:3 + T].T.view(np.uint32) == (taps * np.float32(0.25)).view(np.uint32)).all()
+    assert (y[3 + T:] == 0).all()
+    r.release()
+    x = pb.lcg_input(2 * B, C, True, seed=4)
+    r = rt.Runtime(6, prog); r.set_option("fir_impl", fir_impl)
+    a = np.concatenate([r.run_block(x[:B], C, C), r.run_block(x[B:], C, C)])
+    r.release()
+    r = rt.Runtime(6, prog); r.set_option("fir_impl", fir_impl)
+    b = np.concatenate([r.run_block(x[s:e], C, C) for s, e in [(0, 100), (100, 1124), (1124, 1125), (1125, 2048)]])
+    assert_close(b, a, 6, exact=True, what="re-blocked")
+    r.release()
+    r = rt.Runtime(6, prog); r.set_option("fir_impl", fir_impl)
+    c2 = np.concatenate([r.run_block(2 * x[:B], C, C), r.run_block(2 * x[B:], C, C)])
+    assert (c2.view(np.uint32) == (2 * a).view(np.uint32)).all()
+
+
+def test_north_star_program_sampled_oracle():
+    """4096 ch x (16 biquads + 4096-tap FIR), format 6, 1024 frames x 2 blocks: sampled channels vs oracle."""
+    C, S, T, B = 4096, 16, 4096, 1024
+    pick = [0, 1, 2047, 4095]
+    taps = pb.lcg_taps_all(C, T)
+    prog = pb.synth_program(6, C, S, T, taps=taps)
+    x = pb.lcg_input(2 * B, C, True)
+    r = rt.Runtime(6, prog)
+    got = np.concatenate([r.run_block(x[:B], C, C), r.run_block(x[B:], C, C)])
+    for c in pick:
+        sub = pb.ProgramWriter(6, capacity=1 << 15)
+        sub.core(); sub.param()
+        bank = sub.biquad_bank(pb.synth_sections(c, S, pb.F48000, pb.F48000))
+        imp = sub.fir_impulses([taps[c]])
+        sub.load_gain_fixed(1, 1.0); sub.biquads(bank, S); sub.fir(imp, T); sub.sat0db(); sub.store(0)
+        o = po.OracleProgram(6, sub.end_of_code())
+        want = o.run_block(np.ascontiguousarray(x[:, c:c + 1]), 1, 1)
+        assert_close(np.ascontiguousarray(got[:, c:c + 1]), want, 6, what=f"channel {c}")
