@@ -71,7 +71,7 @@ static struct {
     int             dev_state_valid;     /* device mirror holds the authoritative state */
     core_plan       plans[MAX_CORE_PLANS];
     int             nplans;
-    int             opt_fir_impl, opt_biquad_impl, opt_device;
+    int             opt_fir_impl, opt_biquad_impl, opt_device, opt_profile;
     int             device_selected;
 } G = { .opt_fir_impl = 1, .opt_biquad_impl = 1, .opt_device = -1 };
 
@@ -109,6 +109,11 @@ int dspRuntimeSetOption(const char *key, int value)
     if (!strcmp(key, "fir_impl"))    { G.opt_fir_impl = value; return 0; }
     if (!strcmp(key, "biquad_impl")) { G.opt_biquad_impl = value; return 0; }
     if (!strcmp(key, "device"))      { G.opt_device = value; G.device_selected = 0; return 0; }
+    if (!strcmp(key, "profile")) {
+        G.opt_profile = value;
+        if (G.dev) avdsp_hip_profile_enable(G.dev, value);
+        return 0;
+    }
     return fail(-1, "unknown option '%s'", key);
 }
 
@@ -117,6 +122,7 @@ int dspRuntimeGetOption(const char *key)
     if (!strcmp(key, "fir_impl"))    return G.opt_fir_impl;
     if (!strcmp(key, "biquad_impl")) return G.opt_biquad_impl;
     if (!strcmp(key, "device"))      return G.opt_device;
+    if (!strcmp(key, "profile"))     return G.opt_profile;
     return -1;
 }
 
@@ -394,6 +400,7 @@ static core_plan *get_plan(int format, opcode_t *core)
             fail(-10, "%s", avdsp_hip_last_error()); lowered_free(&L); drop_device(); return 0;
         }
         G.dev_state_valid = 1;
+        avdsp_hip_profile_enable(G.dev, G.opt_profile);
     }
     avdsp_plan_desc d;
     memset(&d, 0, sizeof d);
@@ -413,6 +420,15 @@ static core_plan *get_plan(int format, opcode_t *core)
     if (id < 0) { fail(-10, "%s", avdsp_hip_last_error()); return 0; }
     G.nplans++;
     return cp;
+}
+
+int dspRuntimeKernelTime(int kind, double *total_ms, int *launches)
+{
+    if (total_ms) *total_ms = 0.0;
+    if (launches) *launches = 0;
+    if (!G.dev) return 0;
+    if (avdsp_hip_profile_read(G.dev, kind, total_ms, launches)) return fail(-10, "%s", avdsp_hip_last_error());
+    return 0;
 }
 
 int dspRuntimeCoreInfo(int format, opcode_t *core, int *nchains, int *max_sections, int *max_taps)

@@ -550,6 +550,11 @@ struct avdsp_hip_prog {
     std::vector<Plan> plans;
     float *d_xmid = nullptr; size_t xmid_chains = 0;
     unsigned *d_in = nullptr, *d_out = nullptr; size_t in_cap = 0, out_cap = 0;   /* host-call staging */
+    /* optional per-kernel timing with HIP events on the launch stream (avdsp_hip_profile_*) */
+    bool profile = false;
+    struct Span { int kind; hipEvent_t a, b; };
+    std::vector<Span> spans;            /* recorded, not yet read */
+    std::vector<hipEvent_t> free_events;
 };
 
 namespace {
@@ -581,10 +586,35 @@ size_t fir_lds_bytes(int max_taps, int tiles, int *hs_cap)
     return (size_t)(*hs_cap + W + (W >> 4) + 4) * sizeof(float);
 }
 
+hipEvent_t take_event(avdsp_hip_prog *prog)
+{
+    if (!prog->free_events.empty()) { hipEvent_t e = prog->free_events.back(); prog->free_events.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+struct ProfileScope {                   /* records an event pair around the launches made inside its lifetime */
+    avdsp_hip_prog *prog; hipStream_t stream; int kind; hipEvent_t a = nullptr;
+    ProfileScope(avdsp_hip_prog *p, hipStream_t s, int k) : prog(p), stream(s), kind(k)
+    {
+        if (prog->profile && (a = take_event(prog))) (void)hipEventRecord(a, stream);
+    }
+    ~ProfileScope()
+    {
+        if (!a) return;
+        hipEvent_t b = take_event(prog);
+        if (!b) { prog->free_events.push_back(a); return; }
+        (void)hipEventRecord(b, stream);
+        prog->spans.push_back({kind, a, b});
+    }
+};
+
 template <int FMT>
 int launch_all(avdsp_hip_prog *prog, Plan &pl, BlockIO io, int fir_impl, int biquad_impl, hipStream_t stream)
 {
     for (auto &g : pl.bq) {
+        ProfileScope scope(prog, stream, AVDSP_KERNEL_BIQUAD);
         BiquadArgs a{};
         a.buf = prog->d_buf; a.chains = pl.d_chains; a.sec_coef = pl.d_sec_coef; a.sec_state = pl.d_sec_state;
         a.group = g.d_ids; a.ngroup = g.n; a.xmid = prog->d_xmid; a.xmid_stride = kFirChunk; a.io = io;
@@ -609,6 +639,7 @@ int launch_all(avdsp_hip_prog *prog, Plan &pl, BlockIO io, int fir_impl, int biq
     }
     if constexpr (FMT != 2) {
         if (pl.n_fir) {
+            ProfileScope scope(prog, stream, AVDSP_KERNEL_FIR);
             FirArgs a{};
             a.buf = prog->d_buf; a.chains = pl.d_chains; a.group = pl.d_fir_ids; a.ngroup = pl.n_fir;
             a.xmid = prog->d_xmid; a.xmid_stride = kFirChunk; a.io = io;
@@ -623,6 +654,7 @@ int launch_all(avdsp_hip_prog *prog, Plan &pl, BlockIO io, int fir_impl, int biq
         }
     }
     if (pl.n_pass) {
+        ProfileScope scope(prog, stream, AVDSP_KERNEL_PASS);
         PassArgs a{pl.d_chains, pl.d_pass_ids, pl.n_pass, io};
         const long long total = (long long)pl.n_pass * io.nframes;
         const int grid = (int)std::min<long long>((total + kBlock - 1) / kBlock, 2048);
@@ -666,6 +698,8 @@ void avdsp_hip_prog_destroy(avdsp_hip_prog *p)
     if (!p) return;
     (void)hipDeviceSynchronize();
     for (auto &pl : p->plans) free_plan(pl);
+    for (auto &sp : p->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
+    for (auto e : p->free_events) (void)hipEventDestroy(e);
     (void)hipFree(p->d_buf); (void)hipFree(p->d_xmid); (void)hipFree(p->d_in); (void)hipFree(p->d_out);
     delete p;
 }
@@ -812,6 +846,31 @@ int avdsp_hip_run_block_host(avdsp_hip_prog *prog, int plan, const void *h_in, i
                             nframes, fir_impl, biquad_impl, nullptr)) return -1;
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(h_out, prog->d_out, out_words * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int avdsp_hip_profile_enable(avdsp_hip_prog *prog, int on)
+{
+    prog->profile = on != 0;
+    return 0;
+}
+
+int avdsp_hip_profile_read(avdsp_hip_prog *prog, int kind, double *total_ms, int *launches)
+{
+    double sum = 0.0;
+    int n = 0;
+    std::vector<avdsp_hip_prog::Span> keep;
+    for (auto &sp : prog->spans) {
+        if (sp.kind != kind) { keep.push_back(sp); continue; }
+        HIP_TRY(hipEventSynchronize(sp.b));
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, sp.a, sp.b));
+        sum += ms; n++;
+        prog->free_events.push_back(sp.a); prog->free_events.push_back(sp.b);
+    }
+    prog->spans.swap(keep);
+    if (total_ms) *total_ms = sum;
+    if (launches) *launches = n;
     return 0;
 }
 

@@ -302,9 +302,9 @@ def lcg_taps(channel: int, ntaps: int) -> np.ndarray:
     return x.astype(np.float32)
 
 
-def lcg_taps_all(channels: int, ntaps: int) -> np.ndarray:
-    """Vectorised lcg_taps for every channel at once -> float32 [channels, ntaps]."""
-    v = (7 + np.arange(channels, dtype=np.uint64)) & 0xFFFFFFFF
+def lcg_taps_all(channels: int, ntaps: int, channel_base: int = 0) -> np.ndarray:
+    """Vectorised lcg_taps for channels channel_base .. channel_base+channels-1 -> float32 [channels, ntaps]."""
+    v = (7 + channel_base + np.arange(channels, dtype=np.uint64)) & 0xFFFFFFFF
     out = np.empty((channels, ntaps), dtype=np.uint32)
     for i in range(ntaps):
         v = (v * 1664525 + 1013904223) & 0xFFFFFFFF
@@ -362,23 +362,26 @@ def synth_sections(channel: int, nsections: int, fmin: int, fmax: int, _cache={}
 
 def synth_program(fmt: int, channels: int, nsections: int, ntaps: int = 0,
                   fmin: int = F48000, fmax: int = F48000, gain: float = 1.0,
-                  shared_taps: bool = False, taps: np.ndarray | None = None) -> np.ndarray:
+                  shared_taps: bool = False, taps: np.ndarray | None = None,
+                  channel_base: int = 0) -> np.ndarray:
     """The synthetic workload of SURVEY.md 8(d) / BASELINE.json:
 
         channel c:  PARAM{bank_c [, impulse_c]}  LOAD_GAIN(IO=C+c, gain)  BIQUADS(bank_c)
                     [FIR(impulse_c)]  SAT0DB  STORE(IO=c)       one CORE, inputs at IO C..2C-1.
 
     Returns the program words (uint32, length = header.totalLength); the caller appends
-    header.dataSize words of state space.  `taps` overrides the LCG impulses ([C, T] float32)."""
+    header.dataSize words of state space.  `taps` overrides the LCG impulses ([C, T] float32).
+    `channel_base` makes this the shard [channel_base, channel_base+channels) of a larger program:
+    filters and impulses are those of the global channel numbers, IO numbers stay local."""
     nf = fmax - fmin + 1
     per_ch = 16 + nsections * (2 + 6 * nf) + 8 + nf * (ntaps + 3) + 8
     pw = ProgramWriter(fmt, fmin, fmax, capacity=32 + channels * per_ch)
     if ntaps and taps is None:
-        taps = lcg_taps_all(1 if shared_taps else channels, ntaps)
+        taps = lcg_taps_all(1 if shared_taps else channels, ntaps, channel_base)
     pw.core()
     for c in range(channels):
         pw.param()
-        bank = pw.biquad_bank(synth_sections(c, nsections, fmin, fmax)) if nsections else None
+        bank = pw.biquad_bank(synth_sections(channel_base + c, nsections, fmin, fmax)) if nsections else None
         imp = None
         if ntaps:
             t = taps[0 if shared_taps else c]

@@ -28,11 +28,12 @@ EXPORTED = [
     # block extension (include/avdsp_runtime.h)
     "dspRuntimeBlock_2", "dspRuntimeBlock_4", "dspRuntimeBlock_6", "dspRuntimeBlockDevice",
     "dspRuntimeSyncState", "dspRuntimeUploadState", "dspRuntimeSetOption", "dspRuntimeGetOption",
-    "dspRuntimeCoreInfo", "dspRuntimeLastError", "dspRuntimeRelease",
+    "dspRuntimeCoreInfo", "dspRuntimeKernelTime", "dspRuntimeLastError", "dspRuntimeRelease",
     # thin HIP ABI (include/avdsp_hip.h)
     "avdsp_hip_device_count", "avdsp_hip_set_device", "avdsp_hip_prog_create", "avdsp_hip_prog_destroy",
     "avdsp_hip_prog_add_plan", "avdsp_hip_upload_words", "avdsp_hip_download_words", "avdsp_hip_zero_words",
-    "avdsp_hip_run_block", "avdsp_hip_run_block_host", "avdsp_hip_synchronize", "avdsp_hip_last_error",
+    "avdsp_hip_run_block", "avdsp_hip_run_block_host", "avdsp_hip_profile_enable", "avdsp_hip_profile_read",
+    "avdsp_hip_synchronize", "avdsp_hip_last_error",
 ]
 
 
@@ -54,6 +55,22 @@ def build(force: bool = False) -> str:
 _lib = None
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME
+    libamdhip64.so.7, same as the system one).  If our library were loaded first it would pull the
+    system runtime, torch would later add its bundled copy, and whichever initialises second sees
+    "No HIP GPUs".  Loading torch's copy first (when torch is installed) makes the dynamic loader
+    satisfy our DT_NEEDED libamdhip64.so.7 with it, whatever the import order.  C hosts without
+    torch simply get the ROCm runtime through the library's RUNPATH."""
+    import importlib.util
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.origin:
+        return
+    path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
 def lib() -> C.CDLL:
     """Load the C-ABI library; raises if it is missing (there is no fallback)."""
     global _lib
@@ -62,6 +79,7 @@ def lib() -> C.CDLL:
             raise FileNotFoundError(
                 f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or make -C avdsp_amd/csrc).  The product path has no CPU fallback.")
+        _preload_hip_runtime()
         L = C.CDLL(LIB_PATH)
         vp, i32 = C.c_void_p, C.c_int
         L.dspFindCore.restype = vp; L.dspFindCore.argtypes = [vp, i32]
@@ -80,6 +98,8 @@ def lib() -> C.CDLL:
         L.dspRuntimeGetOption.restype = i32; L.dspRuntimeGetOption.argtypes = [C.c_char_p]
         L.dspRuntimeCoreInfo.restype = i32
         L.dspRuntimeCoreInfo.argtypes = [i32, vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+        L.dspRuntimeKernelTime.restype = i32
+        L.dspRuntimeKernelTime.argtypes = [i32, C.POINTER(C.c_double), C.POINTER(i32)]
         L.dspRuntimeLastError.restype = C.c_char_p
         L.dspRuntimeRelease.restype = None
         L.dspQNM.restype = C.c_longlong; L.dspQNM.argtypes = [C.c_double, i32, i32]
@@ -177,6 +197,13 @@ class Runtime:
         return self._check(self.L.dspRuntimeBlockDevice(
             self.fmt, self.cores[core_index], self.rundata, d_in_ptr, in_stride, in_io_base,
             d_out_ptr, out_stride, out_io_base, nframes, stream))
+
+    def kernel_time(self, kind: int):
+        """(total_ms, launches) of the kernels of `kind` (0 biquad, 1 FIR, 2 pass) since the last read;
+        needs set_option("profile", 1)."""
+        ms, n = C.c_double(), C.c_int()
+        self._check(self.L.dspRuntimeKernelTime(kind, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     def sync_state(self) -> np.ndarray:
         self._check(self.L.dspRuntimeSyncState(self.rundata))

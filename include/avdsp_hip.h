@@ -80,6 +80,13 @@ int avdsp_hip_run_block_host(avdsp_hip_prog *prog, int plan, const void *h_in, i
                              void *h_out, int out_stride, int out_io_base, int nframes,
                              int fir_impl, int biquad_impl);
 
+/* Per-kernel timing: when enabled, every kernel launch of run_block is bracketed by a HIP event pair
+ * recorded on the launch stream; profile_read waits for the recorded pairs of one kind, returns
+ * the summed duration and the number of launches, and forgets them.                              */
+enum { AVDSP_KERNEL_BIQUAD = 0, AVDSP_KERNEL_FIR = 1, AVDSP_KERNEL_PASS = 2 };
+int avdsp_hip_profile_enable(avdsp_hip_prog *prog, int on);
+int avdsp_hip_profile_read(avdsp_hip_prog *prog, int kind, double *total_ms, int *launches);
+
 int avdsp_hip_synchronize(void *stream);
 const char *avdsp_hip_last_error(void);
 

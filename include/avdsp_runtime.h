@@ -91,6 +91,11 @@ int dspRuntimeUploadState(const int *rundata);
 int dspRuntimeSetOption(const char *key, int value);
 int dspRuntimeGetOption(const char *key);
 
+/* Kernel timing with HIP events on the launch stream: enable with dspRuntimeSetOption("profile", 1);
+ * kind 0 = biquad cascade, 1 = FIR, 2 = pass-through.  Returns the summed duration (ms) and launch
+ * count of the launches recorded since the previous read.                                        */
+int dspRuntimeKernelTime(int kind, double *total_ms, int *launches);
+
 /* Introspection of the lowered core (what the device plan contains); negative when not lowerable. */
 int dspRuntimeCoreInfo(int format, opcode_t *core, int *nchains, int *max_sections, int *max_taps);
 

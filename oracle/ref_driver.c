@@ -9,13 +9,16 @@
  * never-called symbols (dspQNMmax, DSP_Q31) stay unbound instead of being stubbed.
  *
  * usage: ref_driver LIB FORMAT PROG.bin MAXSIZE FS RANDOM DITHER IN.raw OUT.raw NFRAMES BLOCK
- *                   IN_STRIDE IN_IO_BASE OUT_STRIDE OUT_IO_BASE SCRATCH_LEN [STATE_OUT.raw]
+ *                   IN_STRIDE IN_IO_BASE OUT_STRIDE OUT_IO_BASE SCRATCH_LEN [STATE_OUT.raw|- [REPEAT [WARM]]]
  *   MAXSIZE 0 = totalLength + dataSize.  Prints "init=<rc>" and, on success, "cores=<n>".
+ *   REPEAT > 1 runs the NFRAMES input that many times back to back (timing runs for bench.py's
+ *   cpu_baseline leg); the first WARM passes are excluded from the "elapsed=<s> frames=<n>" line.
  */
 #include <dlfcn.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include "avdsp_format.h"
 
 typedef int       (*init_fn)(opcode_t *, int, int, int, int);
@@ -49,7 +52,9 @@ int main(int argc, char **argv)
     int in_stride = atoi(argv[12]), in_base = atoi(argv[13]);
     int out_stride = atoi(argv[14]), out_base = atoi(argv[15]);
     int scratch_len = atoi(argv[16]);
-    const char *statepath = argc > 17 ? argv[17] : NULL;
+    const char *statepath = (argc > 17 && strcmp(argv[17], "-")) ? argv[17] : NULL;
+    int repeat = argc > 18 ? atoi(argv[18]) : 1, warm = argc > 19 ? atoi(argv[19]) : 0;
+    struct timespec ts0, ts1;
 
     void *h = dlopen(lib, RTLD_LAZY | RTLD_LOCAL);
     if (!h) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 2; }
@@ -91,6 +96,10 @@ int main(int argc, char **argv)
     unsigned *scratch = (unsigned *)calloc((size_t)scratch_len + 1, 4);
     if (block <= 0) block = nframes;
 
+    if (repeat < 1) repeat = 1;
+    clock_gettime(CLOCK_MONOTONIC, &ts0);
+    for (int rep = 0; rep < repeat; rep++) {
+    if (rep == warm) clock_gettime(CLOCK_MONOTONIC, &ts0);
     for (int b0 = 0; b0 < nframes; b0 += block) {
         int b1 = b0 + block < nframes ? b0 + block : nframes;
         for (int nc = 0; nc < ncores; nc++)
@@ -101,6 +110,11 @@ int main(int argc, char **argv)
                 memcpy(out + (size_t)n * out_stride, scratch + out_base, (size_t)out_stride * 4);
             }
     }
+    }
+    clock_gettime(CLOCK_MONOTONIC, &ts1);
+    if (repeat > 1)
+        printf("elapsed=%.6f frames=%ld\n", (ts1.tv_sec - ts0.tv_sec) + 1e-9 * (ts1.tv_nsec - ts0.tv_nsec),
+               (long)(repeat - warm) * nframes);
 
     FILE *f = fopen(outpath, "wb");
     if (!f) { perror(outpath); return 2; }
