@@ -395,48 +395,74 @@ struct FirArgs {
     int             xmid_stride;
     int             per_xcd;
     int             hs_cap;          /* floats reserved for the taps image */
+    int             win_row;         /* words per row of the transposed window image */
     BlockIO         io;
 };
 
-/* LDS images (floats).  Taps: hs[t + 16] for t in [-16, T+24), zero outside [0,T).
- * Window: position w = q + T + 8 for sample index q (q < 0: history, st[i] <-> q = -1-i;
- * 0 <= q < B: this block; everything else zero); stored at w + (w >> 4) so that the MFMA B
- * operand (16 lanes striding 16 samples) hits 16 different banks.                              */
-__device__ __forceinline__ int win_pos(int w) { return w + (w >> 4); }
-constexpr int kWinOff = 8, kTapPad = 40;
+/* LDS images (floats, subnormals already flushed to +0 as dspMulFloatDouble would treat them).
+ *   taps    hs[t + 16] for t in [-16, T + 96): zero outside [0, T)
+ *   window  sample index q sits at position w = q + T + kWinOff (q < 0: history, st[i] <-> q = -1-i;
+ *           0 <= q < B: this block; zero elsewhere), stored TRANSPOSED in 16 rows:
+ *           pos(w) = (w & 15) * row + (w >> 4).  The MFMA B operand reads x[16(a0+j) - m - k]:
+ *           the 16 lanes j of one k are then 16 consecutive words (conflict free), and with
+ *           row = 16 (mod 32) the two k values sharing a 32-lane LDS pass land 16 banks apart.   */
+constexpr int kWinOff = 64, kTapPad = 112;
+
+__device__ __forceinline__ int win_pos(int w, int row) { return (w & 15) * row + (w >> 4); }
+
+__host__ __device__ inline int win_words(int taps, int frames_pad) { return taps + kWinOff + frames_pad + 16; }
+__host__ __device__ inline int win_row(int taps, int frames_pad)
+{
+    int r = (win_words(taps, frames_pad) + 15) >> 4;
+    return r + ((16 - (r & 31)) & 31);               /* next value that is 16 mod 32 */
+}
+
+/* the raw (unflushed) float the FIR sees for frame q of this block: (float)X of the stage in front */
+template <int FMT>
+__device__ __forceinline__ float fir_input(const FirArgs &a, const avdsp_chain &c, int cid, int q)
+{
+    if (c.nsec) return a.xmid[(size_t)cid * a.xmid_stride + q];
+    const unsigned raw = a.io.in[(size_t)q * a.io.in_stride + (c.in_io - a.io.in_base)];
+    return __uint_as_float(narrow_stage<FMT>(load_stage<FMT>(raw, c.load_mode, c.gain_bits)));
+}
 
 template <int FMT>
 __device__ __forceinline__ void fir_stage_lds(const FirArgs &a, const avdsp_chain &c, int cid,
-                                              float *hs, float *xs, int frames_pad)
+                                              float *hs, float *xs, int row)
 {
-    const int T = c.fir_taps, B = a.io.nframes;
+    const int T = c.fir_taps, B = a.io.nframes, nt = blockDim.x, tid = threadIdx.x;
     const float *taps = reinterpret_cast<const float *>(a.buf + c.fir_coef_word);
     const float *hist = reinterpret_cast<const float *>(a.buf + c.fir_state_word);
-    for (int u = threadIdx.x; u < T + kTapPad; u += blockDim.x) {
-        const int t = u - 16;
-        hs[u] = (t >= 0 && t < T) ? flush_f32(taps[t]) : 0.0f;
-    }
-    const int W = T + kWinOff + frames_pad + 16;
-    const unsigned *inp = a.io.in + (c.in_io - a.io.in_base);
-    for (int w = threadIdx.x; w < W; w += blockDim.x) {
-        const int q = w - (T + kWinOff);
-        float v = 0.0f;
-        if (q >= -T && q < 0) v = hist[-1 - q];
-        else if (q >= 0 && q < B) {
-            if (c.nsec) v = a.xmid[(size_t)cid * a.xmid_stride + q];
-            else v = __uint_as_float(narrow_stage<FMT>(load_stage<FMT>(inp[(size_t)q * a.io.in_stride], c.load_mode, c.gain_bits)));
-        }
-        xs[win_pos(w)] = v;                             /* raw: the delay line keeps subnormals */
-    }
+    /* zero everything first (pads, future samples, rows' tails), then drop the real data in */
+    for (int u = tid; u < 16; u += nt) hs[u] = 0.0f;
+    for (int u = T + 16 + tid; u < T + kTapPad; u += nt) hs[u] = 0.0f;
+    for (int u = tid; u < 16 * row; u += nt) xs[u] = 0.0f;
+    __syncthreads();
+#pragma unroll 4
+    for (int t = tid; t < T; t += nt) hs[16 + t] = flush_f32(taps[t]);
+#pragma unroll 4
+    for (int i = tid; i < T; i += nt) xs[win_pos(T + kWinOff - 1 - i, row)] = flush_f32(hist[i]);
+#pragma unroll 4
+    for (int q = tid; q < B; q += nt) xs[win_pos(T + kWinOff + q, row)] = flush_f32(fir_input<FMT>(a, c, cid, q));
 }
 
-/* new delay line: st[i] = x[B-1-i] (dsp_firSTD.h:45-50 applied B times) */
-__device__ __forceinline__ void fir_write_state(const FirArgs &a, const avdsp_chain &c, const float *xs)
+/* New delay line st[i] = x[B-1-i] (dsp_firSTD.h:45-50 applied B times), from the raw values so that
+ * the state area stays bit-identical to the reference's.  For B < T this shifts the old line up by
+ * B in place: chunks run from the top down, each reads before it writes (barrier in between), and
+ * no chunk reads a word an earlier chunk has already overwritten.                               */
+template <int FMT>
+__device__ __forceinline__ void fir_write_state(const FirArgs &a, const avdsp_chain &c, int cid)
 {
-    const int T = c.fir_taps, B = a.io.nframes;
+    const int T = c.fir_taps, B = a.io.nframes, nt = blockDim.x;
     float *hist = reinterpret_cast<float *>(a.buf + c.fir_state_word);
-    for (int i = threadIdx.x; i < T; i += blockDim.x)
-        hist[i] = xs[win_pos(B - 1 - i + T + kWinOff)];
+    for (int hi = T; hi > 0; hi -= nt) {
+        const int i = hi - 1 - (int)threadIdx.x;
+        float v = 0.0f;
+        if (i >= 0) v = (i < B) ? fir_input<FMT>(a, c, cid, B - 1 - i) : hist[i - B];
+        __syncthreads();
+        if (i >= 0) hist[i] = v;
+        __syncthreads();
+    }
 }
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
@@ -451,28 +477,44 @@ __global__ __launch_bounds__(kBlock) void fir_mfma(const FirArgs a)
     const avdsp_chain c = a.chains[cid];
     float *hs = lds, *xs = lds + a.hs_cap;
     const int tiles = blockDim.x >> 6;                  /* one wave per 256-frame tile */
-    fir_stage_lds<FMT>(a, c, cid, hs, xs, tiles * kTileFrames);
+    const int row = a.win_row;
+    fir_stage_lds<FMT>(a, c, cid, hs, xs, row);
     __syncthreads();
 
     const int T = c.fir_taps, B = a.io.nframes;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ij = lane & 15, k = lane >> 4;
     /* Y[i][col] = y[16*(a0+col) + i] = sum_m A[i][m] * Bm[m][col],  A[i][m] = h[m+i],
-     * Bm[m][col] = x[16*(a0+col) - m],  m = -15 .. T-1 (4 per MFMA, ascending = tap order) */
+     * Bm[m][col] = x[16*(a0+col) - m],  m = -15 .. T-1, four m per MFMA, ascending = tap order.
+     * Steps are taken in groups of four; within a group the window row (w & 15) of a lane steps
+     * by -4 and wraps once, so each lane keeps four fixed LDS addresses that move by one word per
+     * group: pos = K[s] - g.                                                                      */
     const int a0 = wave * 16;
-    const int nsteps = (T + 15 + 3) >> 2;
+    const int ngroups = (((T + 15 + 15) >> 4) + 1) & ~1;  /* 16 values of m per group; even count (zero taps pad the tail) */
+    const float *hp = hs + (16 - 15 + k + ij);          /* h[m + k + i] at m = -15; +4 per step */
+    const int f = 16 * a0 + 15 - k + (T + kWinOff);     /* window position at step 0 for j = 0 */
+    const float *xp[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) xp[s] = xs + win_pos(f - 4 * s, row) + ij;
     v4f64 acc = {0.0, 0.0, 0.0, 0.0};
-    int ha = 16 + (-15) + k + ij;                       /* hs index of h[m + k + i] at m = -15 */
-    int wq = 16 * (a0 + ij) + 15 - k + (T + kWinOff);         /* window position of x[16(a0+j) - m - k] */
-    float hv = hs[ha];
-    float xv = xs[win_pos(wq)];
-    for (int st = 0; st < nsteps; st++) {
-        const double da = (double)hv;                   /* taps were flushed while staging */
-        const double db = mulop(xv);
-        ha += 4; wq -= 4;
-        hv = hs[ha];                                    /* next step's operands (zero padded, in range) */
-        xv = xs[win_pos(wq)];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(da, db, acc, 0, 0, 0);
+    float h0[4], x0[4], h1[4], x1[4];                   /* two operand sets: one feeds the MFMAs while the other loads */
+#pragma unroll
+    for (int s = 0; s < 4; s++) { h0[s] = hp[4 * s]; x0[s] = xp[s][0]; }
+    for (int g = 0; g < ngroups; g += 2) {
+#pragma unroll
+        for (int s = 0; s < 4; s++) { h1[s] = hp[16 * (g + 1) + 4 * s]; x1[s] = xp[s][-(g + 1)]; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)h0[s], (double)x0[s], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 4; s++) { h0[s] = hp[16 * (g + 2) + 4 * s]; x0[s] = xp[s][-(g + 2)]; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)h1[s], (double)x1[s], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     }
     /* C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg */
 #pragma unroll
@@ -480,7 +522,8 @@ __global__ __launch_bounds__(kBlock) void fir_mfma(const FirArgs a)
         const int n = 16 * (a0 + ij) + k + 4 * r;
         if (n < B) emit_out(a.io, c, n, store_stage<FMT>(acc[r], c.sat, a.io.store_mask));
     }
-    fir_write_state(a, c, xs);
+    (void)tiles;
+    fir_write_state<FMT>(a, c, cid);
 }
 
 template <int FMT>
@@ -492,18 +535,18 @@ __global__ __launch_bounds__(kBlock) void fir_plain(const FirArgs a)
     const int cid = a.group[slot];
     const avdsp_chain c = a.chains[cid];
     float *hs = lds, *xs = lds + a.hs_cap;
-    const int tiles = blockDim.x >> 6;
-    fir_stage_lds<FMT>(a, c, cid, hs, xs, tiles * kTileFrames);
+    const int row = a.win_row;
+    fir_stage_lds<FMT>(a, c, cid, hs, xs, row);
     __syncthreads();
     const int T = c.fir_taps, B = a.io.nframes;
     for (int n = threadIdx.x; n < B; n += blockDim.x) {
         double acc = 0.0;                               /* dsp_firSTD.h:43-50: taps in ascending order */
         const int w0 = n + T + kWinOff;
         for (int t = 0; t < T; t++)
-            acc = __builtin_fma(mulop(xs[win_pos(w0 - t)]), (double)hs[16 + t], acc);
+            acc = __builtin_fma((double)xs[win_pos(w0 - t, row)], (double)hs[16 + t], acc);
         emit_out(a.io, c, n, store_stage<FMT>(acc, c.sat, a.io.store_mask));
     }
-    fir_write_state(a, c, xs);
+    fir_write_state<FMT>(a, c, cid);
 }
 
 /* chains with neither biquads nor FIR: LOAD -> [SAT0DB] -> STORE */
@@ -578,12 +621,12 @@ void free_plan(Plan &p)
     (void)hipFree(p.d_fir_ids); (void)hipFree(p.d_pass_ids);
 }
 
-size_t fir_lds_bytes(int max_taps, int tiles, int *hs_cap)
+size_t fir_lds_bytes(int max_taps, int tiles, int *hs_cap, int *row)
 {
     const int hs = max_taps + kTapPad;
-    const int W = max_taps + kWinOff + tiles * kTileFrames + 16;
     *hs_cap = (hs + 3) & ~3;
-    return (size_t)(*hs_cap + W + (W >> 4) + 4) * sizeof(float);
+    *row = win_row(max_taps, tiles * kTileFrames);
+    return (size_t)(*hs_cap + 16 * *row) * sizeof(float);
 }
 
 hipEvent_t take_event(avdsp_hip_prog *prog)
@@ -645,7 +688,7 @@ int launch_all(avdsp_hip_prog *prog, Plan &pl, BlockIO io, int fir_impl, int biq
             a.xmid = prog->d_xmid; a.xmid_stride = kFirChunk; a.io = io;
             a.per_xcd = (pl.n_fir + 7) / 8;
             const int tiles = (io.nframes + kTileFrames - 1) / kTileFrames;
-            const size_t lds = fir_lds_bytes(pl.max_taps, tiles, &a.hs_cap);
+            const size_t lds = fir_lds_bytes(pl.max_taps, tiles, &a.hs_cap, &a.win_row);
             if (lds > 160 * 1024) return set_err("FIR of %d taps needs %zu bytes of LDS (limit 160 KiB)", pl.max_taps, lds);
             auto kern = fir_impl ? fir_mfma<FMT> : fir_plain<FMT>;
             HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

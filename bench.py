@@ -168,13 +168,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+
+    fmt, C, S, T, B = WORKLOADS[args.workload]
+    # The CPU leg runs FIRST, before this process touches the GPU: it starts one child process per host
+    # core, and children must not be forked off a process that has initialised HIP.
+    cpu = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(fmt, S, T, B)
     if not torch.cuda.is_available():
         sys.exit("bench.py: no GPU visible; the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-
-    fmt, C, S, T, B = WORKLOADS[args.workload]
     base = rank * C                                        # this rank's slice of the global channel numbering
     taps = pb.lcg_taps_all(C, T, base) if T else None
     prog = pb.synth_program(fmt, C, S, T, taps=taps, channel_base=base)
@@ -249,10 +254,7 @@ def main():
             "roofline": roof,
             "kernels_ms": {"biquad": bq_ms / max(bq_n, 1), "fir": fir_ms / max(fir_n, 1)},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(fmt, S, T, B)
-        else:
-            line["cpu_baseline"] = None
+        line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)
     r.release()
     if world > 1:
