@@ -35,6 +35,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 #include <algorithm>
 
@@ -194,43 +195,110 @@ __device__ __forceinline__ void emit_out(const BlockIO &io, const avdsp_chain &c
 
 /* ------------------------------------------------------------------------------------------
  * biquad cascade, section-pipelined
+ *
+ * One lane per (channel, section); P = lanes reserved per channel (power of two >= sections).
+ * At step t section s works on frame t - s, so after the pipeline has filled every lane runs one
+ * biquad update per step and hands its result to lane+1 with a single DPP row shift.  Each lane
+ * performs exactly the reference's operations in the reference's order (dsp_biquadSTD.h:37-74,
+ * 87-117); only independent (channel, section, frame) triples overlap.
+ *
+ * Sample IO is batched so that the step loop contains no memory instruction:
+ *   input   every NB = min(P,16) steps the first NB lanes of a channel load NB consecutive frames
+ *           (three batches ahead), convert them once, and the batch is rotated one lane per step
+ *           (DPP row_ror:15) so the section-0 lane always finds "its" frame in its own register;
+ *   output  the last section drops its accumulator into a register that rotates the other way
+ *           (row_ror:1); after NB steps the NB results sit in NB different lanes, which convert
+ *           (SAT0DB/STORE) and store them together.
  * ---------------------------------------------------------------------------------------- */
-template <int P>
-__device__ __forceinline__ unsigned from_prev_lane(unsigned v)
-{
-    if constexpr (P <= 16)          /* row_shr:1 inside a 16-lane DPP row; lane 0 of a row keeps v */
-        return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x111, 0xF, 0xF, false);
-    else
-        return (unsigned)__shfl_up((int)v, 1, 64);
-}
-
 struct BiquadArgs {
     int            *buf;            /* device mirror of the caller's buffer */
     const avdsp_chain *chains;
     const int      *sec_coef, *sec_state;
-    const int      *group;          /* chain ids handled by this launch */
+    const int      *group;          /* chain ids handled by this launch (all with `nsec` sections) */
     int             ngroup;
+    int             nsec;
     float          *xmid;           /* planar [chain][xmid_stride] hand-off to the FIR kernel */
     int             xmid_stride;
     int             per_xcd;
     BlockIO         io;
 };
 
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_mov(unsigned old, unsigned src)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, 0xF, 0xF, false);
+}
+constexpr int kRowShr1 = 0x111, kRowRor1 = 0x121, kRowRor15 = 0x12F;
+
+/* value of lane-1 (lane 0 of a 16-lane row, which has no source, keeps `old`) */
+template <int P>
+__device__ __forceinline__ unsigned from_prev_lane(unsigned old, unsigned v)
+{
+    if constexpr (P <= 16) return dpp_mov<kRowShr1>(old, v);
+    else return (unsigned)__shfl_up((int)v, 1, 64);
+}
+
+template <int FMT> struct Hand;                          /* what travels from section to section */
+template <> struct Hand<2> { unsigned y; };              /* (int)(acc >> 28) */
+template <> struct Hand<4> { unsigned y, lo, hi; };      /* float bits of (float)acc and its flushed double */
+template <> struct Hand<6> { unsigned y, lo, hi; };
+
+template <int FMT>
+__device__ __forceinline__ Hand<FMT> hand_from_sample(unsigned raw, const avdsp_chain &c)
+{
+    Hand<FMT> h;
+    h.y = narrow_stage<FMT>(load_stage<FMT>(raw, c.load_mode, c.gain_bits));
+    if constexpr (FMT != 2) {
+        const unsigned long long d = (unsigned long long)__double_as_longlong(mulop(__uint_as_float(h.y)));
+        h.lo = (unsigned)d; h.hi = (unsigned)(d >> 32);
+    }
+    return h;
+}
+
+template <int FMT, int CTRL>
+__device__ __forceinline__ Hand<FMT> hand_rotate(Hand<FMT> h)
+{
+    h.y = dpp_mov<CTRL>(h.y, h.y);
+    if constexpr (FMT != 2) { h.lo = dpp_mov<CTRL>(h.lo, h.lo); h.hi = dpp_mov<CTRL>(h.hi, h.hi); }
+    return h;
+}
+
 template <int FMT, int P>
 __global__ __launch_bounds__(kBlock) void biquad_pipe(const BiquadArgs a)
 {
     using alu_t = typename Alu<FMT>::type;
+    constexpr int NB = P < 16 ? P : 16;                 /* steps per IO batch */
     constexpr int CPB = kBlock / P;                     /* chains per block */
+    constexpr int DEPTH = 3;                            /* input batches in flight */
+    const int tid = threadIdx.x, rowpos = tid & 15;
     const int blk = xcd_remap(blockIdx.x, a.per_xcd);
-    const int slot = blk * CPB + (int)threadIdx.x / P;
-    const int s = (int)threadIdx.x % P;
+    const int slot = blk * CPB + tid / P;
+    const int s = tid % P;
+    const int nsec = a.nsec, B = a.io.nframes;
     const bool have_chain = slot < a.ngroup;
     const int cid = have_chain ? a.group[slot] : 0;
     const avdsp_chain c = a.chains[cid];
-    const bool lane_on = have_chain && s < c.nsec;
-    const bool first = lane_on && s == 0;
-    const bool last = lane_on && s == c.nsec - 1;
-    const int B = a.io.nframes;
+    const bool lane_on = have_chain && s < nsec;
+    const bool first = s == 0;
+    const bool last = lane_on && s == nsec - 1;
+
+    /* which (chain, step-in-batch) this lane ends up holding in the output batch register */
+    int d, oslot;
+    bool owner;
+    if constexpr (P >= 16) {
+        d = (rowpos - ((nsec - 1) & 15)) & 15;
+        owner = (s >> 4) == ((nsec - 1) >> 4);
+        oslot = slot;
+    } else {
+        d = (rowpos - (nsec - 1)) & (P - 1);
+        owner = true;
+        const int src = (rowpos - d) & 15;               /* row position of the lane that inserted the value */
+        oslot = blk * CPB + (tid >> 4) * (16 / P) + (((src - (nsec - 1)) & 15) / P);
+    }
+    owner = owner && oslot < a.ngroup;
+    const int ocid = owner ? a.group[oslot] : 0;
+    const avdsp_chain oc = a.chains[ocid];
+    const int ostep = NB - 1 - d;                       /* step of the batch whose result this lane stores */
 
     /* coefficients and the 6 state words of this (chain, section) stay in registers */
     int sw = 0;
@@ -243,11 +311,12 @@ __global__ __launch_bounds__(kBlock) void biquad_pipe(const BiquadArgs a)
         const int cw = a.sec_coef[c.sec_base + s];
         sw = a.sec_state[c.sec_base + s];
         const int *st = a.buf + sw;
+        const unsigned long long raw = ((unsigned long long)(unsigned)st[1] << 32) | (unsigned)st[0];
         if constexpr (FMT == 2) {
-            acc = (long long)(((unsigned long long)(unsigned)st[1] << 32) | (unsigned)st[0]);
+            acc = (long long)raw;
             for (int k = 0; k < 5; k++) ci[k] = a.buf[cw + k];
         } else {
-            acc = __longlong_as_double((long long)(((unsigned long long)(unsigned)st[1] << 32) | (unsigned)st[0]));
+            acc = __longlong_as_double((long long)raw);
             for (int k = 0; k < 5; k++) cd[k] = mulop(__int_as_float(a.buf[cw + k]));
         }
         x1 = (unsigned)st[2]; x2 = (unsigned)st[3]; y1 = (unsigned)st[4]; y2 = (unsigned)st[5];
@@ -257,67 +326,107 @@ __global__ __launch_bounds__(kBlock) void biquad_pipe(const BiquadArgs a)
         }
     }
 
+    /* input batches: lane s < NB of a channel fetches frame (batch*NB + s), clamped into the block */
     const unsigned *inp = a.io.in + (c.in_io - a.io.in_base);
-    constexpr int U = 16;                               /* input prefetch depth = unroll */
-    unsigned cur[U], nxt[U];
+    const bool loader = have_chain && s < NB;
+    auto fetch = [&](int batch) -> unsigned {
+        int n = batch * NB + s;
+        n = n < B ? n : B - 1;
+        return loader ? inp[(size_t)n * a.io.in_stride] : 0u;
+    };
+    unsigned rawq[DEPTH];
 #pragma unroll
-    for (int i = 0; i < U; i++) {
-        cur[i] = 0;
-        if (first && i < B) cur[i] = inp[(size_t)i * a.io.in_stride];
-    }
+    for (int k = 0; k < DEPTH; k++) rawq[k] = fetch(k);
 
-    unsigned yprev = 0;                                 /* what this lane hands to section s+1 */
-    const int steps = B + P - 1;
-    for (int t0 = 0; t0 < steps; t0 += U) {
-#pragma unroll
-        for (int i = 0; i < U; i++) {                   /* samples of the NEXT group, in flight now */
-            const int n = t0 + U + i;
-            nxt[i] = 0;
-            if (first && n < B) nxt[i] = inp[(size_t)n * a.io.in_stride];
+    Hand<FMT> hy;                                       /* this lane's latest result, offered to lane+1 */
+    hy.y = y1;
+    if constexpr (FMT != 2) { hy.lo = 0; hy.hi = 0; }
+    unsigned ob_lo = 0, ob_hi = 0;                      /* rotating output batch (accumulator bits) */
+
+    auto step = [&](Hand<FMT> &ib, int t, auto masked) {
+        /* operand from the previous section, or the next input sample for section 0 */
+        Hand<FMT> xin;
+        xin.y = from_prev_lane<P>(ib.y, hy.y);
+        if constexpr (FMT != 2) { xin.lo = from_prev_lane<P>(ib.lo, hy.lo); xin.hi = from_prev_lane<P>(ib.hi, hy.hi); }
+        if constexpr (P != 16) {                        /* section-0 lanes that do not sit at a row start */
+            if (first) xin = ib;
         }
-#pragma unroll
-        for (int i = 0; i < U; i++) {
-            const int t = t0 + i;
-            const int n = t - s;                        /* frame this section works on */
-            unsigned xin = from_prev_lane<P>(yprev);
-            if (first) xin = narrow_stage<FMT>(load_stage<FMT>(cur[i], c.load_mode, c.gain_bits));
-            if (lane_on && n >= 0 && n < B) {
-                if constexpr (FMT == 2) {
-                    /* dsp_biquadSTD.h:37-74: five 32x32 MACs onto the previous full-precision
-                     * output, saturate on the high word, keep acc, y = acc >> 28              */
-                    unsigned long long u = (unsigned long long)acc;
-                    u += (unsigned long long)((long long)(int)xin * ci[0]);
-                    u += (unsigned long long)((long long)(int)x1 * ci[1]);
-                    u += (unsigned long long)((long long)(int)x2 * ci[2]);
-                    u += (unsigned long long)((long long)(int)y1 * ci[3]);
-                    u += (unsigned long long)((long long)(int)y2 * ci[4]);
-                    acc = (long long)u;
-                    const int hi = (int)(acc >> 32);
-                    if (hi >= (1 << 27)) acc = (1ll << 59) - 1;
-                    else if (hi <= 1 - (1 << 27)) acc = -(1ll << 59);
-                    x2 = x1; x1 = xin; y2 = y1;
-                    y1 = (unsigned)(int)(acc >> 28);
-                } else {
-                    /* dsp_biquadSTD.h:87-117: exact float x float products, five sequential f64 adds */
-                    const double dxin = mulop(__uint_as_float(xin));
-                    acc = __builtin_fma(dxin, cd[0], acc);
-                    acc = __builtin_fma(dx1, cd[1], acc);
-                    acc = __builtin_fma(dx2, cd[2], acc);
-                    acc = __builtin_fma(dy1, cd[3], acc);
-                    acc = __builtin_fma(dy2, cd[4], acc);
-                    const float yn = (float)acc;
-                    x2 = x1; x1 = xin; y2 = y1; y1 = __float_as_uint(yn);
-                    dx2 = dx1; dx1 = dxin; dy2 = dy1; dy1 = mulop(yn);
-                }
-                yprev = y1;
-                if (last) {
-                    if (c.fir_taps) a.xmid[(size_t)cid * a.xmid_stride + n] = __uint_as_float(narrow_stage<FMT>(acc));
-                    else emit_out(a.io, c, n, store_stage<FMT>(acc, c.sat, a.io.store_mask));
-                }
+        ib = hand_rotate<FMT, kRowRor15>(ib);
+        ob_lo = dpp_mov<kRowRor1>(ob_lo, ob_lo);
+        ob_hi = dpp_mov<kRowRor1>(ob_hi, ob_hi);
+        bool act = true;
+        if constexpr (decltype(masked)::value) { const int n = t - s; act = lane_on && n >= 0 && n < B; }
+        if (act) {
+            if constexpr (FMT == 2) {
+                /* dsp_biquadSTD.h:37-74: five 32x32 MACs onto the previous full-precision output,
+                 * saturate on the high word, keep acc, y = acc >> 28                              */
+                unsigned long long u = (unsigned long long)acc;
+                u += (unsigned long long)((long long)(int)xin.y * ci[0]);
+                u += (unsigned long long)((long long)(int)x1 * ci[1]);
+                u += (unsigned long long)((long long)(int)x2 * ci[2]);
+                u += (unsigned long long)((long long)(int)y1 * ci[3]);
+                u += (unsigned long long)((long long)(int)y2 * ci[4]);
+                acc = (long long)u;
+                const int hi = (int)(acc >> 32);
+                if (hi >= (1 << 27)) acc = (1ll << 59) - 1;
+                else if (hi <= 1 - (1 << 27)) acc = -(1ll << 59);
+                x2 = x1; x1 = xin.y; y2 = y1;
+                y1 = (unsigned)(int)(acc >> 28);
+                hy.y = y1;
+            } else {
+                /* dsp_biquadSTD.h:87-117: exact float x float products, five sequential f64 adds */
+                const double dxin = __longlong_as_double((long long)(((unsigned long long)xin.hi << 32) | xin.lo));
+                acc = __builtin_fma(dxin, cd[0], acc);
+                acc = __builtin_fma(dx1, cd[1], acc);
+                acc = __builtin_fma(dx2, cd[2], acc);
+                acc = __builtin_fma(dy1, cd[3], acc);
+                acc = __builtin_fma(dy2, cd[4], acc);
+                const float yn = (float)acc;
+                x2 = x1; x1 = xin.y; y2 = y1; y1 = __float_as_uint(yn);
+                dx2 = dx1; dx1 = dxin; dy2 = dy1; dy1 = mulop(yn);
+                const unsigned long long dd = (unsigned long long)__double_as_longlong(dy1);
+                hy.y = y1; hy.lo = (unsigned)dd; hy.hi = (unsigned)(dd >> 32);
+            }
+            if (last) {
+                unsigned long long bits;
+                if constexpr (FMT == 2) bits = (unsigned long long)acc;
+                else bits = (unsigned long long)__double_as_longlong(acc);
+                ob_lo = (unsigned)bits; ob_hi = (unsigned)(bits >> 32);
             }
         }
+    };
+
+    const int steps = B + nsec - 1;
+    const int nbatches = (steps + NB - 1) / NB;
+    auto next_batch = [&](int b) -> Hand<FMT> {         /* batch b's samples, converted once; refill the queue */
+        Hand<FMT> h = hand_from_sample<FMT>(rawq[0], c);
 #pragma unroll
-        for (int i = 0; i < U; i++) cur[i] = nxt[i];
+        for (int k = 0; k + 1 < DEPTH; k++) rawq[k] = rawq[k + 1];
+        rawq[DEPTH - 1] = fetch(b + DEPTH);
+        return h;
+    };
+    Hand<FMT> ib = next_batch(0);
+    for (int b = 0; b < nbatches; b++) {
+        const int tb = b * NB;
+        if (tb >= nsec - 1 && tb + NB <= B) {           /* every lane busy for the whole batch */
+#pragma unroll
+            for (int i = 0; i < NB; i++) step(ib, tb + i, std::false_type{});
+        } else {
+#pragma unroll
+            for (int i = 0; i < NB; i++) step(ib, tb + i, std::true_type{});
+        }
+        /* The next batch's loads were issued three batches ago: waiting for them here, BEFORE this
+         * batch's stores are issued, never waits on a fresh memory operation.                     */
+        ib = next_batch(b + 1);
+        /* flush the output batch: this lane holds the result of step tb + ostep of chain `ocid` */
+        const int n = tb + ostep - (nsec - 1);
+        if (owner && n >= 0 && n < B) {
+            const unsigned long long bits = ((unsigned long long)ob_hi << 32) | ob_lo;
+            alu_t X;
+            if constexpr (FMT == 2) X = (long long)bits; else X = __longlong_as_double((long long)bits);
+            if (oc.fir_taps) a.xmid[(size_t)ocid * a.xmid_stride + n] = __uint_as_float(narrow_stage<FMT>(X));
+            else emit_out(a.io, oc, n, store_stage<FMT>(X, oc.sat, a.io.store_mask));
+        }
     }
 
     if (lane_on) {
@@ -394,19 +503,22 @@ struct FirArgs {
     const float    *xmid;
     int             xmid_stride;
     int             per_xcd;
-    int             hs_cap;          /* floats reserved for the taps image */
+    int             hs_cap;          /* doubles reserved for the taps image */
     int             win_row;         /* words per row of the transposed window image */
+    int             debug;           /* timing experiments only: 1 skip state write-back, 2 skip staging, 4 skip stores */
     BlockIO         io;
 };
 
-/* LDS images (floats, subnormals already flushed to +0 as dspMulFloatDouble would treat them).
- *   taps    hs[t + 16] for t in [-16, T + 96): zero outside [0, T)
+/* LDS images (DOUBLES: every operand is converted once while staging instead of once per MFMA;
+ * subnormal floats are flushed to +0 first, as dspMulFloatDouble would treat them).
+ *   taps    hs[t + 16] for t in [-16, T + 208): zero outside [0, T)
  *   window  sample index q sits at position w = q + T + kWinOff (q < 0: history, st[i] <-> q = -1-i;
  *           0 <= q < B: this block; zero elsewhere), stored TRANSPOSED in 16 rows:
  *           pos(w) = (w & 15) * row + (w >> 4).  The MFMA B operand reads x[16(a0+j) - m - k]:
  *           the 16 lanes j of one k are then 16 consecutive words (conflict free), and with
- *           row = 16 (mod 32) the two k values sharing a 32-lane LDS pass land 16 banks apart.   */
-constexpr int kWinOff = 64, kTapPad = 112;
+ *           row = 16 (mod 32) elements the two k values sharing a 32-lane ds_read_b64 pass use
+ *           disjoint halves of the 64 banks.                                                     */
+constexpr int kWinOff = 192, kTapPad = 224;     /* room for the operand prefetch to run past both ends */
 
 __device__ __forceinline__ int win_pos(int w, int row) { return (w & 15) * row + (w >> 4); }
 
@@ -426,42 +538,75 @@ __device__ __forceinline__ float fir_input(const FirArgs &a, const avdsp_chain &
     return __uint_as_float(narrow_stage<FMT>(load_stage<FMT>(raw, c.load_mode, c.gain_bits)));
 }
 
+/* Stage one channel: taps and the input window (history + this block) into LDS as flushed doubles,
+ * AND advance the delay line in the same pass: st[i] <- x[B-1-i] (dsp_firSTD.h:45-50 applied B
+ * times).  Old history words are read once, used for the LDS window, and written back B places
+ * further up; the raw floats are written, so the state area stays bit-identical to the reference's.
+ * In-place safety: history is processed in super-chunks from the top down, every thread finishes
+ * its reads (vmcnt(0)) before the barrier that precedes the chunk's writes, and a chunk only writes
+ * words at or above its own range.  All loads of a chunk are in flight together.                 */
 template <int FMT>
 __device__ __forceinline__ void fir_stage_lds(const FirArgs &a, const avdsp_chain &c, int cid,
-                                              float *hs, float *xs, int row)
+                                              double *hs, double *xs, int row, bool advance_state)
 {
     const int T = c.fir_taps, B = a.io.nframes, nt = blockDim.x, tid = threadIdx.x;
     const float *taps = reinterpret_cast<const float *>(a.buf + c.fir_coef_word);
-    const float *hist = reinterpret_cast<const float *>(a.buf + c.fir_state_word);
-    /* zero everything first (pads, future samples, rows' tails), then drop the real data in */
-    for (int u = tid; u < 16; u += nt) hs[u] = 0.0f;
-    for (int u = T + 16 + tid; u < T + kTapPad; u += nt) hs[u] = 0.0f;
-    for (int u = tid; u < 16 * row; u += nt) xs[u] = 0.0f;
-    __syncthreads();
-#pragma unroll 4
-    for (int t = tid; t < T; t += nt) hs[16 + t] = flush_f32(taps[t]);
-#pragma unroll 4
-    for (int i = tid; i < T; i += nt) xs[win_pos(T + kWinOff - 1 - i, row)] = flush_f32(hist[i]);
-#pragma unroll 4
-    for (int q = tid; q < B; q += nt) xs[win_pos(T + kWinOff + q, row)] = flush_f32(fir_input<FMT>(a, c, cid, q));
-}
-
-/* New delay line st[i] = x[B-1-i] (dsp_firSTD.h:45-50 applied B times), from the raw values so that
- * the state area stays bit-identical to the reference's.  For B < T this shifts the old line up by
- * B in place: chunks run from the top down, each reads before it writes (barrier in between), and
- * no chunk reads a word an earlier chunk has already overwritten.                               */
-template <int FMT>
-__device__ __forceinline__ void fir_write_state(const FirArgs &a, const avdsp_chain &c, int cid)
-{
-    const int T = c.fir_taps, B = a.io.nframes, nt = blockDim.x;
     float *hist = reinterpret_cast<float *>(a.buf + c.fir_state_word);
-    for (int hi = T; hi > 0; hi -= nt) {
-        const int i = hi - 1 - (int)threadIdx.x;
-        float v = 0.0f;
-        if (i >= 0) v = (i < B) ? fir_input<FMT>(a, c, cid, B - 1 - i) : hist[i - B];
-        __syncthreads();
-        if (i >= 0) hist[i] = v;
-        __syncthreads();
+    constexpr int U = 16;
+    const int span = U * nt;
+
+    /* first super-chunk of taps and the top super-chunk of history: loads issued before anything else */
+    float tv[U], hv[U], xv[4];
+    const int htop = ((T - 1) / span) * span;            /* base of the highest history super-chunk */
+#pragma unroll
+    for (int u = 0; u < U; u++) { const int t = u * nt + tid; tv[u] = t < T ? taps[t] : 0.0f; }
+#pragma unroll
+    for (int u = 0; u < U; u++) { const int i = htop + u * nt + tid; hv[u] = i < T ? hist[i] : 0.0f; }
+
+    /* zero fill (pads, future samples, row tails) while those loads fly */
+    for (int u = tid; u < 16; u += nt) hs[u] = 0.0;
+    for (int u = T + 16 + tid; u < T + kTapPad; u += nt) hs[u] = 0.0;
+    for (int u = tid; u < 16 * row; u += nt) xs[u] = 0.0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+#pragma unroll
+    for (int u = 0; u < U; u++) { const int t = u * nt + tid; if (t < T) hs[16 + t] = mulop(tv[u]); }
+    for (int t0 = span; t0 < T; t0 += span) {            /* more than 16 x blockDim taps */
+#pragma unroll
+        for (int u = 0; u < U; u++) { const int t = t0 + u * nt + tid; tv[u] = t < T ? taps[t] : 0.0f; }
+#pragma unroll
+        for (int u = 0; u < U; u++) { const int t = t0 + u * nt + tid; if (t < T) hs[16 + t] = mulop(tv[u]); }
+    }
+
+    for (int i0 = htop; i0 >= 0; i0 -= span) {
+        if (i0 != htop) {
+#pragma unroll
+            for (int u = 0; u < U; u++) { const int i = i0 + u * nt + tid; hv[u] = i < T ? hist[i] : 0.0f; }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i = i0 + u * nt + tid;
+            if (i < T) {
+                xs[win_pos(T + kWinOff - 1 - i, row)] = mulop(hv[u]);
+                if (advance_state && i + B < T) hist[i + B] = hv[u];
+            }
+        }
+    }
+    /* this block's samples: into the window, and (newest first) into the bottom of the delay line */
+    for (int q0 = 0; q0 < B; q0 += 4 * nt) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int q = q0 + u * nt + tid; xv[u] = q < B ? fir_input<FMT>(a, c, cid, q) : 0.0f; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int q = q0 + u * nt + tid;
+            if (q < B) {
+                xs[win_pos(T + kWinOff + q, row)] = mulop(xv[u]);
+                if (advance_state && B - 1 - q < T) hist[B - 1 - q] = xv[u];
+            }
+        }
     }
 }
 
@@ -470,15 +615,15 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 template <int FMT>
 __global__ __launch_bounds__(kBlock) void fir_mfma(const FirArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+    extern __shared__ __attribute__((aligned(16))) double lds[];
     const int slot = xcd_remap(blockIdx.x, a.per_xcd);
     if (slot >= a.ngroup) return;
     const int cid = a.group[slot];
     const avdsp_chain c = a.chains[cid];
-    float *hs = lds, *xs = lds + a.hs_cap;
+    double *hs = lds, *xs = lds + a.hs_cap;
     const int tiles = blockDim.x >> 6;                  /* one wave per 256-frame tile */
     const int row = a.win_row;
-    fir_stage_lds<FMT>(a, c, cid, hs, xs, row);
+    if (!(a.debug & 2)) fir_stage_lds<FMT>(a, c, cid, hs, xs, row, !(a.debug & 1));
     __syncthreads();
 
     const int T = c.fir_taps, B = a.io.nframes;
@@ -490,63 +635,69 @@ __global__ __launch_bounds__(kBlock) void fir_mfma(const FirArgs a)
      * by -4 and wraps once, so each lane keeps four fixed LDS addresses that move by one word per
      * group: pos = K[s] - g.                                                                      */
     const int a0 = wave * 16;
-    const int ngroups = (((T + 15 + 15) >> 4) + 1) & ~1;  /* 16 values of m per group; even count (zero taps pad the tail) */
-    const float *hp = hs + (16 - 15 + k + ij);          /* h[m + k + i] at m = -15; +4 per step */
+    const int nsets = (((T + 15 + 15) >> 4) + 3) >> 2;   /* 16 values of m per group, 4 groups per operand set */
+    const double *hp = hs + (16 - 15 + k + ij);         /* h[m + k + i] at m = -15; +4 per step */
     const int f = 16 * a0 + 15 - k + (T + kWinOff);     /* window position at step 0 for j = 0 */
-    const float *xp[4];
+    const double *xp[4];
 #pragma unroll
     for (int s = 0; s < 4; s++) xp[s] = xs + win_pos(f - 4 * s, row) + ij;
     v4f64 acc = {0.0, 0.0, 0.0, 0.0};
-    float h0[4], x0[4], h1[4], x1[4];                   /* two operand sets: one feeds the MFMAs while the other loads */
+    /* Two operand sets of 16 MFMAs each: one feeds the matrix pipe while the other is being read.
+     * Per row the four groups of a set are four adjacent words, so the reads pair up (ds_read2_b64):
+     * about one LDS instruction per MFMA, which is what bounds this loop (tools/fir_loop_bench2.hip). */
+    double ha[16], xa[16], hb[16], xb[16];
+    auto load_set = [&](double *h, double *x, int g) {  /* groups g .. g+3 */
 #pragma unroll
-    for (int s = 0; s < 4; s++) { h0[s] = hp[4 * s]; x0[s] = xp[s][0]; }
-    for (int g = 0; g < ngroups; g += 2) {
+        for (int q = 0; q < 4; q++)
 #pragma unroll
-        for (int s = 0; s < 4; s++) { h1[s] = hp[16 * (g + 1) + 4 * s]; x1[s] = xp[s][-(g + 1)]; }
+            for (int s = 0; s < 4; s++) { h[4 * q + s] = hp[16 * (g + q) + 4 * s]; x[4 * q + s] = xp[s][-(g + q)]; }
+    };
+    auto mfma_set = [&](const double *h, const double *x) {
+#pragma unroll
+        for (int u = 0; u < 16; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(h[u], x[u], acc, 0, 0, 0);
+    };
+    load_set(ha, xa, 0);
+    int st = 0;
+    for (; st + 2 <= nsets; st += 2) {
+        load_set(hb, xb, 4 * (st + 1));
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int s = 0; s < 4; s++)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)h0[s], (double)x0[s], acc, 0, 0, 0);
+        mfma_set(ha, xa);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int s = 0; s < 4; s++) { h0[s] = hp[16 * (g + 2) + 4 * s]; x0[s] = xp[s][-(g + 2)]; }
+        load_set(ha, xa, 4 * (st + 2));
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int s = 0; s < 4; s++)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)h1[s], (double)x1[s], acc, 0, 0, 0);
+        mfma_set(hb, xb);
         __builtin_amdgcn_sched_barrier(0);
     }
+    if (st < nsets) mfma_set(ha, xa);                    /* odd number of sets */
     /* C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg */
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int n = 16 * (a0 + ij) + k + 4 * r;
-        if (n < B) emit_out(a.io, c, n, store_stage<FMT>(acc[r], c.sat, a.io.store_mask));
+        if (n < B && !(a.debug & 4)) emit_out(a.io, c, n, store_stage<FMT>(acc[r], c.sat, a.io.store_mask));
     }
     (void)tiles;
-    fir_write_state<FMT>(a, c, cid);
 }
 
 template <int FMT>
 __global__ __launch_bounds__(kBlock) void fir_plain(const FirArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+    extern __shared__ __attribute__((aligned(16))) double lds[];
     const int slot = xcd_remap(blockIdx.x, a.per_xcd);
     if (slot >= a.ngroup) return;
     const int cid = a.group[slot];
     const avdsp_chain c = a.chains[cid];
-    float *hs = lds, *xs = lds + a.hs_cap;
+    double *hs = lds, *xs = lds + a.hs_cap;
     const int row = a.win_row;
-    fir_stage_lds<FMT>(a, c, cid, hs, xs, row);
+    fir_stage_lds<FMT>(a, c, cid, hs, xs, row, true);
     __syncthreads();
     const int T = c.fir_taps, B = a.io.nframes;
     for (int n = threadIdx.x; n < B; n += blockDim.x) {
         double acc = 0.0;                               /* dsp_firSTD.h:43-50: taps in ascending order */
         const int w0 = n + T + kWinOff;
         for (int t = 0; t < T; t++)
-            acc = __builtin_fma((double)xs[win_pos(w0 - t, row)], (double)hs[16 + t], acc);
+            acc = __builtin_fma(xs[win_pos(w0 - t, row)], hs[16 + t], acc);
         emit_out(a.io, c, n, store_stage<FMT>(acc, c.sat, a.io.store_mask));
     }
-    fir_write_state<FMT>(a, c, cid);
 }
 
 /* chains with neither biquads nor FIR: LOAD -> [SAT0DB] -> STORE */
@@ -577,8 +728,8 @@ struct Plan {
     avdsp_chain *d_chains = nullptr;
     int *d_sec_coef = nullptr, *d_sec_state = nullptr;
     /* launch groups (device arrays of chain ids) */
-    struct Group { int P; int n; int *d_ids; };
-    std::vector<Group> bq;            /* biquad chains grouped by lanes-per-chain */
+    struct Group { int P; int nsec; int n; int *d_ids; };
+    std::vector<Group> bq;            /* biquad chains grouped by section count (P = lanes per chain) */
     int *d_fir_ids = nullptr;  int n_fir = 0, max_taps = 0;
     int *d_pass_ids = nullptr; int n_pass = 0;
     bool need_xmid = false;
@@ -626,7 +777,7 @@ size_t fir_lds_bytes(int max_taps, int tiles, int *hs_cap, int *row)
     const int hs = max_taps + kTapPad;
     *hs_cap = (hs + 3) & ~3;
     *row = win_row(max_taps, tiles * kTileFrames);
-    return (size_t)(*hs_cap + 16 * *row) * sizeof(float);
+    return (size_t)(*hs_cap + 16 * *row) * sizeof(double);
 }
 
 hipEvent_t take_event(avdsp_hip_prog *prog)
@@ -656,11 +807,13 @@ struct ProfileScope {                   /* records an event pair around the laun
 template <int FMT>
 int launch_all(avdsp_hip_prog *prog, Plan &pl, BlockIO io, int fir_impl, int biquad_impl, hipStream_t stream)
 {
+    const int debug = fir_impl >> 8;                    /* timing experiments ride in the high bits */
+    fir_impl &= 0xFF;
     for (auto &g : pl.bq) {
         ProfileScope scope(prog, stream, AVDSP_KERNEL_BIQUAD);
         BiquadArgs a{};
         a.buf = prog->d_buf; a.chains = pl.d_chains; a.sec_coef = pl.d_sec_coef; a.sec_state = pl.d_sec_state;
-        a.group = g.d_ids; a.ngroup = g.n; a.xmid = prog->d_xmid; a.xmid_stride = kFirChunk; a.io = io;
+        a.group = g.d_ids; a.ngroup = g.n; a.nsec = g.nsec; a.xmid = prog->d_xmid; a.xmid_stride = kFirChunk; a.io = io;
         if (biquad_impl == 0 || g.P > 64) {
             hipLaunchKernelGGL(biquad_simple<FMT>, dim3((g.n + 63) / 64), dim3(64), 0, stream, a);
         } else {
@@ -685,7 +838,7 @@ int launch_all(avdsp_hip_prog *prog, Plan &pl, BlockIO io, int fir_impl, int biq
             ProfileScope scope(prog, stream, AVDSP_KERNEL_FIR);
             FirArgs a{};
             a.buf = prog->d_buf; a.chains = pl.d_chains; a.group = pl.d_fir_ids; a.ngroup = pl.n_fir;
-            a.xmid = prog->d_xmid; a.xmid_stride = kFirChunk; a.io = io;
+            a.xmid = prog->d_xmid; a.xmid_stride = kFirChunk; a.io = io; a.debug = debug;
             a.per_xcd = (pl.n_fir + 7) / 8;
             const int tiles = (io.nframes + kTileFrames - 1) / kTileFrames;
             const size_t lds = fir_lds_bytes(pl.max_taps, tiles, &a.hs_cap, &a.win_row);
@@ -759,7 +912,7 @@ int avdsp_hip_prog_add_plan(avdsp_hip_prog *prog, const avdsp_plan_desc *d)
     for (int i = 0; i < d->nsections; i++)
         if (coef[i] < 0 || coef[i] + 5 > prog->total_words || state[i] < 0 || state[i] + 6 > prog->total_words || (state[i] & 1))
             return set_err("section %d addresses words outside the loaded buffer", i);
-    std::vector<std::vector<int>> byP(8);
+    std::vector<std::pair<int, std::vector<int>>> byN;   /* (section count, chain ids) in first-seen order */
     std::vector<int> fir, pass;
     pl.io_in_min = pl.io_out_min = 0x7FFFFFFF; pl.io_in_max = pl.io_out_max = -1;
     for (int i = 0; i < d->nchains; i++) {
@@ -781,19 +934,17 @@ int avdsp_hip_prog_add_plan(avdsp_hip_prog *prog, const avdsp_plan_desc *d)
             if (c.nsec) pl.need_xmid = true;
         }
         if (c.nsec) {
-            int P = pow2ceil(c.nsec), idx = 0;
-            while ((1 << idx) < P) idx++;
-            if (idx > 7) idx = 7;                        /* > 64 sections: biquad_simple */
-            byP[idx].push_back(i);
+            auto it = std::find_if(byN.begin(), byN.end(), [&](const auto &e) { return e.first == c.nsec; });
+            if (it == byN.end()) { byN.push_back({c.nsec, {}}); it = byN.end() - 1; }
+            it->second.push_back(i);
         } else if (!c.fir_taps) pass.push_back(i);
     }
     if (upload_vec(&pl.d_chains, chains) || upload_vec(&pl.d_sec_coef, coef) || upload_vec(&pl.d_sec_state, state)) { free_plan(pl); return -1; }
-    for (int idx = 0; idx < 8; idx++)
-        if (!byP[idx].empty()) {
-            Plan::Group g{idx == 7 ? 128 : (1 << idx), (int)byP[idx].size(), nullptr};
-            if (upload_vec(&g.d_ids, byP[idx])) { free_plan(pl); return -1; }
-            pl.bq.push_back(g);
-        }
+    for (auto &e : byN) {                                /* > 64 sections (P = 128): biquad_simple */
+        Plan::Group g{e.first > 64 ? 128 : pow2ceil(e.first), e.first, (int)e.second.size(), nullptr};
+        if (upload_vec(&g.d_ids, e.second)) { free_plan(pl); return -1; }
+        pl.bq.push_back(g);
+    }
     pl.n_fir = (int)fir.size(); pl.n_pass = (int)pass.size();
     if (upload_vec(&pl.d_fir_ids, fir) || upload_vec(&pl.d_pass_ids, pass)) { free_plan(pl); return -1; }
     if (pl.need_xmid && prog->xmid_chains < (size_t)d->nchains) {
