@@ -76,6 +76,7 @@ static struct {
 } G = { .opt_fir_impl = 1, .opt_biquad_impl = 1, .opt_device = -1 };
 
 static char g_err[512];
+static int  g_err_code;
 
 static int fail(int code, const char *fmt, ...)
 {
@@ -83,6 +84,7 @@ static int fail(int code, const char *fmt, ...)
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof g_err, fmt, ap);
     va_end(ap);
+    g_err_code = code;
     return code;
 }
 
@@ -431,14 +433,27 @@ int dspRuntimeKernelTime(int kind, double *total_ms, int *launches)
     return 0;
 }
 
+/* Host-only: lowers the core (no device is touched) and reports what the plan would contain. */
 int dspRuntimeCoreInfo(int format, opcode_t *core, int *nchains, int *max_sections, int *max_taps)
 {
-    core_plan *cp = get_plan(format, core);
-    if (!cp) return -8;
-    if (nchains) *nchains = cp->nchains;
-    if (max_sections) *max_sections = cp->max_sections;
-    if (max_taps) *max_taps = cp->max_taps;
-    return 0;
+    if (!dspHeaderPtr || !G.code) return fail(-1, "no program loaded");
+    if (!G.have_rate) return fail(-1, "dspRuntimeReset(fs) has not selected a sample rate yet");
+    if (format != 2 && format != 4 && format != 6) return fail(-1, "DSP_FORMAT %d has no device path (2, 4, 6 do)", format);
+    if (core < G.code || core >= G.code + dspHeaderPtr->totalLength) return fail(-1, "core pointer outside the loaded program");
+    lowered L;
+    int rc = lower_core(format, core, &L);
+    if (rc == 0) {
+        int ms = 0, mt = 0;
+        for (int i = 0; i < L.nchains; i++) {
+            if (L.chains[i].nsec > ms) ms = L.chains[i].nsec;
+            if (L.chains[i].fir_taps > mt) mt = L.chains[i].fir_taps;
+        }
+        if (nchains) *nchains = L.nchains;
+        if (max_sections) *max_sections = ms;
+        if (max_taps) *max_taps = mt;
+    }
+    lowered_free(&L);
+    return rc;
 }
 
 static int check_rundata(const int *rundata)
@@ -453,7 +468,7 @@ int dspRuntimeBlockDevice(int format, opcode_t *core, int *rundata,
                           void *d_out, int out_stride, int out_io_base, int nframes, void *stream)
 {
     core_plan *cp = get_plan(format, core);
-    if (!cp) return -8;
+    if (!cp) return g_err_code;
     if (check_rundata(rundata)) return -1;
     if (nframes <= 0) return 0;
     if (avdsp_hip_run_block(G.dev, cp->plan_id, d_in, in_stride, in_io_base, d_out, out_stride, out_io_base,
@@ -466,7 +481,7 @@ static int block_host(int format, opcode_t *core, int *rundata, const void *in, 
                       void *out, int out_stride, int out_io_base, int nframes)
 {
     core_plan *cp = get_plan(format, core);
-    if (!cp) return -8;
+    if (!cp) return g_err_code;
     if (check_rundata(rundata)) return -1;
     if (nframes <= 0) return 0;
     if (avdsp_hip_run_block_host(G.dev, cp->plan_id, in, in_stride, in_io_base, out, out_stride, out_io_base,
@@ -492,7 +507,7 @@ int dspRuntimeBlock_6(opcode_t *core, int *rundata, const float *in, int in_stri
 static int one_frame(int format, opcode_t *core, int *rundata, void *samples)
 {
     core_plan *cp = get_plan(format, core);
-    if (!cp) return -8;
+    if (!cp) return g_err_code;
     /* the device side knows the IO span of the plan: stride 0 asks it to use that span */
     return block_host(format, core, rundata, samples, 0, 0, samples, 0, 0, 1);
 }

@@ -49,6 +49,17 @@ PEAK_F64_TFLOPS = 78.6
 PEAK_HBM_GBS = 8000.0
 
 
+def pmc_traffic(workload, kernel):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same
+    command (profiles/traffic.json, produced by tools/summarize_prof.py --traffic; FETCH_SIZE doubled
+    per the gfx950 correction of MI355X_MICROARCH.md, WRITE_SIZE as read).  None when not profiled."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            return json.load(f).get(workload, {}).get(kernel)
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline_reference(fmt, S, T, B, budget_s=12.0):
     """The COMPILED REFERENCE (oracle/_ref, built in the build container from /root/reference with its
     own -Ofast flags; binaries travel to the GPU box): one ref_driver process per host core, each with
@@ -162,6 +173,7 @@ def main():
     import torch.distributed as dist
     from avdsp_amd import progbuilder as pb
     from avdsp_amd import runtime as rt
+    from avdsp_amd import sharding as sh
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -180,9 +192,9 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    base = rank * C                                        # this rank's slice of the global channel numbering
-    taps = pb.lcg_taps_all(C, T, base) if T else None
-    prog = pb.synth_program(fmt, C, S, T, taps=taps, channel_base=base)
+    # weak scaling: the job is C*world channels, this rank owns the contiguous slice [rank*C, (rank+1)*C)
+    prog, ch_lo, ch_hi = sh.shard_program(fmt, C * world, S, T, world, rank)
+    assert ch_hi - ch_lo == C
     r = rt.Runtime(fmt, prog)
     if r.rc < 0:
         sys.exit(f"dspRuntimeInit failed: {r.rc} {r.last_error()}")
@@ -231,15 +243,17 @@ def main():
             per_launch = fir_ms / fir_n * 1e-3
             flops = 2.0 * T * B * C                        # 2*T flop per sample, C*B samples per launch
             ach = flops / per_launch / 1e12
-            roof = dict(bound="mfma", kernel="fir_mfma" if args.fir_impl else "fir_plain", achieved=ach,
-                        peak=PEAK_F64_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_F64_TFLOPS, traffic=None,
+            kname = "fir_mfma" if args.fir_impl else "fir_plain"
+            roof = dict(bound="mfma", kernel=kname, achieved=ach,
+                        peak=PEAK_F64_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_F64_TFLOPS, traffic=pmc_traffic(args.workload, kname),
                         launch_ms=per_launch * 1e3, launches=fir_n)
         elif bq_n:
             per_launch = bq_ms / bq_n * 1e-3
             nbytes = 8.0 * C * B + 48.0 * S * C + 20.0 * S * C   # samples in+out, state r+w, coefficients
             ach = nbytes / per_launch / 1e9
-            roof = dict(bound="hbm", kernel="biquad_pipe" if args.biquad_impl else "biquad_simple", achieved=ach,
-                        peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS, traffic=None,
+            kname = "biquad_pipe" if args.biquad_impl else "biquad_simple"
+            roof = dict(bound="hbm", kernel=kname, achieved=ach,
+                        peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS, traffic=pmc_traffic(args.workload, kname),
                         launch_ms=per_launch * 1e3, launches=bq_n)
         else:
             roof = None

@@ -1,0 +1,114 @@
+"""CPU-only checks of the C-ABI library: it loads, exports every symbol include/*.h declares, and the
+host-side logic (validation, core lookup, lowering, refusals) behaves like the reference API says.
+No compute call is made here: without a GPU the block entry points must FAIL (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from avdsp_amd import progbuilder as pb
+from avdsp_amd import runtime as rt
+from tests.golden_recipes import GOLDEN_DIR
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(autouse=True)
+def _release():
+    yield
+    rt.lib().dspRuntimeRelease()
+
+
+def declared_functions(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{]*\)\s*;", text)
+    return [n for n in names if n.startswith(("dsp", "avdsp_hip_"))]
+
+
+def test_library_exports_everything_the_headers_declare():
+    L = rt.lib()
+    fns = declared_functions("avdsp_runtime.h") + declared_functions("avdsp_hip.h")
+    assert len(fns) > 30
+    missing = [n for n in fns if not hasattr(L, n)]
+    assert not missing, missing
+    for name in rt.EXPORTED + ["dspHeaderPtr", "dspBiquadFreqSkip", "dspMantissa", "dspOpcodeText"]:
+        assert hasattr(L, name), name
+
+
+def test_reference_data_symbols():
+    L = rt.lib()
+    txt = (C.c_char_p * 62).in_dll(L, "dspOpcodeText")
+    assert txt[0] == b"DSP_END_OF_CODE" and txt[50] == b"DSP_BIQUADS" and txt[51] == b"DSP_FIR" and txt[61] == b"DSP_SINE"
+    assert txt[3] == b"\nDSP_CORE"                         # dsp_header.c:10-73 keeps those newlines
+    assert C.c_int.in_dll(L, "dspMantissa").value == 28
+    # dspQNM family (dsp_header.h:276-285): truncation toward zero, saturation
+    assert L.dspQM32(0.5, 28) == 1 << 27
+    assert L.dspQM32(-0.75, 28) == -(3 << 26)
+    assert L.dspQM32(9.0, 28) == 0x7FFFFFFF
+    assert L.dspQM32(-9.0, 28) == -(1 << 31)
+    assert L.dspQNM(1.0, 4, 28) == 1 << 28
+    assert L.dspQM64(1.0, 40) == 1 << 40
+
+
+def test_find_core_and_init_on_committed_program():
+    prog = np.fromfile(os.path.join(GOLDEN_DIR, "crossoverLV6.bin"), dtype=np.uint32)
+    r = rt.Runtime(2, prog, fs=48000, dither=24)
+    assert r.rc == 288                                      # header.totalLength, as the reference returns
+    assert len(r.cores) == 2
+    base = r.buf.ctypes.data
+    # CORE words at 121 and 156; execution starts behind them (core 2 also skips its PARAM)
+    assert (r.cores[0] - base) // 4 == 124
+    assert (r.cores[1] - base) // 4 == 269
+    assert C.c_int.in_dll(r.L, "dspBiquadFreqSkip").value == 2 + 6 * 4      # 44.1k .. 96k encoded
+    assert r.reset(192000) == -2 and r.reset(12345) == -1 and r.reset(96000) == 0
+
+
+def test_lowering_reports_chains():
+    r = rt.Runtime(6, pb.synth_program(6, 5, 3, 7))
+    assert r.core_info() == dict(chains=5, max_sections=3, max_taps=7)
+    r = rt.Runtime(2, pb.synth_program(2, 64, 16))
+    assert r.core_info() == dict(chains=64, max_sections=16, max_taps=0)
+
+
+def test_refusals_are_loud():
+    prog = np.fromfile(os.path.join(GOLDEN_DIR, "crossoverLV6.bin"), dtype=np.uint32)
+    r = rt.Runtime(2, prog, fs=48000, dither=24)
+    with pytest.raises(rt.AvdspError) as e:
+        r.core_info(0)
+    assert e.value.code == -8 and "DSP_TPDF_CALC" in str(e.value)
+    r = rt.Runtime(2, pb.synth_program(2, 2, 1, 9))          # FIR in int64 mode: undefined in the reference
+    with pytest.raises(rt.AvdspError) as e:
+        r.core_info()
+    assert e.value.code == -8 and "undefined behaviour" in str(e.value)
+    r = rt.Runtime(2, pb.synth_program(6, 2, 1))             # float-encoded program, int64 entry point
+    with pytest.raises(rt.AvdspError) as e:
+        r.core_info()
+    assert e.value.code == -7
+    # a chain that loads what another chain of the same core stores is a sequential dependency
+    pw = pb.ProgramWriter(6)
+    pw.core(); pw.load(4); pw.store(1); pw.load(1); pw.store(2)
+    r = rt.Runtime(6, pw.end_of_code())
+    with pytest.raises(rt.AvdspError) as e:
+        r.core_info()
+    assert e.value.code == -8 and "cross-chain" in str(e.value)
+    # two chains storing the same IO
+    pw = pb.ProgramWriter(6)
+    pw.core(); pw.load(4); pw.store(1); pw.load(5); pw.store(1)
+    r = rt.Runtime(6, pw.end_of_code())
+    with pytest.raises(rt.AvdspError):
+        r.core_info()
+
+
+def test_no_cpu_fallback_without_a_gpu():
+    if rt.lib().avdsp_hip_device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    r = rt.Runtime(6, pb.synth_program(6, 2, 2))
+    with pytest.raises(rt.AvdspError) as e:
+        r.run_block(np.zeros((4, 2), dtype=np.float32), 2, 2)
+    assert e.value.code == -10 and "HIP" in str(e.value)
+    frame = np.zeros(4, dtype=np.float32)
+    with pytest.raises(rt.AvdspError):
+        r.run_frame(frame)

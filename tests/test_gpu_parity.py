@@ -221,7 +221,7 @@ def test_refuses_cores_it_cannot_lower():
     r = rt.Runtime(2, pb.synth_program(6, 2, 1))
     with pytest.raises(rt.AvdspError) as e:
         r.run_block(np.zeros((4, 2), dtype=np.int32), 2, 2)
-    assert e.value.code == -8 and "encoded" in str(e.value)
+    assert e.value.code == -7 and "encoded" in str(e.value)
 
 
 @pytest.mark.parametrize("neg", MANIFEST["init_return_codes"], ids=lambda n: n["case"])
