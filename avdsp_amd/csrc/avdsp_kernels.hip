@@ -178,6 +178,20 @@ __device__ __forceinline__ unsigned store_stage(typename Alu<FMT>::type X, int s
  * 128-byte lines of the interleaved sample block) in the same L2.  Speed only, never correctness. */
 __device__ __forceinline__ int xcd_remap(int b, int per_xcd) { return (b & 7) * per_xcd + (b >> 3); }
 
+/* FIR history, device-native: one ring of R floats (R a power of two) per chain.  Frame n of the block
+ * being processed lives at (wpos + n) & (R-1); older samples sit behind it.  The reference layout of
+ * the delay line (st[i] = x[n-1-i], dsp_firSTD.h:45-50) is produced from the ring only when the
+ * host asks for the state (ring_to_state) and loaded back by state_to_ring.                     */
+struct Ring {
+    float *base;
+    int    R;
+    int    wpos;
+};
+__device__ __forceinline__ float *ring_at(const Ring &r, int cid, int q)
+{
+    return r.base + (size_t)cid * r.R + ((r.wpos + q) & (r.R - 1));
+}
+
 struct BlockIO {
     const unsigned *in;  int in_stride,  in_base;
     unsigned       *out; int out_stride, out_base;
@@ -217,8 +231,7 @@ struct BiquadArgs {
     const int      *group;          /* chain ids handled by this launch (all with `nsec` sections) */
     int             ngroup;
     int             nsec;
-    float          *xmid;           /* planar [chain][xmid_stride] hand-off to the FIR kernel */
-    int             xmid_stride;
+    Ring            ring;           /* where (float)X goes when a FIR follows the cascade */
     int             per_xcd;
     BlockIO         io;
 };
@@ -424,7 +437,7 @@ __global__ __launch_bounds__(kBlock) void biquad_pipe(const BiquadArgs a)
             const unsigned long long bits = ((unsigned long long)ob_hi << 32) | ob_lo;
             alu_t X;
             if constexpr (FMT == 2) X = (long long)bits; else X = __longlong_as_double((long long)bits);
-            if (oc.fir_taps) a.xmid[(size_t)ocid * a.xmid_stride + n] = __uint_as_float(narrow_stage<FMT>(X));
+            if (oc.fir_taps) *ring_at(a.ring, ocid, n) = __uint_as_float(narrow_stage<FMT>(X));
             else emit_out(a.io, oc, n, store_stage<FMT>(X, oc.sat, a.io.store_mask));
         }
     }
@@ -487,7 +500,7 @@ __global__ __launch_bounds__(64) void biquad_simple(const BiquadArgs a)
             st[2] = (int)xin; st[3] = (int)x1; st[4] = (int)yn; st[5] = (int)y1;
             xin = yn;
         }
-        if (c.fir_taps) a.xmid[(size_t)cid * a.xmid_stride + n] = __uint_as_float(narrow_stage<FMT>(X));
+        if (c.fir_taps) *ring_at(a.ring, cid, n) = __uint_as_float(narrow_stage<FMT>(X));
         else emit_out(a.io, c, n, store_stage<FMT>(X, c.sat, a.io.store_mask));
     }
 }
@@ -500,120 +513,99 @@ struct FirArgs {
     const avdsp_chain *chains;
     const int      *group;
     int             ngroup;
-    const float    *xmid;
-    int             xmid_stride;
+    Ring            ring;
     int             per_xcd;
+    int             gpc;             /* groups of 16 tap positions per LDS chunk */
     int             hs_cap;          /* doubles reserved for the taps image */
-    int             win_row;         /* words per row of the transposed window image */
-    int             debug;           /* timing experiments only: 1 skip state write-back, 2 skip staging, 4 skip stores */
+    int             win_row;         /* doubles per row of the transposed window image */
+    int             debug;           /* timing experiments only: 2 skip staging, 4 skip stores, 8 skip global fetch, 16 skip LDS refill */
     BlockIO         io;
 };
 
-/* LDS images (DOUBLES: every operand is converted once while staging instead of once per MFMA;
- * subnormal floats are flushed to +0 first, as dspMulFloatDouble would treat them).
- *   taps    hs[t + 16] for t in [-16, T + 208): zero outside [0, T)
- *   window  sample index q sits at position w = q + T + kWinOff (q < 0: history, st[i] <-> q = -1-i;
- *           0 <= q < B: this block; zero elsewhere), stored TRANSPOSED in 16 rows:
- *           pos(w) = (w & 15) * row + (w >> 4).  The MFMA B operand reads x[16(a0+j) - m - k]:
- *           the 16 lanes j of one k are then 16 consecutive words (conflict free), and with
- *           row = 16 (mod 32) elements the two k values sharing a 32-lane ds_read_b64 pass use
- *           disjoint halves of the 64 banks.                                                     */
-constexpr int kWinOff = 192, kTapPad = 224;     /* room for the operand prefetch to run past both ends */
+constexpr int kNG  = 2;              /* groups of 16 tap positions per operand set (8 MFMAs) */
+constexpr int kMaxGpc = 78;          /* 1248 tap positions per chunk: <= 29 KB of LDS, 5 workgroups per CU */
+constexpr int kFirPad = 1024;        /* frames per launch the window image is laid out for (4 tiles) */
 
-__device__ __forceinline__ int win_pos(int w, int row) { return (w & 15) * row + (w >> 4); }
-
-__host__ __device__ inline int win_words(int taps, int frames_pad) { return taps + kWinOff + frames_pad + 16; }
-__host__ __device__ inline int win_row(int taps, int frames_pad)
+/* the operand prefetch runs up to kNG + 1 groups past the end of a chunk: both images carry that margin */
+__host__ __device__ inline int fir_hs_len(int gpc) { return 16 * gpc + 16 * (kNG + 1) + 32; }
+__host__ __device__ inline int fir_win_off(int gpc) { return 16 * gpc + 16 * (kNG + 1) + 8; }
+__host__ __device__ inline int fir_win_len(int gpc) { return kFirPad + 16 * gpc + 16 * (kNG + 2); }
+__host__ __device__ inline int fir_win_row(int gpc)
 {
-    int r = (win_words(taps, frames_pad) + 15) >> 4;
+    int r = (fir_win_len(gpc) + 15) >> 4;
     return r + ((16 - (r & 31)) & 31);               /* next value that is 16 mod 32 */
 }
+__device__ __forceinline__ int win_pos(int w, int row) { return (w & 15) * row + (w >> 4); }
+constexpr int kHRegs = (16 * kMaxGpc + 16 * (kNG + 1) + 32 + kBlock - 1) / kBlock;              /* 6 */
+constexpr int kWRegs = (kFirPad + 16 * kMaxGpc + 16 * (kNG + 2) + kBlock - 1) / kBlock;         /* 10: slots enumerate w in blocks of 256 */
 
-/* the raw (unflushed) float the FIR sees for frame q of this block: (float)X of the stage in front */
+/* FIR-only chains: the FIR's input is (float)X of the load stage; append it to the ring first */
 template <int FMT>
-__device__ __forceinline__ float fir_input(const FirArgs &a, const avdsp_chain &c, int cid, int q)
+__device__ __forceinline__ void fir_append_input(const FirArgs &a, const avdsp_chain &c, int cid)
 {
-    if (c.nsec) return a.xmid[(size_t)cid * a.xmid_stride + q];
-    const unsigned raw = a.io.in[(size_t)q * a.io.in_stride + (c.in_io - a.io.in_base)];
-    return __uint_as_float(narrow_stage<FMT>(load_stage<FMT>(raw, c.load_mode, c.gain_bits)));
+    const int B = a.io.nframes;
+    const unsigned *inp = a.io.in + (c.in_io - a.io.in_base);
+    for (int q = threadIdx.x; q < B; q += blockDim.x)
+        *ring_at(a.ring, cid, q) = __uint_as_float(narrow_stage<FMT>(load_stage<FMT>(inp[(size_t)q * a.io.in_stride], c.load_mode, c.gain_bits)));
+    __syncthreads();
 }
 
-/* Stage one channel: taps and the input window (history + this block) into LDS as flushed doubles,
- * AND advance the delay line in the same pass: st[i] <- x[B-1-i] (dsp_firSTD.h:45-50 applied B
- * times).  Old history words are read once, used for the LDS window, and written back B places
- * further up; the raw floats are written, so the state area stays bit-identical to the reference's.
- * In-place safety: history is processed in super-chunks from the top down, every thread finishes
- * its reads (vmcnt(0)) before the barrier that precedes the chunk's writes, and a chunk only writes
- * words at or above its own range.  All loads of a chunk are in flight together.                 */
-template <int FMT>
-__device__ __forceinline__ void fir_stage_lds(const FirArgs &a, const avdsp_chain &c, int cid,
-                                              double *hs, double *xs, int row, bool advance_state)
+/* One chunk = tap positions m in [mlo, mlo + 16*gpc) plus the prefetch overrun.  Its operands travel
+ * global -> registers (issued one chunk ahead, under the previous chunk's MFMAs) -> LDS as DOUBLES:
+ * converted, and flushed to +0 when the float is subnormal (dspMulFloatDouble, dsp_ieee754.h:383-386),
+ * once per chunk instead of once per MFMA.
+ *   taps    hs[u] = h[mlo + u]                                  (0 outside [0, T))
+ *   window  sample q sits at w = q + mlo + fir_win_off(gpc), stored TRANSPOSED in 16 rows,
+ *           pos(w) = (w & 15) * row + (w >> 4) with row = 16 (mod 32): the MFMA B operand
+ *           x[16(a0+j) - m - k] is 16 consecutive doubles over j, and the two k sharing a
+ *           ds_read_b64 pass use disjoint bank halves.  q >= B (the future) reads as 0.          */
+struct ChunkRegs { float h[kHRegs], x[kWRegs]; };
+
+/* Which window position thread `tid` handles in its u-th slot.  The image is a transpose (reads walk w
+ * in steps of 16), so the 16 lanes of an LDS write group take 16 positions of ONE row -- consecutive
+ * doubles, conflict free -- at the price of a 64-byte stride between their global loads (the four
+ * groups of a wave take adjacent rows, i.e. adjacent floats of the same cache lines).               */
+__device__ __forceinline__ int fir_win_slot(int u, int tid)
 {
-    const int T = c.fir_taps, B = a.io.nframes, nt = blockDim.x, tid = threadIdx.x;
+    const int idx = u * kBlock + tid, i = idx & 15, t = idx >> 4;
+    return 16 * (16 * (t >> 4) + i) + (t & 15);
+}
+
+__device__ __forceinline__ void fir_chunk_fetch(const FirArgs &a, const avdsp_chain &c, int cid, int mlo, ChunkRegs &r)
+{
+    const int T = c.fir_taps, B = a.io.nframes, tid = threadIdx.x;
     const float *taps = reinterpret_cast<const float *>(a.buf + c.fir_coef_word);
-    float *hist = reinterpret_cast<float *>(a.buf + c.fir_state_word);
-    constexpr int U = 16;
-    const int span = U * nt;
-
-    /* first super-chunk of taps and the top super-chunk of history: loads issued before anything else */
-    float tv[U], hv[U], xv[4];
-    const int htop = ((T - 1) / span) * span;            /* base of the highest history super-chunk */
+    const float *ringrow = a.ring.base + (size_t)cid * a.ring.R;
+    const int rmask = a.ring.R - 1, wlen = fir_win_len(a.gpc), woff = fir_win_off(a.gpc);
 #pragma unroll
-    for (int u = 0; u < U; u++) { const int t = u * nt + tid; tv[u] = t < T ? taps[t] : 0.0f; }
+    for (int u = 0; u < kHRegs; u++) { const int t = mlo + u * kBlock + tid; r.h[u] = (t >= 0 && t < T) ? taps[t] : 0.0f; }
 #pragma unroll
-    for (int u = 0; u < U; u++) { const int i = htop + u * nt + tid; hv[u] = i < T ? hist[i] : 0.0f; }
-
-    /* zero fill (pads, future samples, row tails) while those loads fly */
-    for (int u = tid; u < 16; u += nt) hs[u] = 0.0;
-    for (int u = T + 16 + tid; u < T + kTapPad; u += nt) hs[u] = 0.0;
-    for (int u = tid; u < 16 * row; u += nt) xs[u] = 0.0;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-#pragma unroll
-    for (int u = 0; u < U; u++) { const int t = u * nt + tid; if (t < T) hs[16 + t] = mulop(tv[u]); }
-    for (int t0 = span; t0 < T; t0 += span) {            /* more than 16 x blockDim taps */
-#pragma unroll
-        for (int u = 0; u < U; u++) { const int t = t0 + u * nt + tid; tv[u] = t < T ? taps[t] : 0.0f; }
-#pragma unroll
-        for (int u = 0; u < U; u++) { const int t = t0 + u * nt + tid; if (t < T) hs[16 + t] = mulop(tv[u]); }
+    for (int u = 0; u < kWRegs; u++) {
+        const int w = fir_win_slot(u, tid), q = w - mlo - woff;
+        r.x[u] = (w < wlen && q < B) ? ringrow[(a.ring.wpos + q) & rmask] : 0.0f;
     }
+}
 
-    for (int i0 = htop; i0 >= 0; i0 -= span) {
-        if (i0 != htop) {
+__device__ __forceinline__ void fir_chunk_to_lds(const FirArgs &a, const ChunkRegs &r, double *hs, double *xs, int row)
+{
+    const int tid = threadIdx.x, hlen = fir_hs_len(a.gpc), wlen = fir_win_len(a.gpc);
 #pragma unroll
-            for (int u = 0; u < U; u++) { const int i = i0 + u * nt + tid; hv[u] = i < T ? hist[i] : 0.0f; }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
+    for (int u = 0; u < kHRegs; u++) { const int i = u * kBlock + tid; if (i < hlen) hs[i] = mulop(r.h[u]); }
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int i = i0 + u * nt + tid;
-            if (i < T) {
-                xs[win_pos(T + kWinOff - 1 - i, row)] = mulop(hv[u]);
-                if (advance_state && i + B < T) hist[i + B] = hv[u];
-            }
-        }
-    }
-    /* this block's samples: into the window, and (newest first) into the bottom of the delay line */
-    for (int q0 = 0; q0 < B; q0 += 4 * nt) {
-#pragma unroll
-        for (int u = 0; u < 4; u++) { const int q = q0 + u * nt + tid; xv[u] = q < B ? fir_input<FMT>(a, c, cid, q) : 0.0f; }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int q = q0 + u * nt + tid;
-            if (q < B) {
-                xs[win_pos(T + kWinOff + q, row)] = mulop(xv[u]);
-                if (advance_state && B - 1 - q < T) hist[B - 1 - q] = xv[u];
-            }
-        }
-    }
+    for (int u = 0; u < kWRegs; u++) { const int w = fir_win_slot(u, tid); if (w < wlen) xs[win_pos(w, row)] = mulop(r.x[u]); }
 }
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
+/* FIR as a dense contraction on v_mfma_f64_16x16x4_f64.
+ *   Y[i][a] = y[16a + i] = sum_m A[i][m] * Bm[m][a],   A[i][m] = h[m + i],   Bm[m][a] = x[16a - m],
+ *   m = -15 .. T-1, four values of m per MFMA, ascending = the reference's tap order (dsp_firSTD.h:45-50);
+ *   products of two floats are exact in f64, so each accumulator is the reference's sequential sum.
+ * One workgroup (4 waves) per channel, one wave per column tile of 16 (256 frames).  The tap range is
+ * walked in LDS chunks while the accumulators stay in registers; the small chunk images let five
+ * workgroups share a CU, so one workgroup's staging hides under the others' MFMAs.               */
 template <int FMT>
-__global__ __launch_bounds__(kBlock) void fir_mfma(const FirArgs a)
+__global__ __launch_bounds__(kBlock, 4) void fir_mfma(const FirArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int slot = xcd_remap(blockIdx.x, a.per_xcd);
@@ -621,83 +613,112 @@ __global__ __launch_bounds__(kBlock) void fir_mfma(const FirArgs a)
     const int cid = a.group[slot];
     const avdsp_chain c = a.chains[cid];
     double *hs = lds, *xs = lds + a.hs_cap;
-    const int tiles = blockDim.x >> 6;                  /* one wave per 256-frame tile */
-    const int row = a.win_row;
-    if (!(a.debug & 2)) fir_stage_lds<FMT>(a, c, cid, hs, xs, row, !(a.debug & 1));
-    __syncthreads();
-
+    const int row = a.win_row, gpc = a.gpc;
     const int T = c.fir_taps, B = a.io.nframes;
+    if (c.nsec == 0) fir_append_input<FMT>(a, c, cid);
+
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ij = lane & 15, k = lane >> 4;
-    /* Y[i][col] = y[16*(a0+col) + i] = sum_m A[i][m] * Bm[m][col],  A[i][m] = h[m+i],
-     * Bm[m][col] = x[16*(a0+col) - m],  m = -15 .. T-1, four m per MFMA, ascending = tap order.
-     * Steps are taken in groups of four; within a group the window row (w & 15) of a lane steps
-     * by -4 and wraps once, so each lane keeps four fixed LDS addresses that move by one word per
-     * group: pos = K[s] - g.                                                                      */
-    const int a0 = wave * 16;
-    const int nsets = (((T + 15 + 15) >> 4) + 3) >> 2;   /* 16 values of m per group, 4 groups per operand set */
-    const double *hp = hs + (16 - 15 + k + ij);         /* h[m + k + i] at m = -15; +4 per step */
-    const int f = 16 * a0 + 15 - k + (T + kWinOff);     /* window position at step 0 for j = 0 */
-    const double *xp[4];
+    const bool busy = wave * kTileFrames < B;           /* waves beyond the block's last tile only help staging */
+    const double *hp = hs + k + ij;                     /* h[mlo + 16 g + 4 s + k + i] at [16 g + 4 s] */
+    const double *xp[4];                                /* x[16(a0+j) - (mlo + 16 g + 4 s + k)] at [-g] */
+    const int f0 = 16 * 16 * wave + fir_win_off(gpc) - k;
 #pragma unroll
-    for (int s = 0; s < 4; s++) xp[s] = xs + win_pos(f - 4 * s, row) + ij;
+    for (int s = 0; s < 4; s++) xp[s] = xs + win_pos(f0 - 4 * s, row) + ij;
     v4f64 acc = {0.0, 0.0, 0.0, 0.0};
-    /* Two operand sets of 16 MFMAs each: one feeds the matrix pipe while the other is being read.
-     * Per row the four groups of a set are four adjacent words, so the reads pair up (ds_read2_b64):
-     * about one LDS instruction per MFMA, which is what bounds this loop (tools/fir_loop_bench2.hip). */
-    double ha[16], xa[16], hb[16], xb[16];
-    auto load_set = [&](double *h, double *x, int g) {  /* groups g .. g+3 */
+
+    double ha[4 * kNG], xa[4 * kNG], hb[4 * kNG], xb[4 * kNG];
+    auto load_set = [&](double *h, double *x, int g) {
 #pragma unroll
-        for (int q = 0; q < 4; q++)
+        for (int q = 0; q < kNG; q++)
 #pragma unroll
             for (int s = 0; s < 4; s++) { h[4 * q + s] = hp[16 * (g + q) + 4 * s]; x[4 * q + s] = xp[s][-(g + q)]; }
     };
     auto mfma_set = [&](const double *h, const double *x) {
 #pragma unroll
-        for (int u = 0; u < 16; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(h[u], x[u], acc, 0, 0, 0);
+        for (int u = 0; u < 4 * kNG; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(h[u], x[u], acc, 0, 0, 0);
     };
-    load_set(ha, xa, 0);
-    int st = 0;
-    for (; st + 2 <= nsets; st += 2) {
-        load_set(hb, xb, 4 * (st + 1));
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_set(ha, xa);
-        __builtin_amdgcn_sched_barrier(0);
-        load_set(ha, xa, 4 * (st + 2));
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_set(hb, xb);
-        __builtin_amdgcn_sched_barrier(0);
+
+    const int total_groups = (T + 15 + 15) >> 4;        /* tap positions m = -15 .. T-1 in groups of 16 */
+    /* Workgroups that share a CU were dispatched together and do identical work: left alone they hit
+     * their chunk boundaries (barriers + LDS refill, no MFMA) in lockstep.  A first chunk of 1/4 .. 4/4
+     * of the normal size, chosen by dispatch round, keeps their refills apart.                     */
+    const int phase = (blockIdx.x >> 8) & 3;
+    int glen = max(kNG, (gpc * (phase + 1) / 4) / kNG * kNG);
+    ChunkRegs regs;
+    if (!(a.debug & (2 | 8))) fir_chunk_fetch(a, c, cid, -15, regs);
+    else for (int u = 0; u < kHRegs; u++) regs.h[u] = 1.0f;
+    if (a.debug & (2 | 8)) for (int u = 0; u < kWRegs; u++) regs.x[u] = 0.5f;
+    for (int g0 = 0; g0 < total_groups; g0 += glen, glen = gpc) {
+        __syncthreads();                                /* everyone is done reading the previous chunk */
+        if (!(a.debug & (2 | 16))) fir_chunk_to_lds(a, regs, hs, xs, row);
+        __syncthreads();
+        if (g0 + glen < total_groups && !(a.debug & (2 | 8))) fir_chunk_fetch(a, c, cid, -15 + 16 * (g0 + glen), regs);
+        if (busy) {
+            const int ng = min(glen, total_groups - g0);
+            const int nsets = (ng + kNG - 1) / kNG;
+            load_set(ha, xa, 0);
+            int st = 0;
+            for (; st + 2 <= nsets; st += 2) {
+                load_set(hb, xb, kNG * (st + 1));
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_set(ha, xa);
+                __builtin_amdgcn_sched_barrier(0);
+                load_set(ha, xa, kNG * (st + 2));
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_set(hb, xb);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (st < nsets) mfma_set(ha, xa);
+        }
     }
-    if (st < nsets) mfma_set(ha, xa);                    /* odd number of sets */
     /* C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg */
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        const int n = 16 * (a0 + ij) + k + 4 * r;
+        const int n = 16 * (16 * wave + ij) + k + 4 * r;
         if (n < B && !(a.debug & 4)) emit_out(a.io, c, n, store_stage<FMT>(acc[r], c.sat, a.io.store_mask));
     }
-    (void)tiles;
 }
 
+/* cross-check path: one thread per output frame, the reference's loop verbatim (ascending taps),
+ * operands straight from the ring and the program words (L1/L2)                                */
 template <int FMT>
 __global__ __launch_bounds__(kBlock) void fir_plain(const FirArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
     const int slot = xcd_remap(blockIdx.x, a.per_xcd);
     if (slot >= a.ngroup) return;
     const int cid = a.group[slot];
     const avdsp_chain c = a.chains[cid];
-    double *hs = lds, *xs = lds + a.hs_cap;
-    const int row = a.win_row;
-    fir_stage_lds<FMT>(a, c, cid, hs, xs, row, true);
-    __syncthreads();
     const int T = c.fir_taps, B = a.io.nframes;
+    if (c.nsec == 0) fir_append_input<FMT>(a, c, cid);
+    const float *taps = reinterpret_cast<const float *>(a.buf + c.fir_coef_word);
+    const float *ringrow = a.ring.base + (size_t)cid * a.ring.R;
+    const int rmask = a.ring.R - 1;
     for (int n = threadIdx.x; n < B; n += blockDim.x) {
-        double acc = 0.0;                               /* dsp_firSTD.h:43-50: taps in ascending order */
-        const int w0 = n + T + kWinOff;
+        double acc = 0.0;
         for (int t = 0; t < T; t++)
-            acc = __builtin_fma(xs[win_pos(w0 - t, row)], hs[16 + t], acc);
+            acc = __builtin_fma(mulop(ringrow[(a.ring.wpos + n - t) & rmask]), mulop(taps[t]), acc);
         emit_out(a.io, c, n, store_stage<FMT>(acc, c.sat, a.io.store_mask));
     }
+}
+
+/* ring <-> reference delay-line layout, one workgroup per FIR chain */
+struct RingConvArgs {
+    int *buf; const avdsp_chain *chains; const int *group; int ngroup; Ring ring;
+};
+__global__ __launch_bounds__(kBlock) void ring_to_state(const RingConvArgs a)
+{
+    const int cid = a.group[blockIdx.x];
+    const avdsp_chain c = a.chains[cid];
+    float *st = reinterpret_cast<float *>(a.buf + c.fir_state_word);
+    for (int i = threadIdx.x; i < c.fir_taps; i += blockDim.x) st[i] = *ring_at(a.ring, cid, -1 - i);
+}
+__global__ __launch_bounds__(kBlock) void state_to_ring(const RingConvArgs a)
+{
+    const int cid = a.group[blockIdx.x];
+    const avdsp_chain c = a.chains[cid];
+    const float *st = reinterpret_cast<const float *>(a.buf + c.fir_state_word);
+    for (int i = threadIdx.x; i < a.ring.R; i += blockDim.x) *ring_at(a.ring, cid, -1 - i) = i < c.fir_taps ? st[i] : 0.0f;
 }
 
 /* chains with neither biquads nor FIR: LOAD -> [SAT0DB] -> STORE */
@@ -732,7 +753,9 @@ struct Plan {
     std::vector<Group> bq;            /* biquad chains grouped by section count (P = lanes per chain) */
     int *d_fir_ids = nullptr;  int n_fir = 0, max_taps = 0;
     int *d_pass_ids = nullptr; int n_pass = 0;
-    bool need_xmid = false;
+    /* FIR history rings: [nchains][ring_R] floats, frame 0 of the next block goes to index wpos */
+    float *d_ring = nullptr; int ring_R = 0, wpos = 0;
+    int fir_gpc = 0;                  /* groups of 16 tap positions per LDS chunk */
     int io_in_min = 0, io_in_max = -1, io_out_min = 0, io_out_max = -1;
 };
 
@@ -742,7 +765,6 @@ struct avdsp_hip_prog {
     int total_words = 0;
     int *d_buf = nullptr;
     std::vector<Plan> plans;
-    float *d_xmid = nullptr; size_t xmid_chains = 0;
     unsigned *d_in = nullptr, *d_out = nullptr; size_t in_cap = 0, out_cap = 0;   /* host-call staging */
     /* optional per-kernel timing with HIP events on the launch stream (avdsp_hip_profile_*) */
     bool profile = false;
@@ -769,16 +791,25 @@ void free_plan(Plan &p)
 {
     (void)hipFree(p.d_chains); (void)hipFree(p.d_sec_coef); (void)hipFree(p.d_sec_state);
     for (auto &g : p.bq) (void)hipFree(g.d_ids);
-    (void)hipFree(p.d_fir_ids); (void)hipFree(p.d_pass_ids);
+    (void)hipFree(p.d_fir_ids); (void)hipFree(p.d_pass_ids); (void)hipFree(p.d_ring);
 }
 
-size_t fir_lds_bytes(int max_taps, int tiles, int *hs_cap, int *row)
+int fir_groups_per_chunk(int max_taps)
 {
-    const int hs = max_taps + kTapPad;
-    *hs_cap = (hs + 3) & ~3;
-    *row = win_row(max_taps, tiles * kTileFrames);
+    const int G = (max_taps + 15 + 15) >> 4;
+    const int nc = (G + kMaxGpc - 1) / kMaxGpc;
+    const int gpc = (G + nc - 1) / nc;
+    return std::min((gpc + kNG - 1) / kNG * kNG, kMaxGpc);
+}
+
+size_t fir_lds_bytes(int gpc, int *hs_cap, int *row)
+{
+    *hs_cap = (fir_hs_len(gpc) + 3) & ~3;
+    *row = fir_win_row(gpc);
     return (size_t)(*hs_cap + 16 * *row) * sizeof(double);
 }
+
+Ring plan_ring(const Plan &pl) { return Ring{pl.d_ring, pl.ring_R, pl.wpos}; }
 
 hipEvent_t take_event(avdsp_hip_prog *prog)
 {
@@ -805,50 +836,68 @@ struct ProfileScope {                   /* records an event pair around the laun
 };
 
 template <int FMT>
+int launch_biquad(avdsp_hip_prog *prog, Plan &pl, const Plan::Group &g, const int *ids, int n, BlockIO io,
+                  int biquad_impl, hipStream_t stream)
+{
+    ProfileScope scope(prog, stream, AVDSP_KERNEL_BIQUAD);
+    BiquadArgs a{};
+    a.buf = prog->d_buf; a.chains = pl.d_chains; a.sec_coef = pl.d_sec_coef; a.sec_state = pl.d_sec_state;
+    a.group = ids; a.ngroup = n; a.nsec = g.nsec; a.ring = plan_ring(pl); a.io = io;
+    if (biquad_impl == 0 || g.P > 64) {
+        hipLaunchKernelGGL(biquad_simple<FMT>, dim3((n + 63) / 64), dim3(64), 0, stream, a);
+    } else {
+        const int cpb = kBlock / g.P;
+        const int nblk = (n + cpb - 1) / cpb;
+        a.per_xcd = (nblk + 7) / 8;
+        const dim3 grid(a.per_xcd * 8), block(kBlock);
+        switch (g.P) {
+        case 1:  hipLaunchKernelGGL((biquad_pipe<FMT, 1>),  grid, block, 0, stream, a); break;
+        case 2:  hipLaunchKernelGGL((biquad_pipe<FMT, 2>),  grid, block, 0, stream, a); break;
+        case 4:  hipLaunchKernelGGL((biquad_pipe<FMT, 4>),  grid, block, 0, stream, a); break;
+        case 8:  hipLaunchKernelGGL((biquad_pipe<FMT, 8>),  grid, block, 0, stream, a); break;
+        case 16: hipLaunchKernelGGL((biquad_pipe<FMT, 16>), grid, block, 0, stream, a); break;
+        case 32: hipLaunchKernelGGL((biquad_pipe<FMT, 32>), grid, block, 0, stream, a); break;
+        default: hipLaunchKernelGGL((biquad_pipe<FMT, 64>), grid, block, 0, stream, a); break;
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <int FMT>
+int launch_fir(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, BlockIO io, int fir_impl, int debug, hipStream_t stream)
+{
+    if constexpr (FMT == 2) { (void)prog; (void)pl; (void)ids; (void)n; (void)io; (void)fir_impl; (void)debug; (void)stream; return 0; }
+    else {
+        ProfileScope scope(prog, stream, AVDSP_KERNEL_FIR);
+        FirArgs a{};
+        a.buf = prog->d_buf; a.chains = pl.d_chains; a.group = ids; a.ngroup = n;
+        a.ring = plan_ring(pl); a.io = io; a.debug = debug;
+        a.per_xcd = (n + 7) / 8;
+        const int nwaves = 4;                            /* always 4: idle tiles' waves still stage */
+        a.gpc = pl.fir_gpc;
+        size_t lds = 0;
+        if (fir_impl) lds = fir_lds_bytes(a.gpc, &a.hs_cap, &a.win_row);
+        auto kern = fir_impl ? fir_mfma<FMT> : fir_plain<FMT>;
+        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(a.per_xcd * 8), dim3(64 * nwaves), lds, stream, a);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+}
+
+/* The cascade and the FIR of a block run back to back on the caller's stream.  Running the cascades
+ * of one slice of channels underneath the FIR of another slice (separate streams) was tried and is
+ * 30 % SLOWER: the cascade's v_fma_f64 chain and v_mfma_f64 share the FP64 datapath, so a cascade step
+ * behind a saturated matrix pipe waits a whole MFMA per FMA (152 us per quarter instead of 19 us).  */
+template <int FMT>
 int launch_all(avdsp_hip_prog *prog, Plan &pl, BlockIO io, int fir_impl, int biquad_impl, hipStream_t stream)
 {
-    const int debug = fir_impl >> 8;                    /* timing experiments ride in the high bits */
+    const int debug = (fir_impl >> 8) & 0xFF;           /* timing experiments ride in the high bits */
     fir_impl &= 0xFF;
-    for (auto &g : pl.bq) {
-        ProfileScope scope(prog, stream, AVDSP_KERNEL_BIQUAD);
-        BiquadArgs a{};
-        a.buf = prog->d_buf; a.chains = pl.d_chains; a.sec_coef = pl.d_sec_coef; a.sec_state = pl.d_sec_state;
-        a.group = g.d_ids; a.ngroup = g.n; a.nsec = g.nsec; a.xmid = prog->d_xmid; a.xmid_stride = kFirChunk; a.io = io;
-        if (biquad_impl == 0 || g.P > 64) {
-            hipLaunchKernelGGL(biquad_simple<FMT>, dim3((g.n + 63) / 64), dim3(64), 0, stream, a);
-        } else {
-            const int cpb = kBlock / g.P;
-            const int nblk = (g.n + cpb - 1) / cpb;
-            a.per_xcd = (nblk + 7) / 8;
-            const dim3 grid(a.per_xcd * 8), block(kBlock);
-            switch (g.P) {
-            case 1:  hipLaunchKernelGGL((biquad_pipe<FMT, 1>),  grid, block, 0, stream, a); break;
-            case 2:  hipLaunchKernelGGL((biquad_pipe<FMT, 2>),  grid, block, 0, stream, a); break;
-            case 4:  hipLaunchKernelGGL((biquad_pipe<FMT, 4>),  grid, block, 0, stream, a); break;
-            case 8:  hipLaunchKernelGGL((biquad_pipe<FMT, 8>),  grid, block, 0, stream, a); break;
-            case 16: hipLaunchKernelGGL((biquad_pipe<FMT, 16>), grid, block, 0, stream, a); break;
-            case 32: hipLaunchKernelGGL((biquad_pipe<FMT, 32>), grid, block, 0, stream, a); break;
-            default: hipLaunchKernelGGL((biquad_pipe<FMT, 64>), grid, block, 0, stream, a); break;
-            }
-        }
-        HIP_TRY(hipGetLastError());
-    }
-    if constexpr (FMT != 2) {
-        if (pl.n_fir) {
-            ProfileScope scope(prog, stream, AVDSP_KERNEL_FIR);
-            FirArgs a{};
-            a.buf = prog->d_buf; a.chains = pl.d_chains; a.group = pl.d_fir_ids; a.ngroup = pl.n_fir;
-            a.xmid = prog->d_xmid; a.xmid_stride = kFirChunk; a.io = io; a.debug = debug;
-            a.per_xcd = (pl.n_fir + 7) / 8;
-            const int tiles = (io.nframes + kTileFrames - 1) / kTileFrames;
-            const size_t lds = fir_lds_bytes(pl.max_taps, tiles, &a.hs_cap, &a.win_row);
-            if (lds > 160 * 1024) return set_err("FIR of %d taps needs %zu bytes of LDS (limit 160 KiB)", pl.max_taps, lds);
-            auto kern = fir_impl ? fir_mfma<FMT> : fir_plain<FMT>;
-            HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(kern, dim3(a.per_xcd * 8), dim3(64 * tiles), lds, stream, a);
-            HIP_TRY(hipGetLastError());
-        }
-    }
+    for (auto &g : pl.bq)
+        if (launch_biquad<FMT>(prog, pl, g, g.d_ids, g.n, io, biquad_impl, stream)) return -1;
+    if (pl.n_fir && launch_fir<FMT>(prog, pl, pl.d_fir_ids, pl.n_fir, io, fir_impl, debug, stream)) return -1;
     if (pl.n_pass) {
         ProfileScope scope(prog, stream, AVDSP_KERNEL_PASS);
         PassArgs a{pl.d_chains, pl.d_pass_ids, pl.n_pass, io};
@@ -896,7 +945,7 @@ void avdsp_hip_prog_destroy(avdsp_hip_prog *p)
     for (auto &pl : p->plans) free_plan(pl);
     for (auto &sp : p->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (auto e : p->free_events) (void)hipEventDestroy(e);
-    (void)hipFree(p->d_buf); (void)hipFree(p->d_xmid); (void)hipFree(p->d_in); (void)hipFree(p->d_out);
+    (void)hipFree(p->d_buf); (void)hipFree(p->d_in); (void)hipFree(p->d_out);
     delete p;
 }
 
@@ -931,7 +980,6 @@ int avdsp_hip_prog_add_plan(avdsp_hip_prog *prog, const avdsp_plan_desc *d)
                 return set_err("chain %d: FIR addresses words outside the loaded buffer", i);
             fir.push_back(i);
             pl.max_taps = std::max(pl.max_taps, c.fir_taps);
-            if (c.nsec) pl.need_xmid = true;
         }
         if (c.nsec) {
             auto it = std::find_if(byN.begin(), byN.end(), [&](const auto &e) { return e.first == c.nsec; });
@@ -947,11 +995,16 @@ int avdsp_hip_prog_add_plan(avdsp_hip_prog *prog, const avdsp_plan_desc *d)
     }
     pl.n_fir = (int)fir.size(); pl.n_pass = (int)pass.size();
     if (upload_vec(&pl.d_fir_ids, fir) || upload_vec(&pl.d_pass_ids, pass)) { free_plan(pl); return -1; }
-    if (pl.need_xmid && prog->xmid_chains < (size_t)d->nchains) {
-        (void)hipFree(prog->d_xmid); prog->d_xmid = nullptr; prog->xmid_chains = 0;
-        hipError_t e = hipMalloc((void **)&prog->d_xmid, (size_t)d->nchains * kFirChunk * sizeof(float));
-        if (e != hipSuccess) { free_plan(pl); return set_err("hipMalloc(xmid): %s", hipGetErrorString(e)); }
-        prog->xmid_chains = (size_t)d->nchains;
+    if (pl.n_fir) {
+        pl.fir_gpc = fir_groups_per_chunk(pl.max_taps);
+        pl.ring_R = pow2ceil(pl.max_taps + kFirChunk + 16 * pl.fir_gpc + 16 * (kNG + 4) + 64);
+        static_assert(kFirChunk == kFirPad, "one FIR launch covers exactly the frames the window image is laid out for");
+        hipError_t e = hipMalloc((void **)&pl.d_ring, (size_t)d->nchains * pl.ring_R * sizeof(float));
+        if (e != hipSuccess) { free_plan(pl); return set_err("hipMalloc(FIR rings, %d x %d): %s", d->nchains, pl.ring_R, hipGetErrorString(e)); }
+        pl.wpos = 0;
+        RingConvArgs ca{prog->d_buf, pl.d_chains, pl.d_fir_ids, pl.n_fir, plan_ring(pl)};
+        hipLaunchKernelGGL(state_to_ring, dim3(pl.n_fir), dim3(kBlock), 0, nullptr, ca);   /* history the caller's buffer holds */
+        if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) { free_plan(pl); return set_err("state_to_ring failed"); }
     }
     prog->plans.push_back(pl);
     return (int)prog->plans.size() - 1;
@@ -963,16 +1016,43 @@ static int check_range(avdsp_hip_prog *p, int first, int n)
     return 0;
 }
 
+/* The FIR delay lines live in rings on the device; the mirror's state words are brought up to date
+ * before they are read back, and the rings are rebuilt after the mirror's state words were written. */
+static int rings_to_mirror(avdsp_hip_prog *p)
+{
+    for (auto &pl : p->plans)
+        if (pl.n_fir) {
+            RingConvArgs ca{p->d_buf, pl.d_chains, pl.d_fir_ids, pl.n_fir, plan_ring(pl)};
+            hipLaunchKernelGGL(ring_to_state, dim3(pl.n_fir), dim3(kBlock), 0, nullptr, ca);
+            HIP_TRY(hipGetLastError());
+        }
+    return 0;
+}
+
+static int mirror_to_rings(avdsp_hip_prog *p)
+{
+    for (auto &pl : p->plans)
+        if (pl.n_fir) {
+            RingConvArgs ca{p->d_buf, pl.d_chains, pl.d_fir_ids, pl.n_fir, plan_ring(pl)};
+            hipLaunchKernelGGL(state_to_ring, dim3(pl.n_fir), dim3(kBlock), 0, nullptr, ca);
+            HIP_TRY(hipGetLastError());
+        }
+    return 0;
+}
+
 int avdsp_hip_upload_words(avdsp_hip_prog *p, const int32_t *host_buf, int first, int n)
 {
     if (check_range(p, first, n)) return -1;
+    HIP_TRY(hipDeviceSynchronize());
     if (n) HIP_TRY(hipMemcpy(p->d_buf + first, host_buf + first, (size_t)n * 4, hipMemcpyHostToDevice));
-    return 0;
+    return mirror_to_rings(p);
 }
 
 int avdsp_hip_download_words(avdsp_hip_prog *p, int32_t *host_buf, int first, int n)
 {
     if (check_range(p, first, n)) return -1;
+    HIP_TRY(hipDeviceSynchronize());
+    if (rings_to_mirror(p)) return -1;
     HIP_TRY(hipDeviceSynchronize());
     if (n) HIP_TRY(hipMemcpy(host_buf + first, p->d_buf + first, (size_t)n * 4, hipMemcpyDeviceToHost));
     return 0;
@@ -981,8 +1061,9 @@ int avdsp_hip_download_words(avdsp_hip_prog *p, int32_t *host_buf, int first, in
 int avdsp_hip_zero_words(avdsp_hip_prog *p, int first, int n)
 {
     if (check_range(p, first, n)) return -1;
+    HIP_TRY(hipDeviceSynchronize());
     if (n) HIP_TRY(hipMemset(p->d_buf + first, 0, (size_t)n * 4));
-    return 0;
+    return mirror_to_rings(p);
 }
 
 int avdsp_hip_run_block(avdsp_hip_prog *prog, int plan, const void *d_in, int in_stride, int in_io_base,
@@ -1010,6 +1091,7 @@ int avdsp_hip_run_block(avdsp_hip_prog *prog, int plan, const void *d_in, int in
         default: rc = launch_all<6>(prog, pl, io, fir_impl, biquad_impl, (hipStream_t)stream); break;
         }
         if (rc) return rc;
+        if (pl.n_fir) pl.wpos = (pl.wpos + io.nframes) & (pl.ring_R - 1);
     }
     return 0;
 }

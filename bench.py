@@ -241,7 +241,8 @@ def main():
         value = total_samples / elapsed / 1e6
         if T and fir_n:
             per_launch = fir_ms / fir_n * 1e-3
-            flops = 2.0 * T * B * C                        # 2*T flop per sample, C*B samples per launch
+            # 2*T flop per sample; the C*B samples of a step are spread over fir_n/steps launches
+            flops = 2.0 * T * B * C * args.steps / fir_n
             ach = flops / per_launch / 1e12
             kname = "fir_mfma" if args.fir_impl else "fir_plain"
             roof = dict(bound="mfma", kernel=kname, achieved=ach,
