@@ -518,7 +518,6 @@ struct FirArgs {
     int             gpc;             /* groups of 16 tap positions per LDS chunk */
     int             hs_cap;          /* doubles reserved for the taps image */
     int             win_row;         /* doubles per row of the transposed window image */
-    int             debug;           /* timing experiments only: 2 skip staging, 4 skip stores, 8 skip global fetch, 16 skip LDS refill */
     BlockIO         io;
 };
 
@@ -646,14 +645,12 @@ __global__ __launch_bounds__(kBlock, 4) void fir_mfma(const FirArgs a)
     const int phase = (blockIdx.x >> 8) & 3;
     int glen = max(kNG, (gpc * (phase + 1) / 4) / kNG * kNG);
     ChunkRegs regs;
-    if (!(a.debug & (2 | 8))) fir_chunk_fetch(a, c, cid, -15, regs);
-    else for (int u = 0; u < kHRegs; u++) regs.h[u] = 1.0f;
-    if (a.debug & (2 | 8)) for (int u = 0; u < kWRegs; u++) regs.x[u] = 0.5f;
+    fir_chunk_fetch(a, c, cid, -15, regs);
     for (int g0 = 0; g0 < total_groups; g0 += glen, glen = gpc) {
         __syncthreads();                                /* everyone is done reading the previous chunk */
-        if (!(a.debug & (2 | 16))) fir_chunk_to_lds(a, regs, hs, xs, row);
+        fir_chunk_to_lds(a, regs, hs, xs, row);
         __syncthreads();
-        if (g0 + glen < total_groups && !(a.debug & (2 | 8))) fir_chunk_fetch(a, c, cid, -15 + 16 * (g0 + glen), regs);
+        if (g0 + glen < total_groups) fir_chunk_fetch(a, c, cid, -15 + 16 * (g0 + glen), regs);
         if (busy) {
             const int ng = min(glen, total_groups - g0);
             const int nsets = (ng + kNG - 1) / kNG;
@@ -676,7 +673,7 @@ __global__ __launch_bounds__(kBlock, 4) void fir_mfma(const FirArgs a)
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int n = 16 * (16 * wave + ij) + k + 4 * r;
-        if (n < B && !(a.debug & 4)) emit_out(a.io, c, n, store_stage<FMT>(acc[r], c.sat, a.io.store_mask));
+        if (n < B) emit_out(a.io, c, n, store_stage<FMT>(acc[r], c.sat, a.io.store_mask));
     }
 }
 
@@ -865,21 +862,20 @@ int launch_biquad(avdsp_hip_prog *prog, Plan &pl, const Plan::Group &g, const in
 }
 
 template <int FMT>
-int launch_fir(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, BlockIO io, int fir_impl, int debug, hipStream_t stream)
+int launch_fir(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, BlockIO io, int fir_impl, hipStream_t stream)
 {
-    if constexpr (FMT == 2) { (void)prog; (void)pl; (void)ids; (void)n; (void)io; (void)fir_impl; (void)debug; (void)stream; return 0; }
+    if constexpr (FMT == 2) { (void)prog; (void)pl; (void)ids; (void)n; (void)io; (void)fir_impl; (void)stream; return 0; }
     else {
         ProfileScope scope(prog, stream, AVDSP_KERNEL_FIR);
         FirArgs a{};
         a.buf = prog->d_buf; a.chains = pl.d_chains; a.group = ids; a.ngroup = n;
-        a.ring = plan_ring(pl); a.io = io; a.debug = debug;
+        a.ring = plan_ring(pl); a.io = io;
         a.per_xcd = (n + 7) / 8;
         const int nwaves = 4;                            /* always 4: idle tiles' waves still stage */
         a.gpc = pl.fir_gpc;
         size_t lds = 0;
         if (fir_impl) lds = fir_lds_bytes(a.gpc, &a.hs_cap, &a.win_row);
-        auto kern = fir_impl ? fir_mfma<FMT> : fir_plain<FMT>;
-        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        auto kern = fir_impl ? fir_mfma<FMT> : fir_plain<FMT>;      /* LDS opt-in was done at plan creation */
         hipLaunchKernelGGL(kern, dim3(a.per_xcd * 8), dim3(64 * nwaves), lds, stream, a);
         HIP_TRY(hipGetLastError());
         return 0;
@@ -893,11 +889,9 @@ int launch_fir(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, BlockIO io
 template <int FMT>
 int launch_all(avdsp_hip_prog *prog, Plan &pl, BlockIO io, int fir_impl, int biquad_impl, hipStream_t stream)
 {
-    const int debug = (fir_impl >> 8) & 0xFF;           /* timing experiments ride in the high bits */
-    fir_impl &= 0xFF;
     for (auto &g : pl.bq)
         if (launch_biquad<FMT>(prog, pl, g, g.d_ids, g.n, io, biquad_impl, stream)) return -1;
-    if (pl.n_fir && launch_fir<FMT>(prog, pl, pl.d_fir_ids, pl.n_fir, io, fir_impl, debug, stream)) return -1;
+    if (pl.n_fir && launch_fir<FMT>(prog, pl, pl.d_fir_ids, pl.n_fir, io, fir_impl, stream)) return -1;
     if (pl.n_pass) {
         ProfileScope scope(prog, stream, AVDSP_KERNEL_PASS);
         PassArgs a{pl.d_chains, pl.d_pass_ids, pl.n_pass, io};
@@ -997,6 +991,13 @@ int avdsp_hip_prog_add_plan(avdsp_hip_prog *prog, const avdsp_plan_desc *d)
     if (upload_vec(&pl.d_fir_ids, fir) || upload_vec(&pl.d_pass_ids, pass)) { free_plan(pl); return -1; }
     if (pl.n_fir) {
         pl.fir_gpc = fir_groups_per_chunk(pl.max_taps);
+        {   /* nothing in the launch path may touch function attributes (stream capture) */
+            int hs_cap, row;
+            const int lds = (int)fir_lds_bytes(pl.fir_gpc, &hs_cap, &row);
+            hipError_t e = d->format == 4 ? hipFuncSetAttribute((const void *)fir_mfma<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)
+                                          : hipFuncSetAttribute((const void *)fir_mfma<6>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e != hipSuccess) { free_plan(pl); return set_err("hipFuncSetAttribute(LDS %d): %s", lds, hipGetErrorString(e)); }
+        }
         pl.ring_R = pow2ceil(pl.max_taps + kFirChunk + 16 * pl.fir_gpc + 16 * (kNG + 4) + 64);
         static_assert(kFirChunk == kFirPad, "one FIR launch covers exactly the frames the window image is laid out for");
         hipError_t e = hipMalloc((void **)&pl.d_ring, (size_t)d->nchains * pl.ring_R * sizeof(float));

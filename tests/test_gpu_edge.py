@@ -1,0 +1,151 @@
+"""Edge cases of the HIP path against the oracle: long and odd tap counts (several LDS chunks), deep
+cascades (lanes-per-channel 32, 64 and the > 64 fallback), chains of different shape in one core,
+several cores, IO windows with offsets and spare slots, blocks longer than one launch, rate changes,
+reset, and the asynchronous device entry point on a side stream."""
+import numpy as np
+import pytest
+
+from avdsp_amd import progbuilder as pb
+from avdsp_amd import runtime as rt
+from oracle import pyoracle as po
+from tests.test_gpu_parity import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _release():
+    yield
+    rt.lib().dspRuntimeRelease()
+
+
+def both(fmt, prog, x, out_stride, in_base, out_base=0, blocks=None, opts=None, fs=48000, scratch=None):
+    o = po.OracleProgram(fmt, prog, fs=fs)
+    r = rt.Runtime(fmt, prog, fs=fs)
+    for k, v in (opts or {}).items():
+        r.set_option(k, v)
+    blocks = blocks or [len(x)]
+    pos = 0
+    for b in blocks:
+        want = o.run_block(x[pos:pos + b], out_stride, in_base, out_base, scratch_len=scratch)
+        got = r.run_block(x[pos:pos + b], out_stride, in_base, out_base)
+        assert_close(got, want, fmt, what=f"frames {pos}..{pos + b}")
+        pos += b
+    assert (r.sync_state() == o.state).all()
+    return r, o
+
+
+@pytest.mark.parametrize("taps,fir_impl", [(1249, 1), (1249, 0), (2500, 1), (5000, 1), (9001, 1), (20000, 1)])
+def test_long_fir_many_chunks(taps, fir_impl):
+    prog = pb.synth_program(6, 2, 1, taps)
+    blocks = [300, 1024, 3, 500]
+    x = pb.lcg_input(sum(blocks), 2, True, seed=taps)
+    both(6, prog, x, 2, 2, blocks=blocks, opts={"fir_impl": fir_impl})
+
+
+@pytest.mark.parametrize("fmt", [2, 6])
+@pytest.mark.parametrize("sections", [17, 31, 33, 64, 65, 100])
+def test_deep_cascades(fmt, sections):
+    prog = pb.synth_program(fmt, 3, sections)
+    x = pb.lcg_input(150, 3, fmt == 6, seed=sections)
+    both(fmt, prog, x, 3, 3, blocks=[70, 1, 79])
+
+
+def test_mixed_shapes_in_one_core():
+    """chain 0: 2 sections + 31 taps; chain 1: 5 sections; chain 2: FIR only, 100 taps; chain 3: plain copy;
+    chain 4: 5 sections + 300 taps.  IO: inputs 40..44, outputs 20, 3, 7, 0, 30 (windows do not overlap)."""
+    fmt = 6
+    pw = pb.ProgramWriter(fmt)
+    pw.core()
+    pw.param()
+    b0 = pw.biquad_bank(pb.synth_sections(0, 2, pb.F48000, pb.F48000))
+    i0 = pw.fir_impulses([pb.lcg_taps(0, 31)])
+    b1 = pw.biquad_bank(pb.synth_sections(1, 5, pb.F48000, pb.F48000))
+    pw.param()
+    i2 = pw.fir_impulses([pb.lcg_taps(2, 100)])
+    b4 = pw.biquad_bank(pb.synth_sections(4, 5, pb.F48000, pb.F48000))
+    i4 = pw.fir_impulses([pb.lcg_taps(4, 300)])
+    pw.load_gain_fixed(40, 0.9); pw.biquads(b0, 2); pw.fir(i0, 31); pw.sat0db(); pw.store(20)
+    pw.load_gain_fixed(41, 1.1); pw.biquads(b1, 5); pw.store(3)
+    pw.load(42); pw.fir(i2, 100); pw.sat0db(); pw.store(7)
+    pw.load(43); pw.store(0)
+    pw.load_gain_fixed(44, 0.7); pw.biquads(b4, 5); pw.fir(i4, 300); pw.store(30)
+    prog = pw.end_of_code()
+    x = pb.lcg_input(900, 5, True, seed=21)
+    r, _ = both(fmt, prog, x, 31, 40, 0, blocks=[400, 500], scratch=48)
+    assert r.core_info() == dict(chains=5, max_sections=5, max_taps=300)
+
+
+def test_two_cores_and_untouched_slots():
+    fmt = 2
+    pw = pb.ProgramWriter(fmt)
+    pw.core()
+    pw.param()
+    b0 = pw.biquad_bank(pb.synth_sections(0, 3, pb.F48000, pb.F48000))
+    pw.load_gain_fixed(8, 1.0); pw.biquads(b0, 3); pw.sat0db(); pw.store(0)
+    pw.core()
+    pw.param()
+    b1 = pw.biquad_bank(pb.synth_sections(1, 2, pb.F48000, pb.F48000))
+    pw.load_gain_fixed(9, 0.5); pw.biquads(b1, 2); pw.sat0db(); pw.store(2)
+    prog = pw.end_of_code()
+    x = pb.lcg_input(300, 4, False, seed=5)                 # IO 8..11 offered, 10 and 11 unused
+    o = po.OracleProgram(fmt, prog)
+    r = rt.Runtime(fmt, prog)
+    assert len(r.cores) == 2
+    out_o = np.full((300, 4), 77, dtype=np.int32)
+    out_d = out_o.copy()
+    o.run_block(x, 4, 8, 0, out=out_o)
+    r.run_block(x, 4, 8, 0, out=out_d)
+    assert (out_o == out_d).all()
+    assert (out_d[:, 1] == 77).all() and (out_d[:, 3] == 77).all()      # never stored: left as they were
+    assert (r.sync_state() == o.state).all()
+
+
+@pytest.mark.parametrize("fmt", [2, 6])
+def test_block_longer_than_one_launch(fmt):
+    prog = pb.synth_program(fmt, 4, 3, 0 if fmt == 2 else 70)
+    x = pb.lcg_input(2500, 4, fmt == 6, seed=9)
+    both(fmt, prog, x, 4, 4, blocks=[2500])
+
+
+@pytest.mark.parametrize("fmt", [2, 6])
+def test_rate_change_and_reset(fmt):
+    """Multi-rate program (44.1k..96k encoded): dspRuntimeReset picks another coefficient column and
+    zeroes the state; a second run after Reset equals a fresh run."""
+    prog = pb.synth_program(fmt, 3, 4, 0, pb.F44100, pb.F96000)
+    x = pb.lcg_input(200, 3, fmt == 6, seed=2)
+    r = rt.Runtime(fmt, prog, fs=44100)
+    o = po.OracleProgram(fmt, prog, fs=44100)
+    assert_close(r.run_block(x, 3, 3), o.run_block(x, 3, 3), fmt)
+    for fs in (96000, 48000):
+        assert r.reset(fs) == 0 and o.reset(fs) == 0
+        assert_close(r.run_block(x, 3, 3), o.run_block(x, 3, 3), fmt, what=f"fs {fs}")
+        assert (r.sync_state() == o.state).all()
+    assert r.reset(192000) == -2                           # outside the encoded range
+
+
+def test_device_entry_point_on_a_side_stream():
+    """dspRuntimeBlockDevice only enqueues kernels on the stream it is given (no sync, no allocation
+    after the plan exists): blocks issued on a non-default stream, inputs refilled in stream order."""
+    torch = pytest.importorskip("torch")
+    C, S, T, B = 16, 4, 200, 256
+    prog = pb.synth_program(6, C, S, T)
+    x = pb.lcg_input(3 * B, C, True, seed=14)
+    o = po.OracleProgram(6, prog)
+    want = o.run_block(x, C, C)
+    r = rt.Runtime(6, prog)
+    xd = torch.zeros((B, C), dtype=torch.float32, device="cuda")
+    yd = torch.zeros((B, C), dtype=torch.float32, device="cuda")
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        xd.copy_(torch.from_numpy(x[:B]))
+        r.run_block_device(xd.data_ptr(), C, C, yd.data_ptr(), C, 0, B, side.cuda_stream)     # plan creation outside capture
+    side.synchronize()
+    got = [yd.cpu().numpy().copy()]
+    for k in (1, 2):
+        with torch.cuda.stream(side):
+            xd.copy_(torch.from_numpy(x[k * B:(k + 1) * B]))
+            r.run_block_device(xd.data_ptr(), C, C, yd.data_ptr(), C, 0, B, side.cuda_stream)
+        side.synchronize()
+        got.append(yd.cpu().numpy().copy())
+    assert_close(np.concatenate(got), want, 6)

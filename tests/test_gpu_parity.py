@@ -44,9 +44,11 @@ def assert_close(got, want, fmt, exact=True, what="output"):
         peak = max(np.abs(want.astype(np.int64)).max(), 1)
         assert d <= REL_TOL * peak, f"{what}: max abs diff {d} vs peak {peak}"
     else:
-        d = np.abs(got.astype(np.float64) - want.astype(np.float64)).max()
+        diff = np.abs(got.astype(np.float64) - want.astype(np.float64))
+        d = diff.max()
         peak = max(np.abs(want.astype(np.float64)).max(), 1e-30)
-        assert d <= REL_TOL * peak, f"{what}: max abs diff {d} vs peak {peak}"
+        bad_cols = np.nonzero(diff.max(axis=0) > REL_TOL * peak)[0] if diff.ndim == 2 else []
+        assert d <= REL_TOL * peak, f"{what}: max abs diff {d} vs peak {peak}; columns {list(bad_cols)[:8]}, first frame {int(np.argmax(diff.max(axis=1) > REL_TOL * peak)) if diff.ndim == 2 else -1}"
     if exact:
         assert (g == w).all(), f"{what}: expected bit-exact, {np.count_nonzero(g != w)} words differ"
 
