@@ -6,8 +6,9 @@
  * dsp_runtime.c:150-195), sample-rate selection and state reset (dspRuntimeReset, :116-145), core
  * lookup (:42-77) and the *lowering* of a core's opcode stream into channel chains for the device.
  * It contains no signal arithmetic: every sample is computed by the gfx950 kernels.  A core that
- * is not a set of independent  LOAD|LOAD_GAIN -> BIQUADS* -> [FIR] -> [SAT0DB] -> STORE+  chains
- * is refused with an error (no CPU fallback).
+ * is a set of independent  LOAD|LOAD_GAIN -> BIQUADS* -> [FIR] -> [SAT0DB] -> STORE+  chains goes to
+ * the parallel kernels; any other core is bounds-checked here (scan_generic) and handed to the
+ * general device interpreter.  There is no CPU fallback.
  */
 #include "avdsp_runtime.h"
 #include "avdsp_hip.h"
@@ -56,7 +57,7 @@ typedef struct {
     opcode_t   *core;            /* key: the pointer the host passes (after dspFindCoreBegin) */
     int         format;
     int         plan_id;         /* id inside the device program, < 0 = lowering failed */
-    int         nchains, max_sections, max_taps;
+    int         nchains, max_sections, max_taps;      /* nchains 0 = general interpreter */
 } core_plan;
 
 #define MAX_CORE_PLANS 64
@@ -66,12 +67,12 @@ static struct {
     int             total_words;         /* totalLength + dataSize */
     int             have_rate;
     int             freq_index, num_freq, biquad_offset;
-    int             dither, store_mask;
+    int             dither, store_mask, random, fs_index;
     avdsp_hip_prog *dev;
     int             dev_state_valid;     /* device mirror holds the authoritative state */
     core_plan       plans[MAX_CORE_PLANS];
     int             nplans;
-    int             opt_fir_impl, opt_biquad_impl, opt_device, opt_profile;
+    int             opt_fir_impl, opt_biquad_impl, opt_device, opt_profile, opt_generic;
     int             device_selected;
 } G = { .opt_fir_impl = 1, .opt_biquad_impl = 1, .opt_device = -1 };
 
@@ -111,6 +112,7 @@ int dspRuntimeSetOption(const char *key, int value)
     if (!strcmp(key, "fir_impl"))    { G.opt_fir_impl = value; return 0; }
     if (!strcmp(key, "biquad_impl")) { G.opt_biquad_impl = value; return 0; }
     if (!strcmp(key, "device"))      { G.opt_device = value; G.device_selected = 0; return 0; }
+    if (!strcmp(key, "generic"))     { G.opt_generic = value; drop_device(); return 0; }
     if (!strcmp(key, "profile")) {
         G.opt_profile = value;
         if (G.dev) avdsp_hip_profile_enable(G.dev, value);
@@ -125,6 +127,7 @@ int dspRuntimeGetOption(const char *key)
     if (!strcmp(key, "biquad_impl")) return G.opt_biquad_impl;
     if (!strcmp(key, "device"))      return G.opt_device;
     if (!strcmp(key, "profile"))     return G.opt_profile;
+    if (!strcmp(key, "generic"))     return G.opt_generic;
     return -1;
 }
 
@@ -159,7 +162,6 @@ opcode_t *dspFindCoreBegin(opcode_t *p)
 /* ---- dsp_runtime.c:116-145 ---- */
 int dspRuntimeReset(const int fs, int random, int defaultDither)
 {
-    (void)random;                        /* seeds the TPDF generator; no TPDF opcode is lowered yet */
     if (!dspHeaderPtr) return fail(-1, "dspRuntimeReset before dspRuntimeInit");
     int idx = dspConvertFrequencyToIndex(fs);
     if (idx >= FMAXpos) return fail(-1, "sampling frequency %d not supported", fs);
@@ -170,6 +172,8 @@ int dspRuntimeReset(const int fs, int random, int defaultDither)
     dspBiquadFreqSkip = 2 + 6 * G.num_freq;
     G.biquad_offset = 5 + 6 * G.freq_index;
     G.have_rate = 1;
+    G.fs_index = idx;
+    G.random = random;                   /* seeds the device copy of the TPDF generator at first use */
     G.dither = defaultDither;
     /* dsp_tpdf.h:55-59: mask = -1 << (32 - dither) */
     G.store_mask = (int)(0xFFFFFFFFu << ((32 - defaultDither) & 31));
@@ -362,6 +366,182 @@ static int lower_core(int format, opcode_t *core, lowered *L)
     return check_independent(L);
 }
 
+
+/* ------------------------------------------------------------------------------------------
+ * general path: bounds-check every offset the interpreter will follow (dsp_runtime.c trusts the
+ * encoder; a device kernel must not), collect the IO span, refuse what has no defined result
+ * ---------------------------------------------------------------------------------------- */
+#define GENERIC_IO_LIMIT 65536
+
+typedef struct {
+    int format, aw, prog_words, data_words, at;
+    unsigned skip;
+    avdsp_generic_desc *d;
+} gscan;
+
+static int gs_payload(const gscan *s, int need)
+{
+    if ((unsigned)(1 + need) > s->skip) return fail(-8, "word %d: opcode payload shorter than %d words", s->at, need);
+    return 0;
+}
+static int gs_prog(const gscan *s, int off, int n)          /* words [at+off, at+off+n) of the program */
+{
+    long long lo = (long long)s->at + off;
+    if (n < 0 || lo < 0 || lo + n > s->prog_words) return fail(-8, "word %d: program offset %d (+%d) outside the program", s->at, off, n);
+    return 0;
+}
+static int gs_data(const gscan *s, int off, long long n)    /* words [off, off+n) of the data area */
+{
+    if (n < 0 || off < 0 || (long long)off + n > s->data_words) return fail(-8, "word %d: data offset %d (+%lld) outside the state area (%d words)", s->at, off, n, s->data_words);
+    return 0;
+}
+static int gs_io(const gscan *s, int io, int is_out)
+{
+    if (io < 0 || io >= GENERIC_IO_LIMIT) return fail(-8, "word %d: IO number %d outside [0,%d)", s->at, io, GENERIC_IO_LIMIT);
+    avdsp_generic_desc *d = s->d;
+    if (io + 1 > d->io_span) d->io_span = io + 1;
+    if (is_out) { if (io < d->io_out_min) d->io_out_min = io; if (io > d->io_out_max) d->io_out_max = io; }
+    else        { if (io < d->io_in_min)  d->io_in_min = io;  if (io > d->io_in_max)  d->io_in_max = io; }
+    return 0;
+}
+
+static int scan_generic(int format, opcode_t *core, avdsp_generic_desc *d)
+{
+    if (format < 2 || format > 6) return fail(-1, "DSP_FORMAT %d is not one of 2..6", format);
+    if ((format == DSP_FORMAT_INT64) != (dspHeaderPtr->format != 0))
+        return fail(-7, "program is %s-encoded but dspRuntime_%d was called: the reference's "
+                        "dspChangeFormat conversion is not provided", dspHeaderPtr->format ? "Q28" : "float", format);
+    const int alu_int = (format == DSP_FORMAT_INT64);
+    const int nf = G.num_freq, fi = G.freq_index;
+    gscan S;
+    S.format = format; S.aw = (format == 3 || format == 5) ? 1 : 2;
+    S.prog_words = dspHeaderPtr->totalLength; S.data_words = dspHeaderPtr->dataSize; S.d = d;
+    memset(d, 0, sizeof *d);
+    d->io_in_min = d->io_out_min = GENERIC_IO_LIMIT; d->io_in_max = d->io_out_max = -1;
+    opcode_t *p = dspFindCoreBegin(core);
+    d->format = format;
+    d->core_word = (int)(p - G.code);
+    d->prog_words = S.prog_words;
+    d->freq_index = fi; d->num_freq = nf;
+    d->biquad_freq_skip = dspBiquadFreqSkip; d->biquad_freq_offset = G.biquad_offset;
+    d->delay_line_factor = (unsigned)(4294.967296 * (double)dspConvertFrequencyFromIndex(G.fs_index));   /* dsp_runtime.c:81-90 */
+
+    for (;;) {
+        const int op = p->op.opcode;
+        const unsigned skip = p->op.skip;
+        const int *a = (const int *)p + 1;
+        const int at = (int)(p - G.code);
+        if (at < 0 || at >= S.prog_words) return fail(-8, "opcode stream runs past the program (word %d)", at);
+        if (skip == 0 || op == DSP_CORE || op == DSP_END_OF_CODE) break;
+        if ((long long)at + skip > S.prog_words) return fail(-8, "word %d: opcode longer than the program", at);
+        S.at = at; S.skip = skip;
+        int rc = 0;
+        switch (op) {
+        case DSP_NOP: case DSP_PARAM: case DSP_PARAM_NUM: case DSP_SERIAL:
+        case DSP_SWAPXY: case DSP_COPYXY: case DSP_COPYYX: case DSP_CLRXY:
+        case DSP_ADDXY: case DSP_ADDYX: case DSP_SUBXY: case DSP_SUBYX: case DSP_NEGX: case DSP_NEGY:
+        case DSP_MULXY: case DSP_DIVXY: case DSP_DIVYX: case DSP_AVGXY: case DSP_AVGYX:
+        case DSP_SQRTX: case DSP_SAT0DB: case DSP_SAT0DB_TPDF: case DSP_WHITE:
+            break;
+        case DSP_SHIFT: case DSP_MUL_VALUE: case DSP_DIV_VALUE: case DSP_MUL_VALUE_INT: case DSP_DIV_VALUE_INT:
+        case DSP_AND_VALUE_INT: case DSP_CLIP:
+            rc = gs_payload(&S, 1); break;
+        case DSP_LOAD:  rc = gs_payload(&S, 1) || gs_io(&S, a[0], 0); break;
+        case DSP_STORE: rc = gs_payload(&S, 1) || gs_io(&S, a[0], 1); break;
+        case DSP_LOAD_GAIN: rc = gs_payload(&S, 2) || gs_io(&S, a[0], 0) || gs_prog(&S, a[1], 1); break;
+        case DSP_LOAD_STORE:
+            for (unsigned k = 0; k + 2 <= skip - 1 && !rc; k += 2) rc = gs_io(&S, a[k], 0) || gs_io(&S, a[k + 1], 1);
+            break;
+        case DSP_GAIN: case DSP_SAT0DB_GAIN: case DSP_SAT0DB_TPDF_GAIN: case DSP_VALUE: case DSP_VALUE_INT:
+            rc = gs_payload(&S, 1) || gs_prog(&S, a[0], 1); break;
+        case DSP_LOAD_MEM: case DSP_STORE_MEM:
+            rc = gs_payload(&S, 1) || gs_prog(&S, a[0], S.aw); break;
+        case DSP_TPDF_CALC: case DSP_TPDF:
+            rc = gs_payload(&S, 2) || gs_data(&S, a[1], S.aw); break;
+        case DSP_DELAY_1: case DSP_LOAD_MEM_DATA:
+            rc = gs_payload(&S, 1) || gs_data(&S, a[0], S.aw); break;
+        case DSP_DELAY: case DSP_DELAY_DP:
+            rc = gs_payload(&S, 3);
+            if (!rc && a[0] < 0) rc = fail(-8, "word %d: negative delay size", at);
+            if (!rc) {
+                /* :769-790: with a parameter the first word is the line's size in samples; without
+                 * (fixed delay) it is microseconds and the length follows from the sample rate */
+                long long n = a[2] ? (long long)a[0] : (long long)(((unsigned long long)(unsigned)a[0] * d->delay_line_factor) >> 32);
+                rc = gs_data(&S, a[1], 1 + n * (op == DSP_DELAY ? 1 : S.aw));
+            }
+            if (!rc && a[2]) rc = gs_prog(&S, a[2], 1);
+            break;
+        case DSP_BIQUADS: {
+            rc = gs_payload(&S, 2) || gs_prog(&S, a[1], 2);
+            if (rc) break;
+            const opcode_t *bank = p + a[1];
+            const int num = (short)bank[0].i32;
+            if (num < 1) { rc = fail(-8, "word %d: biquad bank with %d sections", at, num); break; }
+            rc = gs_prog(&S, a[1], G.biquad_offset + (num - 1) * dspBiquadFreqSkip + 5) || gs_data(&S, a[0], 6ll * num);
+            break; }
+        case DSP_LOAD_MUX: {
+            rc = gs_payload(&S, 2) || gs_prog(&S, a[0], 1) || gs_data(&S, a[1], S.aw);
+            if (rc) break;
+            const opcode_t *t = p + a[0];
+            const int n = (short)t[0].i32;
+            if (n > 0) rc = gs_prog(&S, a[0], 1 + 2 * n);
+            for (int k = 0; k < n && !rc; k++) rc = gs_io(&S, t[1 + 2 * k].i32, 0);
+            break; }
+        case DSP_DATA_TABLE:
+            rc = gs_payload(&S, 5);
+            if (!rc && (a[2] < 1 || a[1] < 0 || a[1] > a[2])) rc = fail(-8, "word %d: data table size %d / step %d", at, a[2], a[1]);
+            if (!rc) rc = gs_data(&S, a[3], 1) || gs_prog(&S, a[4], a[2]);
+            break;
+        case DSP_FIR: {
+            rc = gs_payload(&S, nf + 1);
+            if (rc) break;
+            const int off = a[fi];
+            if (!off) break;
+            rc = gs_prog(&S, off, 1);
+            if (rc) break;
+            const int length = p[off].i32, delay = length >> 16;
+            if (delay) rc = gs_data(&S, a[nf], 1 + (long long)delay);
+            else if (length > 0) {
+                if (alu_int)
+                    rc = fail(-8, "word %d: DSP_FIR in int64 mode is undefined behaviour in the reference "
+                                  "(dsp_firSTD.h:8-35) and is not provided", at);
+                else rc = gs_prog(&S, off, 1 + length) || gs_data(&S, a[nf], length);
+            }
+            break; }
+        case DSP_RMS:
+            rc = gs_payload(&S, 2 + 2 * nf);
+            if (!rc && a[1] < 0) rc = fail(-8, "word %d: negative RMS delay", at);
+            if (!rc) rc = gs_data(&S, a[0], 5 + 2ll * S.aw + (long long)a[1] * S.aw);
+            break;
+        case DSP_DCBLOCK:
+            rc = gs_payload(&S, 1 + nf) || gs_data(&S, a[0], S.aw + 2); break;
+        case DSP_DITHER:
+            rc = gs_payload(&S, 1) || gs_data(&S, a[0], 3ll * S.aw); break;
+        case DSP_DITHER_NS2:
+            rc = gs_payload(&S, 2) || gs_data(&S, a[0], 3) || gs_prog(&S, a[1] + fi * 3, 3); break;
+        case DSP_DISTRIB:
+            rc = gs_payload(&S, 3);
+            if (!rc && a[1] < 2) rc = fail(-8, "word %d: DISTRIB with %d bins", at, a[1]);
+            if (!rc) rc = gs_io(&S, a[0], 1) || gs_data(&S, a[2], 1 + (long long)a[1]);
+            break;
+        case DSP_DIRAC: case DSP_SQUAREWAVE: case DSP_SINE:
+            if (alu_int) {
+                rc = fail(-8, "word %d: %s in int64 mode calls dspQNMmax()/DSP_Q31(), which the reference never "
+                              "defines (dsp_runtime.c:1213-1305): no result to match", at, dspOpcodeText[op]);
+                break;
+            }
+            rc = gs_payload(&S, 2 + nf) || gs_data(&S, a[0], op == DSP_SINE ? 2 * S.aw : 1);
+            break;
+        default:
+            rc = fail(-8, "word %d: unknown opcode %d", at, op);
+        }
+        if (rc) return g_err_code;
+        p += skip;
+    }
+    if (d->io_span == 0) d->io_span = 1;
+    return 0;
+}
+
 static int select_device(void)
 {
     if (G.device_selected) return 0;
@@ -382,7 +562,7 @@ static core_plan *get_plan(int format, opcode_t *core)
 {
     if (!dspHeaderPtr || !G.code) { fail(-1, "no program loaded"); return 0; }
     if (!G.have_rate) { fail(-1, "dspRuntimeReset(fs) has not selected a sample rate yet"); return 0; }
-    if (format != 2 && format != 4 && format != 6) { fail(-1, "DSP_FORMAT %d has no device path (2, 4, 6 do)", format); return 0; }
+    if (format < 2 || format > 6) { fail(-1, "DSP_FORMAT %d is not one of 2..6", format); return 0; }
     for (int i = 0; i < G.nplans; i++)
         if (G.plans[i].core == core && G.plans[i].format == format) {
             if (G.plans[i].plan_id < 0) { fail(-8, "core was refused earlier"); return 0; }
@@ -391,35 +571,50 @@ static core_plan *get_plan(int format, opcode_t *core)
     if (G.nplans == MAX_CORE_PLANS) { fail(-9, "too many cores"); return 0; }
     if (core < G.code || core >= G.code + dspHeaderPtr->totalLength) { fail(-1, "core pointer outside the loaded program"); return 0; }
 
+    /* chains first (formats with parallel kernels); anything else the chain lowering calls "not
+     * lowerable" (-8) is offered to the general interpreter; other failures are final */
     lowered L;
-    if (lower_core(format, core, &L)) { lowered_free(&L); return 0; }
+    avdsp_generic_desc gd;
+    int chains = 0;
+    memset(&L, 0, sizeof L);
+    if ((format == 2 || format == 4 || format == 6) && !G.opt_generic) {
+        int rc = lower_core(format, core, &L);
+        if (rc == 0) chains = 1;
+        else { lowered_free(&L); if (rc != -8) return 0; }
+    }
+    if (!chains && scan_generic(format, core, &gd)) return 0;
 
     if (select_device()) { lowered_free(&L); return 0; }
     if (!G.dev) {
         G.dev = avdsp_hip_prog_create(G.total_words);
         if (!G.dev) { fail(-10, "%s", avdsp_hip_last_error()); lowered_free(&L); return 0; }
-        if (avdsp_hip_upload_words(G.dev, (const int32_t *)G.code, 0, G.total_words)) {
+        if (avdsp_hip_upload_words(G.dev, (const int32_t *)G.code, 0, G.total_words) ||
+            avdsp_hip_tpdf_reset(G.dev, G.random, G.dither)) {
             fail(-10, "%s", avdsp_hip_last_error()); lowered_free(&L); drop_device(); return 0;
         }
         G.dev_state_valid = 1;
         avdsp_hip_profile_enable(G.dev, G.opt_profile);
     }
-    avdsp_plan_desc d;
-    memset(&d, 0, sizeof d);
-    d.format = format;
-    d.nchains = L.nchains; d.chains = L.chains;
-    d.nsections = L.nsec; d.sec_coef_word = L.coef_word; d.sec_state_word = L.state_word;
-    d.store_mask = G.store_mask;
-    int id = avdsp_hip_prog_add_plan(G.dev, &d);
     core_plan *cp = &G.plans[G.nplans];
-    cp->core = core; cp->format = format; cp->plan_id = id;
-    cp->nchains = L.nchains; cp->max_sections = 0; cp->max_taps = 0;
-    for (int i = 0; i < L.nchains; i++) {
-        if (L.chains[i].nsec > cp->max_sections) cp->max_sections = L.chains[i].nsec;
-        if (L.chains[i].fir_taps > cp->max_taps) cp->max_taps = L.chains[i].fir_taps;
-    }
-    lowered_free(&L);
-    if (id < 0) { fail(-10, "%s", avdsp_hip_last_error()); return 0; }
+    cp->core = core; cp->format = format;
+    cp->nchains = 0; cp->max_sections = 0; cp->max_taps = 0;
+    if (chains) {
+        avdsp_plan_desc d;
+        memset(&d, 0, sizeof d);
+        d.format = format;
+        d.nchains = L.nchains; d.chains = L.chains;
+        d.nsections = L.nsec; d.sec_coef_word = L.coef_word; d.sec_state_word = L.state_word;
+        d.store_mask = G.store_mask;
+        cp->plan_id = avdsp_hip_prog_add_plan(G.dev, &d);
+        cp->nchains = L.nchains;
+        for (int i = 0; i < L.nchains; i++) {
+            if (L.chains[i].nsec > cp->max_sections) cp->max_sections = L.chains[i].nsec;
+            if (L.chains[i].fir_taps > cp->max_taps) cp->max_taps = L.chains[i].fir_taps;
+        }
+        lowered_free(&L);
+    } else
+        cp->plan_id = avdsp_hip_prog_add_generic(G.dev, &gd);
+    if (cp->plan_id < 0) { fail(-10, "%s", avdsp_hip_last_error()); return 0; }
     G.nplans++;
     return cp;
 }
@@ -438,22 +633,30 @@ int dspRuntimeCoreInfo(int format, opcode_t *core, int *nchains, int *max_sectio
 {
     if (!dspHeaderPtr || !G.code) return fail(-1, "no program loaded");
     if (!G.have_rate) return fail(-1, "dspRuntimeReset(fs) has not selected a sample rate yet");
-    if (format != 2 && format != 4 && format != 6) return fail(-1, "DSP_FORMAT %d has no device path (2, 4, 6 do)", format);
+    if (format < 2 || format > 6) return fail(-1, "DSP_FORMAT %d is not one of 2..6", format);
     if (core < G.code || core >= G.code + dspHeaderPtr->totalLength) return fail(-1, "core pointer outside the loaded program");
-    lowered L;
-    int rc = lower_core(format, core, &L);
-    if (rc == 0) {
-        int ms = 0, mt = 0;
-        for (int i = 0; i < L.nchains; i++) {
-            if (L.chains[i].nsec > ms) ms = L.chains[i].nsec;
-            if (L.chains[i].fir_taps > mt) mt = L.chains[i].fir_taps;
+    int nc = 0, ms = 0, mt = 0, rc = -8;
+    if ((format == 2 || format == 4 || format == 6) && !G.opt_generic) {
+        lowered L;
+        rc = lower_core(format, core, &L);
+        if (rc == 0) {
+            nc = L.nchains;
+            for (int i = 0; i < L.nchains; i++) {
+                if (L.chains[i].nsec > ms) ms = L.chains[i].nsec;
+                if (L.chains[i].fir_taps > mt) mt = L.chains[i].fir_taps;
+            }
         }
-        if (nchains) *nchains = L.nchains;
-        if (max_sections) *max_sections = ms;
-        if (max_taps) *max_taps = mt;
+        lowered_free(&L);
     }
-    lowered_free(&L);
-    return rc;
+    if (rc == -8) {
+        avdsp_generic_desc gd;
+        rc = scan_generic(format, core, &gd);
+    }
+    if (rc) return rc;
+    if (nchains) *nchains = nc;
+    if (max_sections) *max_sections = ms;
+    if (max_taps) *max_taps = mt;
+    return 0;
 }
 
 static int check_rundata(const int *rundata)
@@ -494,6 +697,14 @@ int dspRuntimeBlock_2(opcode_t *core, int *rundata, const int *in, int in_stride
                       int *out, int out_stride, int out_io_base, int nframes)
 { return block_host(2, core, rundata, in, in_stride, in_io_base, out, out_stride, out_io_base, nframes); }
 
+int dspRuntimeBlock_3(opcode_t *core, int *rundata, const int *in, int in_stride, int in_io_base,
+                      int *out, int out_stride, int out_io_base, int nframes)
+{ return block_host(3, core, rundata, in, in_stride, in_io_base, out, out_stride, out_io_base, nframes); }
+
+int dspRuntimeBlock_5(opcode_t *core, int *rundata, const float *in, int in_stride, int in_io_base,
+                      float *out, int out_stride, int out_io_base, int nframes)
+{ return block_host(5, core, rundata, in, in_stride, in_io_base, out, out_stride, out_io_base, nframes); }
+
 int dspRuntimeBlock_4(opcode_t *core, int *rundata, const int *in, int in_stride, int in_io_base,
                       int *out, int out_stride, int out_io_base, int nframes)
 { return block_host(4, core, rundata, in, in_stride, in_io_base, out, out_stride, out_io_base, nframes); }
@@ -513,7 +724,9 @@ static int one_frame(int format, opcode_t *core, int *rundata, void *samples)
 }
 
 int dspRuntime_2(opcode_t *core, int *rundata, int *samples)   { return one_frame(2, core, rundata, samples); }
+int dspRuntime_3(opcode_t *core, int *rundata, int *samples)   { return one_frame(3, core, rundata, samples); }
 int dspRuntime_4(opcode_t *core, int *rundata, int *samples)   { return one_frame(4, core, rundata, samples); }
+int dspRuntime_5(opcode_t *core, int *rundata, float *samples) { return one_frame(5, core, rundata, samples); }
 int dspRuntime_6(opcode_t *core, int *rundata, float *samples) { return one_frame(6, core, rundata, samples); }
 
 int dspRuntimeSyncState(int *rundata)
@@ -521,7 +734,9 @@ int dspRuntimeSyncState(int *rundata)
     if (!dspHeaderPtr) return fail(-1, "no program loaded");
     if (check_rundata(rundata)) return -1;
     if (!G.dev || !G.dev_state_valid) return 0;              /* nothing ran yet: host copy is current */
-    if (avdsp_hip_download_words(G.dev, (int32_t *)G.code, dspHeaderPtr->totalLength, dspHeaderPtr->dataSize))
+    /* the header stays the host's: only words behind it can have been written (DSP_STORE_MEM) */
+    const int first = (int)(sizeof(dspHeader_t) / sizeof(int));
+    if (avdsp_hip_download_words(G.dev, (int32_t *)G.code, first, G.total_words - first))
         return fail(-10, "%s", avdsp_hip_last_error());
     return 0;
 }

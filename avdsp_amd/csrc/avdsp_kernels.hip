@@ -40,6 +40,7 @@
 #include <algorithm>
 
 #include "avdsp_hip.h"
+#include "avdsp_format.h"
 
 namespace {
 
@@ -738,10 +739,16 @@ __global__ __launch_bounds__(kBlock) void passthrough(const PassArgs a)
     }
 }
 
+#include "avdsp_interp.inc"
+
 /* ------------------------------------------------------------------------------------------
  * host side of the thin ABI
  * ---------------------------------------------------------------------------------------- */
 struct Plan {
+    bool generic = false;             /* general interpreter instead of chain kernels */
+    GenericArgs ga{};                 /* launch template of the generic path (io filled per block) */
+    int io_span = 0;                  /* highest IO number the core touches + 1 */
+    size_t ga_lds = 0;
     int format = 0, nchains = 0, store_mask = -1;
     avdsp_chain *d_chains = nullptr;
     int *d_sec_coef = nullptr, *d_sec_state = nullptr;
@@ -761,6 +768,8 @@ struct Plan {
 struct avdsp_hip_prog {
     int total_words = 0;
     int *d_buf = nullptr;
+    TpdfGlobals *d_tpdf = nullptr;
+    unsigned *d_frame = nullptr; int frame_words = 0;     /* samples[] frame of the general interpreter */
     std::vector<Plan> plans;
     unsigned *d_in = nullptr, *d_out = nullptr; size_t in_cap = 0, out_cap = 0;   /* host-call staging */
     /* optional per-kernel timing with HIP events on the launch stream (avdsp_hip_profile_*) */
@@ -939,7 +948,7 @@ void avdsp_hip_prog_destroy(avdsp_hip_prog *p)
     for (auto &pl : p->plans) free_plan(pl);
     for (auto &sp : p->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (auto e : p->free_events) (void)hipEventDestroy(e);
-    (void)hipFree(p->d_buf); (void)hipFree(p->d_in); (void)hipFree(p->d_out);
+    (void)hipFree(p->d_buf); (void)hipFree(p->d_in); (void)hipFree(p->d_out); (void)hipFree(p->d_tpdf); (void)hipFree(p->d_frame);
     delete p;
 }
 
@@ -1011,6 +1020,82 @@ int avdsp_hip_prog_add_plan(avdsp_hip_prog *prog, const avdsp_plan_desc *d)
     return (int)prog->plans.size() - 1;
 }
 
+/* LDS budget of the generic path: frame (when small) + staged mirror, one workgroup per CU at most */
+static const int kGenericFrameLds = 4096;            /* words */
+static const size_t kGenericLdsMax = 144 * 1024;     /* bytes */
+
+int avdsp_hip_prog_add_generic(avdsp_hip_prog *prog, const avdsp_generic_desc *d)
+{
+    if (d->format < 2 || d->format > 6) return set_err("format %d is not one of 2..6", d->format);
+    if (d->core_word < 0 || d->core_word >= d->prog_words || d->prog_words > prog->total_words || d->io_span < 1)
+        return set_err("generic plan: core word %d / program %d words / IO span %d do not fit the mirror (%d words)",
+                       d->core_word, d->prog_words, d->io_span, prog->total_words);
+    if (!prog->d_tpdf) return set_err("generic plan before avdsp_hip_tpdf_reset");
+    Plan pl;
+    pl.generic = true; pl.format = d->format; pl.io_span = d->io_span;
+    pl.io_in_min = d->io_in_min; pl.io_in_max = d->io_in_max; pl.io_out_min = d->io_out_min; pl.io_out_max = d->io_out_max;
+    GenericArgs &a = pl.ga;
+    a.buf = prog->d_buf; a.tpdf = prog->d_tpdf;
+    a.core_word = d->core_word; a.prog_words = d->prog_words;
+    a.freq_index = d->freq_index; a.num_freq = d->num_freq;
+    a.biquad_skip = d->biquad_freq_skip; a.biquad_offset = d->biquad_freq_offset;
+    a.delay_factor = d->delay_line_factor;
+    /* one samples[] frame per program, shared by its cores; small frames are worked on in LDS */
+    const int want = std::max(d->io_span, kGenericFrameLds);
+    if (prog->frame_words < want) {
+        for (auto &o : prog->plans) if (o.generic) return set_err("generic plan: IO span %d after a core with a smaller frame", d->io_span);
+        (void)hipFree(prog->d_frame); prog->d_frame = nullptr; prog->frame_words = 0;
+        HIP_TRY(hipMalloc((void **)&prog->d_frame, (size_t)want * 4));
+        HIP_TRY(hipMemset(prog->d_frame, 0, (size_t)want * 4));
+        prog->frame_words = want;
+    }
+    a.scratch = prog->d_frame;
+    a.scratch_len = prog->frame_words;
+    a.frame_in_lds = prog->frame_words <= kGenericFrameLds;
+    a.frame_lds = a.frame_in_lds ? prog->frame_words : 0;
+    const size_t staged = ((size_t)a.frame_lds + prog->total_words) * 4;
+    if (staged <= kGenericLdsMax) { a.stage_words = prog->total_words; a.keep_words = (int)(sizeof(dspHeader_t) / 4); }
+    pl.ga_lds = a.stage_words ? staged : (size_t)a.frame_lds * 4;
+    const void *fn = nullptr;
+    switch (d->format) {
+    case 2: fn = (const void *)interp_core<2>; break;
+    case 3: fn = (const void *)interp_core<3>; break;
+    case 4: fn = (const void *)interp_core<4>; break;
+    case 5: fn = (const void *)interp_core<5>; break;
+    default: fn = (const void *)interp_core<6>; break;
+    }
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGenericLdsMax);
+    if (e != hipSuccess) { free_plan(pl); return set_err("hipFuncSetAttribute(generic LDS): %s", hipGetErrorString(e)); }
+    prog->plans.push_back(pl);
+    return (int)prog->plans.size() - 1;
+}
+
+int avdsp_hip_tpdf_reset(avdsp_hip_prog *prog, int seed, int default_dither)
+{
+    if (!prog->d_tpdf) HIP_TRY(hipMalloc((void **)&prog->d_tpdf, sizeof(TpdfGlobals)));
+    hipLaunchKernelGGL(tpdf_init_kernel, dim3(1), dim3(1), 0, nullptr, prog->d_tpdf, seed, default_dither);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    return 0;
+}
+
+static int launch_generic(avdsp_hip_prog *prog, Plan &pl, BlockIO io, hipStream_t stream)
+{
+    ProfileScope scope(prog, stream, AVDSP_KERNEL_GENERIC);
+    GenericArgs a = pl.ga;
+    a.io = io;
+    const dim3 grid(1), block(64);
+    switch (pl.format) {
+    case 2:  hipLaunchKernelGGL(interp_core<2>, grid, block, pl.ga_lds, stream, a); break;
+    case 3:  hipLaunchKernelGGL(interp_core<3>, grid, block, pl.ga_lds, stream, a); break;
+    case 4:  hipLaunchKernelGGL(interp_core<4>, grid, block, pl.ga_lds, stream, a); break;
+    case 5:  hipLaunchKernelGGL(interp_core<5>, grid, block, pl.ga_lds, stream, a); break;
+    default: hipLaunchKernelGGL(interp_core<6>, grid, block, pl.ga_lds, stream, a); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 static int check_range(avdsp_hip_prog *p, int first, int n)
 {
     if (first < 0 || n < 0 || first + n > p->total_words) return set_err("word range [%d,%d) outside the mirror (%d words)", first, first + n, p->total_words);
@@ -1075,10 +1160,22 @@ int avdsp_hip_run_block(avdsp_hip_prog *prog, int plan, const void *d_in, int in
     Plan &pl = prog->plans[plan];
     if (nframes <= 0) return 0;
     /* the kernels index the sample blocks with the chains' IO numbers: check the windows once here */
-    if (pl.io_in_min < in_io_base || pl.io_in_max >= in_io_base + in_stride)
+    if (pl.io_in_max >= pl.io_in_min && (pl.io_in_min < in_io_base || pl.io_in_max >= in_io_base + in_stride))
         return set_err("input window IO [%d,%d) does not cover the IOs the core loads [%d,%d]", in_io_base, in_io_base + in_stride, pl.io_in_min, pl.io_in_max);
-    if (pl.io_out_min < out_io_base || pl.io_out_max >= out_io_base + out_stride)
+    if (pl.io_out_max >= pl.io_out_min && (pl.io_out_min < out_io_base || pl.io_out_max >= out_io_base + out_stride))
         return set_err("output window IO [%d,%d) does not cover the IOs the core stores [%d,%d]", out_io_base, out_io_base + out_stride, pl.io_out_min, pl.io_out_max);
+    if (pl.generic) {
+        /* the scratch frame is indexed by IO number: both windows must lie inside it */
+        if (in_stride < 0 || out_stride < 0 || in_io_base < 0 || out_io_base < 0 ||
+            (in_stride && in_io_base + in_stride > pl.ga.scratch_len) || (out_stride && out_io_base + out_stride > pl.ga.scratch_len))
+            return set_err("sample windows [%d,%d) / [%d,%d) reach past the core's IO span %d", in_io_base, in_io_base + in_stride,
+                           out_io_base, out_io_base + out_stride, pl.ga.scratch_len);
+        BlockIO io;
+        io.in = (const unsigned *)d_in;  io.in_stride = in_stride;   io.in_base = in_io_base;
+        io.out = (unsigned *)d_out;      io.out_stride = out_stride; io.out_base = out_io_base;
+        io.nframes = nframes; io.store_mask = -1;
+        return launch_generic(prog, pl, io, (hipStream_t)stream);
+    }
     for (int f0 = 0; f0 < nframes; f0 += kFirChunk) {
         BlockIO io;
         io.in = (const unsigned *)d_in + (size_t)f0 * in_stride;  io.in_stride = in_stride;   io.in_base = in_io_base;
@@ -1105,7 +1202,7 @@ int avdsp_hip_run_block_host(avdsp_hip_prog *prog, int plan, const void *h_in, i
     Plan &pl = prog->plans[plan];
     if (in_stride == 0 && out_stride == 0) {
         /* single-frame dspRuntime_N(): both windows are the caller's samples[] array, IO 0 .. span */
-        in_stride = out_stride = std::max(pl.io_in_max, pl.io_out_max) + 1;
+        in_stride = out_stride = pl.generic ? pl.io_span : std::max(pl.io_in_max, pl.io_out_max) + 1;
         in_io_base = out_io_base = 0;
     }
     const size_t in_words = (size_t)nframes * in_stride, out_words = (size_t)nframes * out_stride;

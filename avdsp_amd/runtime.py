@@ -23,15 +23,16 @@ CSRC = os.path.join(HERE, "csrc")
 EXPORTED = [
     # reference API
     "dspFindCore", "dspFindCoreBegin", "dspRuntimeReset", "dspRuntimeInit",
-    "dspRuntime_2", "dspRuntime_4", "dspRuntime_6",
+    "dspRuntime_2", "dspRuntime_3", "dspRuntime_4", "dspRuntime_5", "dspRuntime_6",
     "dspHeaderPtr", "dspBiquadFreqSkip", "dspMantissa", "dspOpcodeText", "dspQNM", "dspQM64", "dspQM32",
     # block extension (include/avdsp_runtime.h)
-    "dspRuntimeBlock_2", "dspRuntimeBlock_4", "dspRuntimeBlock_6", "dspRuntimeBlockDevice",
+    "dspRuntimeBlock_2", "dspRuntimeBlock_3", "dspRuntimeBlock_4", "dspRuntimeBlock_5", "dspRuntimeBlock_6",
+    "dspRuntimeBlockDevice",
     "dspRuntimeSyncState", "dspRuntimeUploadState", "dspRuntimeSetOption", "dspRuntimeGetOption",
     "dspRuntimeCoreInfo", "dspRuntimeKernelTime", "dspRuntimeLastError", "dspRuntimeRelease",
     # thin HIP ABI (include/avdsp_hip.h)
     "avdsp_hip_device_count", "avdsp_hip_set_device", "avdsp_hip_prog_create", "avdsp_hip_prog_destroy",
-    "avdsp_hip_prog_add_plan", "avdsp_hip_upload_words", "avdsp_hip_download_words", "avdsp_hip_zero_words",
+    "avdsp_hip_prog_add_plan", "avdsp_hip_prog_add_generic", "avdsp_hip_tpdf_reset", "avdsp_hip_upload_words", "avdsp_hip_download_words", "avdsp_hip_zero_words",
     "avdsp_hip_run_block", "avdsp_hip_run_block_host", "avdsp_hip_profile_enable", "avdsp_hip_profile_read",
     "avdsp_hip_synchronize", "avdsp_hip_last_error",
 ]
@@ -86,9 +87,9 @@ def lib() -> C.CDLL:
         L.dspFindCoreBegin.restype = vp; L.dspFindCoreBegin.argtypes = [vp]
         L.dspRuntimeReset.restype = i32; L.dspRuntimeReset.argtypes = [i32, i32, i32]
         L.dspRuntimeInit.restype = i32; L.dspRuntimeInit.argtypes = [vp, i32, i32, i32, i32]
-        for n in ("dspRuntime_2", "dspRuntime_4", "dspRuntime_6"):
+        for n in ("dspRuntime_2", "dspRuntime_3", "dspRuntime_4", "dspRuntime_5", "dspRuntime_6"):
             f = getattr(L, n); f.restype = i32; f.argtypes = [vp, vp, vp]
-        for n in ("dspRuntimeBlock_2", "dspRuntimeBlock_4", "dspRuntimeBlock_6"):
+        for n in ("dspRuntimeBlock_2", "dspRuntimeBlock_3", "dspRuntimeBlock_4", "dspRuntimeBlock_5", "dspRuntimeBlock_6"):
             f = getattr(L, n); f.restype = i32; f.argtypes = [vp, vp, vp, i32, i32, vp, i32, i32, i32]
         L.dspRuntimeBlockDevice.restype = i32
         L.dspRuntimeBlockDevice.argtypes = [i32, vp, vp, vp, i32, i32, vp, i32, i32, i32, vp]
@@ -113,7 +114,7 @@ def lib() -> C.CDLL:
 
 
 def sample_dtype(fmt: int):
-    return np.float32 if fmt == 6 else np.int32
+    return np.float32 if fmt in (5, 6) else np.int32
 
 
 class Runtime:
@@ -123,8 +124,8 @@ class Runtime:
 
     def __init__(self, fmt: int, prog_words: np.ndarray, fs: int = 48000, random: int = 0,
                  dither: int = 31, max_size: int | None = None):
-        if fmt not in (2, 4, 6):
-            raise ValueError("device entry points exist for DSP_FORMAT 2, 4 and 6")
+        if fmt not in (2, 3, 4, 5, 6):
+            raise ValueError("DSP_FORMAT must be one of 2..6")
         self.L = lib()
         self.fmt = fmt
         n = int(prog_words[1]) + max(int(np.int32(prog_words[2])), 0)

@@ -53,6 +53,21 @@ typedef struct avdsp_plan_desc {
     int32_t  store_mask;             /* tpdf mask applied by STORE in int-sample formats         */
 } avdsp_plan_desc;
 
+/* A core that is not a set of independent chains runs through the general device interpreter
+ * (avdsp_interp.inc: every opcode of dsp_runtime.c:302-1314, formats 2..6, sequential over frames).
+ * The host has validated every offset the opcode stream can reach before it asks for this.       */
+typedef struct avdsp_generic_desc {
+    int32_t  format;                 /* 2..6                                                     */
+    int32_t  core_word;              /* word index of the first opcode executed                  */
+    int32_t  prog_words;             /* header totalLength: the data area starts at this word    */
+    int32_t  freq_index, num_freq;   /* dsp_runtime.c:103-107                                    */
+    int32_t  biquad_freq_skip;       /* 2 + 6*num_freq, :37                                      */
+    int32_t  biquad_freq_offset;     /* 5 + 6*freq_index, :110                                   */
+    uint32_t delay_line_factor;      /* 2^32 * fs / 10^6, :82-90,108                             */
+    int32_t  io_span;                /* highest IO number the core touches + 1                   */
+    int32_t  io_in_min, io_in_max, io_out_min, io_out_max;   /* for the window check (max < min = none) */
+} avdsp_generic_desc;
+
 /* A loaded program on the device: the mirror of the caller's buffer plus one plan per lowered core */
 typedef struct avdsp_hip_prog avdsp_hip_prog;
 
@@ -63,6 +78,9 @@ int             avdsp_hip_set_device(int ordinal);
 avdsp_hip_prog *avdsp_hip_prog_create(int total_words);
 void            avdsp_hip_prog_destroy(avdsp_hip_prog *prog);
 int             avdsp_hip_prog_add_plan(avdsp_hip_prog *prog, const avdsp_plan_desc *desc);   /* plan id */
+int             avdsp_hip_prog_add_generic(avdsp_hip_prog *prog, const avdsp_generic_desc *desc);   /* plan id */
+/* dspTpdfInit (dsp_tpdf.h:85-99) on the device copy of the dither generator's globals */
+int             avdsp_hip_tpdf_reset(avdsp_hip_prog *prog, int seed, int default_dither);
 
 /* mirror maintenance: word ranges of the caller's buffer */
 int avdsp_hip_upload_words(avdsp_hip_prog *prog, const int32_t *host_buf, int first_word, int nwords);
@@ -83,7 +101,7 @@ int avdsp_hip_run_block_host(avdsp_hip_prog *prog, int plan, const void *h_in, i
 /* Per-kernel timing: when enabled, every kernel launch of run_block is bracketed by a HIP event pair
  * recorded on the launch stream; profile_read waits for the recorded pairs of one kind, returns
  * the summed duration and the number of launches, and forgets them.                              */
-enum { AVDSP_KERNEL_BIQUAD = 0, AVDSP_KERNEL_FIR = 1, AVDSP_KERNEL_PASS = 2 };
+enum { AVDSP_KERNEL_BIQUAD = 0, AVDSP_KERNEL_FIR = 1, AVDSP_KERNEL_PASS = 2, AVDSP_KERNEL_GENERIC = 3 };
 int avdsp_hip_profile_enable(avdsp_hip_prog *prog, int on);
 int avdsp_hip_profile_read(avdsp_hip_prog *prog, int kind, double *total_ms, int *launches);
 

@@ -51,7 +51,9 @@ int dspRuntimeInit(opcode_t *codePtr, int maxSize, const int fs, int random, int
  * read and written in place.  Returns 0 like the reference on success; negative on failure
  * (the reference cannot fail here; this implementation can: no GPU, core not lowerable).         */
 int dspRuntime_2(opcode_t *core, int *rundata, int   *samples);   /* DSP_FORMAT_INT64        */
+int dspRuntime_3(opcode_t *core, int *rundata, int   *samples);   /* DSP_FORMAT_FLOAT        */
 int dspRuntime_4(opcode_t *core, int *rundata, int   *samples);   /* DSP_FORMAT_DOUBLE       */
+int dspRuntime_5(opcode_t *core, int *rundata, float *samples);   /* DSP_FORMAT_FLOAT_FLOAT  */
 int dspRuntime_6(opcode_t *core, int *rundata, float *samples);   /* DSP_FORMAT_DOUBLE_FLOAT */
 
 extern dspHeader_t *dspHeaderPtr;           /* dsp_runtime.c:36 */
@@ -68,9 +70,21 @@ int       dspQM32(double x, int m);         /* dsp_header.c:83-85 */
  *     samples[in_io_base + k]  = in[n*in_stride + k]          k in [0, in_stride)
  *     dspRuntime_N(core, rundata, samples)
  *     out[n*out_stride + k]    = samples[out_io_base + k]     k in [0, out_stride)
- * Output slots the core never stores are left untouched.  in/out are HOST pointers here.         */
+ * Output slots the core never stores are left untouched.  in/out are HOST pointers here.
+ * The two windows must not overlap in IO numbers (a single frame through dspRuntime_N, where both
+ * are the caller's samples[] array, is the exception).
+ *
+ * Two device paths sit behind these entry points.  A core that is a set of independent
+ * LOAD|LOAD_GAIN -> BIQUADS* -> [FIR] -> [SAT0DB] -> STORE+ chains (formats 2, 4, 6) runs on the
+ * parallel kernels (section-pipelined cascade, MFMA FIR).  Any other core -- X/Y arithmetic, TPDF
+ * dither, delay lines, LOAD_MUX, RMS ..., and every core in formats 3 and 5 -- runs through the
+ * general device interpreter, which is sequential over frames like the reference.  There is no CPU path. */
 int dspRuntimeBlock_2(opcode_t *core, int *rundata, const int *in, int in_stride, int in_io_base,
                       int *out, int out_stride, int out_io_base, int nframes);
+int dspRuntimeBlock_3(opcode_t *core, int *rundata, const int *in, int in_stride, int in_io_base,
+                      int *out, int out_stride, int out_io_base, int nframes);
+int dspRuntimeBlock_5(opcode_t *core, int *rundata, const float *in, int in_stride, int in_io_base,
+                      float *out, int out_stride, int out_io_base, int nframes);
 int dspRuntimeBlock_4(opcode_t *core, int *rundata, const int *in, int in_stride, int in_io_base,
                       int *out, int out_stride, int out_io_base, int nframes);
 int dspRuntimeBlock_6(opcode_t *core, int *rundata, const float *in, int in_stride, int in_io_base,
@@ -82,7 +96,10 @@ int dspRuntimeBlockDevice(int format, opcode_t *core, int *rundata,
                           const void *d_in, int in_stride, int in_io_base,
                           void *d_out, int out_stride, int out_io_base, int nframes, void *stream);
 
-/* device state -> rundata (the buffer stays the checkpoint) / rundata -> device state (restore) */
+/* device state -> rundata (the buffer stays the checkpoint) / rundata -> device state (restore).
+ * Sync also brings back the program words (DSP_STORE_MEM writes into the program's parameter
+ * section, dsp_runtime.c:755-760).  A host that edits parameters in the program words afterwards
+ * calls dspRuntimeReset (plans are rebuilt from the buffer at the next block).                   */
 int dspRuntimeSyncState(int *rundata);
 int dspRuntimeUploadState(const int *rundata);
 
@@ -92,11 +109,13 @@ int dspRuntimeSetOption(const char *key, int value);
 int dspRuntimeGetOption(const char *key);
 
 /* Kernel timing with HIP events on the launch stream: enable with dspRuntimeSetOption("profile", 1);
- * kind 0 = biquad cascade, 1 = FIR, 2 = pass-through.  Returns the summed duration (ms) and launch
+ * kind 0 = biquad cascade, 1 = FIR, 2 = pass-through, 3 = general interpreter.  Returns the summed duration (ms) and launch
  * count of the launches recorded since the previous read.                                        */
 int dspRuntimeKernelTime(int kind, double *total_ms, int *launches);
 
-/* Introspection of the lowered core (what the device plan contains); negative when not lowerable. */
+/* Introspection of the lowered core (what the device plan contains), host-only.  nchains > 0: the
+ * parallel chain kernels take it; nchains == 0: the general interpreter takes it; negative: neither
+ * (encoding mismatch, an offset outside the buffer, an opcode with no defined result in this format). */
 int dspRuntimeCoreInfo(int format, opcode_t *core, int *nchains, int *max_sections, int *max_taps);
 
 const char *dspRuntimeLastError(void);

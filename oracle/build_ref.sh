@@ -19,7 +19,7 @@
 #       the libraries are opened with RTLD_LAZY by ref_driver, so they are simply never bound.
 #   refk_{2,6}.so               oracle/ref_kernels.c, which #includes the UNPATCHED reference headers
 #       (dsp_biquadSTD.h, dsp_firSTD.h, dsp_ieee754.h, dsp_fpmath.h) and exports the hot kernels.
-#   libavdspencoder.so, ref_encode   the unmodified reference encoder + oracle/ref_encode.c driver.
+#   libavdspencoder.so, ref_encode, ref_encode_ops   the unmodified reference encoder + the oracle/ref_encode*.c drivers.
 #   ref_driver                  oracle/ref_driver.c: runs a .bin over a raw input file through a
 #                               libavdspref_N.so and writes the raw output (used to make goldens).
 set -euo pipefail
@@ -52,6 +52,8 @@ gcc $CF -I"$ENC" -I"$RT" -shared -o "$OUT/libavdspencoder.so" \
     "$ENC/dsp_encoder.c" "$ENC/dsp_fileaccess.c" "$ENC/dsp_filters.c" \
     "$ENC/dsp_HilbertDesign.c" "$ENC/dsp_nanosharcxml.c" "$RT/dsp_header.c" -lm
 gcc $CF -I"$ENC" -I"$RT" -o "$OUT/ref_encode" "$HERE/ref_encode.c" \
+    -L"$OUT" -lavdspencoder -Wl,-rpath,'$ORIGIN' -lm -ldl
+gcc $CF -I"$ENC" -I"$RT" -o "$OUT/ref_encode_ops" "$HERE/ref_encode_ops.c" \
     -L"$OUT" -lavdspencoder -Wl,-rpath,'$ORIGIN' -lm -ldl
 gcc $CF -I"$ENC" -I"$RT" -o "$OUT/dspcreate" "$ENC/dspcreate.c" \
     -L"$OUT" -lavdspencoder -Wl,-rpath,'$ORIGIN' -lm -ldl

@@ -90,6 +90,20 @@ def main():
              lcg(300, 16, seed=4242), 32, 8, 0, fs=96000, random=7, dither=24, block=1,
              scratch=40, manifest=manifest)
 
+    # ---- opcode tour: every opcode the committed programs do not reach, encoded by the reference
+    #      encoder (oracle/ref_encode_ops.c) and run by the reference runtimes in all five formats.
+    #      (DSP_DCBLOCK in the float-accumulator formats 3 and 5: the reference's own -Ofast build
+    #      evaluates acc + (x - x1) as (acc + x) - x1; restatements follow the binary, see oracle_interp.inc.)
+    print("opcode tour")
+    for enc_fmt, fname, fmts in ((2, "tour_int.bin", [2]), (6, "tour_float.bin", [3, 4, 5, 6])):
+        subprocess.check_call([os.path.join(REFBIN, "ref_encode_ops"), str(enc_fmt), os.path.join(OUT, fname)],
+                              stdout=subprocess.DEVNULL)
+        for fmt in fmts:
+            for fs, block, full in ((48000, 64, True), (48000, 1, False), (96000, 1200, False)):
+                run_case(f"{fname[:-4]}_f{fmt}_fs{fs}_b{block}", fmt, dict(kind="file", name=fname),
+                         lcg(1200, 16, seed=77), 32, 32, 0, fs=fs, random=12345, dither=24, block=block,
+                         scratch=48, full=full, manifest=manifest)
+
     # ---- reference-encoder byte identity for progbuilder.py ----
     print("reference encoder programs")
     enc = []

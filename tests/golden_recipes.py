@@ -42,3 +42,22 @@ def make_input(recipe: dict, fmt: int) -> np.ndarray:
         x[0, :] = recipe["value_f"] if fl else recipe["value_i"]
         return x
     raise ValueError(kind)
+
+
+
+def check_against_golden(case: dict, out: np.ndarray, state: np.ndarray, sha) -> None:
+    """Outputs and final state area against what the compiled reference produced, bit for bit."""
+    g = np.load(os.path.join(GOLDEN_DIR, case["name"] + ".npz"))
+
+    def same(a, b, what):
+        a, b = a.view(np.uint32), b.view(np.uint32)
+        assert (a == b).all(), f"{case['name']}: {what} differs from the reference's " \
+            f"(columns {sorted(set(np.nonzero(a != b)[1].tolist()))[:8]})"
+
+    same(out[:16], g["head"], "head")
+    same(out[-16:], g["tail"], "tail")
+    if case["full"]:
+        same(out, g["out"], "output")
+        assert (state == g["state"]).all(), f"{case['name']}: state area differs from the reference's"
+    assert sha(out) == case["out_sha"]
+    assert sha(state) == case["state_sha"]

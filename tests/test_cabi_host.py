@@ -73,12 +73,18 @@ def test_lowering_reports_chains():
     assert r.core_info() == dict(chains=64, max_sections=16, max_taps=0)
 
 
-def test_refusals_are_loud():
+def test_path_selection_and_refusals():
+    """Host-only lowering: chains -> parallel kernels, anything else -> general interpreter (chains == 0),
+    and a loud refusal where neither has a defined result."""
     prog = np.fromfile(os.path.join(GOLDEN_DIR, "crossoverLV6.bin"), dtype=np.uint32)
     r = rt.Runtime(2, prog, fs=48000, dither=24)
-    with pytest.raises(rt.AvdspError) as e:
-        r.core_info(0)
-    assert e.value.code == -8 and "DSP_TPDF_CALC" in str(e.value)
+    assert r.core_info(0) == dict(chains=0, max_sections=0, max_taps=0)      # TPDF, X/Y ops, delay
+    assert r.core_info(1)["chains"] == 0
+    for name, fmt in (("tour_int.bin", 2), ("tour_float.bin", 3), ("tour_float.bin", 6)):
+        r = rt.Runtime(fmt, np.fromfile(os.path.join(GOLDEN_DIR, name), dtype=np.uint32), fs=96000, dither=24)
+        assert all(r.core_info(k)["chains"] == 0 for k in range(len(r.cores)))
+    r = rt.Runtime(5, pb.synth_program(6, 4, 2, 7))          # formats 3 and 5: interpreter only
+    assert r.core_info()["chains"] == 0
     r = rt.Runtime(2, pb.synth_program(2, 2, 1, 9))          # FIR in int64 mode: undefined in the reference
     with pytest.raises(rt.AvdspError) as e:
         r.core_info()
@@ -87,19 +93,31 @@ def test_refusals_are_loud():
     with pytest.raises(rt.AvdspError) as e:
         r.core_info()
     assert e.value.code == -7
-    # a chain that loads what another chain of the same core stores is a sequential dependency
+    # a chain that loads what another chain of the same core stores is a sequential dependency:
+    # not parallel chains, so the frame-sequential interpreter takes it
     pw = pb.ProgramWriter(6)
     pw.core(); pw.load(4); pw.store(1); pw.load(1); pw.store(2)
     r = rt.Runtime(6, pw.end_of_code())
-    with pytest.raises(rt.AvdspError) as e:
-        r.core_info()
-    assert e.value.code == -8 and "cross-chain" in str(e.value)
-    # two chains storing the same IO
+    assert r.core_info()["chains"] == 0
+    # two chains storing the same IO: order matters, same answer
     pw = pb.ProgramWriter(6)
     pw.core(); pw.load(4); pw.store(1); pw.load(5); pw.store(1)
     r = rt.Runtime(6, pw.end_of_code())
-    with pytest.raises(rt.AvdspError):
-        r.core_info()
+    assert r.core_info()["chains"] == 0
+    # offsets the opcode stream would follow outside the buffer are caught on the host
+    prog = np.fromfile(os.path.join(GOLDEN_DIR, "dacdiy1.bin"), dtype=np.uint32).copy()
+    i = 0
+    while (int(prog[i]) >> 16) != 39:                       # DSP_LOAD_MEM: [program-relative offset]
+        i += int(prog[i]) & 0xFFFF
+    prog[i + 1] = 100000
+    r = rt.Runtime(2, prog, fs=48000, dither=24)
+    bad = []
+    for k in range(len(r.cores)):
+        try:
+            r.core_info(k)
+        except rt.AvdspError as e:
+            bad.append((e.code, str(e)))
+    assert len(bad) == 1 and bad[0][0] == -8 and "outside the program" in bad[0][1]
 
 
 def test_no_cpu_fallback_without_a_gpu():

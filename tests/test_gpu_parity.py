@@ -17,7 +17,7 @@ import pytest
 from avdsp_amd import progbuilder as pb
 from avdsp_amd import runtime as rt
 from oracle import pyoracle as po
-from tests.golden_recipes import GOLDEN_DIR, make_input, make_program
+from tests.golden_recipes import GOLDEN_DIR, check_against_golden, make_input, make_program
 
 pytestmark = pytest.mark.gpu
 
@@ -27,6 +27,11 @@ with open(os.path.join(GOLDEN_DIR, "manifest.json")) as _f:
     MANIFEST = json.load(_f)
 
 DEVICE_CASES = [c for c in MANIFEST["cases"] if c["fmt"] in (2, 4, 6) and c["program"]["kind"] == "synth"]
+# the general device interpreter: every committed / reference-encoded program (none of them is a pure
+# set of chains), and the synthetic chain programs forced through it (formats 3 and 5 have no other path);
+# the long-FIR cases would take minutes on one lane
+GENERAL_CASES = [c for c in MANIFEST["cases"] if c["program"]["kind"] == "file" or
+                 (c["nframes"] * max(c["program"].get("taps", 0), 1) * c["program"].get("channels", 1) <= 2_000_000)]
 
 
 def sha(a):
@@ -204,26 +209,75 @@ def test_bypass_and_multi_bank_and_plain_load():
     assert r.core_info() == dict(chains=2, max_sections=3, max_taps=0)
 
 
-def test_refuses_cores_it_cannot_lower():
-    """No CPU fallback: opcodes outside the hot path make the block call fail loudly."""
-    prog = np.fromfile(os.path.join(GOLDEN_DIR, "crossoverLV6.bin"), dtype=np.uint32)
-    r = rt.Runtime(2, prog, fs=48000, dither=24)
-    assert r.rc == 288 and len(r.cores) == 2
-    x = np.zeros((4, 16), dtype=np.int32)
-    with pytest.raises(rt.AvdspError) as e:
-        r.run_block(x, 32, 8)
-    assert e.value.code == -8 and "not lowered" in str(e.value)
+@pytest.mark.parametrize("case", GENERAL_CASES, ids=lambda c: c["name"])
+def test_golden_general_interpreter(case):
+    """Programs with X/Y arithmetic, dither, delay lines, mixers, meters ... against
+    the vectors the compiled reference produced: outputs and the final state area, bit for bit, in
+    all five arithmetic models."""
+    fmt = case["fmt"]
+    prog = make_program(case["program"])
+    x = make_input(case["input"], fmt)
+    r = rt.Runtime(fmt, prog, fs=case["fs"], random=case["random"], dither=case["dither"])
+    assert r.rc == case["init_rc"]
+    if case["program"]["kind"] == "synth":
+        r.set_option("generic", 1)
+    try:
+        out = r.run_block(x, case["out_stride"], case["in_base"], case["out_base"], block=case["block"])
+        if r.cores:
+            assert r.core_info(0)["chains"] == 0            # it really was the interpreter
+        check_against_golden(case, out, r.sync_state(), sha)
+    finally:
+        r.set_option("generic", 0)
+
+
+def test_general_interpreter_single_frame_and_store_mem():
+    """dspRuntime_N on a non-chain program: samples[] in place, frame by frame, equals the block call;
+    DSP_STORE_MEM results come back into the program words with dspRuntimeSyncState."""
+    prog = np.fromfile(os.path.join(GOLDEN_DIR, "dacdiy1.bin"), dtype=np.uint32)
+    x = pb.lcg_input(40, 16, False, seed=5)
+    o = po.OracleProgram(2, prog, fs=48000, random=3, dither=24)
+    want = o.run_block(x, 32, 8, 0, scratch_len=40, block=1)
+    r = rt.Runtime(2, prog, fs=48000, random=3, dither=24)
+    got = np.zeros_like(want)
+    frame = np.zeros(40, dtype=np.int32)
+    for n in range(len(x)):
+        frame[8:24] = x[n]
+        for core in range(len(r.cores)):
+            r.run_frame(frame, core)
+        got[n] = frame[:32]
+        frame[:32] = 0
+    # the oracle's block loop starts every frame from the (zero) output row: same thing
+    assert (got == want).all()
+    assert (r.sync_state() == o.state).all()
+    n = int(prog[1])
+    assert (r.buf[:n] == o.buf[:n]).all(), "program words (STORE_MEM targets) differ"
+    assert (r.buf[:n] != prog[:n]).any(), "this program is expected to write into its parameter section"
+
+
+def test_refusals_are_loud():
+    """No CPU fallback and no guessing: what neither device path can run fails with a reason."""
     # int64 FIR is undefined behaviour in the reference: refused, not guessed
     prog = pb.synth_program(2, 2, 1, 9)
     r = rt.Runtime(2, prog)
     with pytest.raises(rt.AvdspError) as e:
         r.run_block(np.zeros((4, 2), dtype=np.int32), 2, 2)
-    assert e.value.code == -8
+    assert e.value.code == -8 and "undefined behaviour" in str(e.value)
     # float-encoded program through the int64 entry point
     r = rt.Runtime(2, pb.synth_program(6, 2, 1))
     with pytest.raises(rt.AvdspError) as e:
         r.run_block(np.zeros((4, 2), dtype=np.int32), 2, 2)
     assert e.value.code == -7 and "encoded" in str(e.value)
+    # a state offset outside the data area (the reference would scribble over memory)
+    prog = np.fromfile(os.path.join(GOLDEN_DIR, "crossoverLV6.bin"), dtype=np.uint32).copy()
+    i = 0
+    while (int(prog[i]) >> 16) != 47:                       # DSP_DELAY: [maxSize][data offset][us offset]
+        i += int(prog[i]) & 0xFFFF
+    prog[i + 2] = 1 << 20
+    r = rt.Runtime(2, prog, fs=48000, dither=24)
+    assert r.rc == 288                                       # payload words are not part of the checksum
+    with pytest.raises(rt.AvdspError) as e:
+        r.run_block(np.zeros((4, 16), dtype=np.int32), 32, 8)
+    assert e.value.code == -8 and "outside the state area" in str(e.value)
 
 
 @pytest.mark.parametrize("neg", MANIFEST["init_return_codes"], ids=lambda n: n["case"])
