@@ -34,6 +34,9 @@ REF = os.environ.get("AVDSP_REFERENCE", "/root/reference") + "/module_avdsp"
 REFBIN = po.REF_DIR
 
 
+ENC_SWEEP_VARIANTS = [(2, 4, 9), (6, 4, 7), (6, 0, 13), (2, 5, 5)]     # (encoding, freqMin index, freqMax index)
+
+
 def sha(a: np.ndarray) -> str:
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
@@ -103,6 +106,13 @@ def main():
                 run_case(f"{fname[:-4]}_f{fmt}_fs{fs}_b{block}", fmt, dict(kind="file", name=fname),
                          lcg(1200, 16, seed=77), 32, 32, 0, fs=fs, random=12345, dither=24, block=block,
                          scratch=48, full=full, manifest=manifest)
+
+    # ---- encoder workout (oracle/enc_sweep.c) through the reference encoder: byte fixtures for
+    #      avdsp_amd/csrc/avdsp_encoder.c (tests/test_encoder.py) ----
+    print("encoder sweep")
+    for fmt, fmin, fmax in ENC_SWEEP_VARIANTS:
+        subprocess.check_call([os.path.join(REFBIN, "enc_sweep"), str(fmt), str(fmin), str(fmax),
+                               os.path.join(OUT, f"enc_sweep_{fmt}_{fmin}_{fmax}.bin")], stdout=subprocess.DEVNULL)
 
     # ---- reference-encoder byte identity for progbuilder.py ----
     print("reference encoder programs")
