@@ -701,6 +701,29 @@ int dspRuntimeBlock_6(opcode_t *core, int *rundata, const float *in, int in_stri
                       float *out, int out_stride, int out_io_base, int nframes)
 { return block_host(6, core, rundata, in, in_stride, in_io_base, out, out_stride, out_io_base, nframes); }
 
+/* linux/avdsp_plugin.c:95-142 with the sample-format switch of :109-121: packed PCM in, S32 out */
+int dspRuntimeBlockPcm(int format, opcode_t *core, int *rundata, int pcm, const void *src, int in_stride, int in_io_base,
+                       int *dst, int out_stride, int out_io_base, int nframes)
+{
+    if (format != 2 && format != 3 && format != 4)
+        return fail(-1, "packed PCM feeds the int-sample formats 2, 3 and 4 (DSP_FORMAT %d has float samples)", format);
+    core_plan *cp = get_plan(format, core);
+    if (!cp) return g_err_code;
+    if (check_rundata(rundata)) return -1;
+    if (nframes <= 0) return 0;
+    if (avdsp_hip_run_block_pcm_host(G.dev, cp->plan_id, pcm, src, in_stride, in_io_base, dst, out_stride, out_io_base,
+                                     nframes, G.opt_fir_impl, G.opt_biquad_impl))
+        return fail(-10, "%s", avdsp_hip_last_error());
+    return 0;
+}
+
+int dspRuntimeUnpackPcmDevice(int pcm, const void *d_src, int *d_dst, long long nsamples, void *stream)
+{
+    if (!G.dev) return fail(-1, "no device program yet: run a block first");
+    if (avdsp_hip_unpack_pcm(G.dev, pcm, d_src, d_dst, (size_t)nsamples, stream)) return fail(-10, "%s", avdsp_hip_last_error());
+    return 0;
+}
+
 /* One frame = a block of one frame whose input and output windows are both the caller's samples[]
  * array (IO numbers index it directly).  The window is the span of IO numbers the core touches. */
 static int one_frame(int format, opcode_t *core, int *rundata, void *samples)

@@ -739,6 +739,42 @@ __global__ __launch_bounds__(kBlock) void passthrough(const PassArgs a)
     }
 }
 
+/* ------------------------------------------------------------------------------------------
+ * host sample formats -> s.31 words (linux/avdsp_plugin.c:103-121): pure byte traffic, HBM-bound.
+ * Each thread converts four consecutive samples from whole 32-bit loads (S24_3LE: 3 words in, 4 out;
+ * S16: 2 words in, 4 out) so that a wave reads and writes contiguous, dword-aligned spans; the ragged
+ * end (and a misaligned source) is done sample by sample.
+ * ---------------------------------------------------------------------------------------- */
+struct UnpackArgs { const unsigned char *src; unsigned *dst; size_t n; };
+
+__device__ __forceinline__ unsigned pcm24_at(const unsigned char *p) { return ((unsigned)p[0] << 8) | ((unsigned)p[1] << 16) | ((unsigned)p[2] << 24); }
+
+template <int PCM>
+__global__ __launch_bounds__(kBlock) void pcm_unpack(const UnpackArgs a)
+{
+    const size_t quads = ((reinterpret_cast<size_t>(a.src) & 3) == 0) ? a.n / 4 : 0;
+    const size_t stride = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned *w = reinterpret_cast<const unsigned *>(a.src);
+    for (size_t q = t0; q < quads; q += stride) {
+        uint4 o;
+        if constexpr (PCM == AVDSP_PCM_S24_3LE) {
+            const unsigned w0 = w[3 * q], w1 = w[3 * q + 1], w2 = w[3 * q + 2];
+            o.x = w0 << 8;
+            o.y = ((w0 >> 24) | (w1 << 8)) << 8;
+            o.z = ((w1 >> 16) | (w2 << 16)) << 8;
+            o.w = w2 & 0xFFFFFF00u;
+        } else {
+            const unsigned w0 = w[2 * q], w1 = w[2 * q + 1];
+            o.x = w0 << 16; o.y = w0 & 0xFFFF0000u; o.z = w1 << 16; o.w = w1 & 0xFFFF0000u;
+        }
+        reinterpret_cast<uint4 *>(a.dst)[q] = o;
+    }
+    for (size_t i = quads * 4 + t0; i < a.n; i += stride) {
+        if constexpr (PCM == AVDSP_PCM_S24_3LE) a.dst[i] = pcm24_at(a.src + 3 * i);
+        else a.dst[i] = ((unsigned)a.src[2 * i] | ((unsigned)a.src[2 * i + 1] << 8)) << 16;
+    }
+}
+
 #include "avdsp_interp.inc"
 
 /* ------------------------------------------------------------------------------------------
@@ -748,7 +784,7 @@ struct Plan {
     bool generic = false;             /* general interpreter instead of chain kernels */
     GenericArgs ga{};                 /* launch template of the generic path (io filled per block) */
     int io_span = 0;                  /* highest IO number the core touches + 1 */
-    size_t ga_lds = 0;
+    size_t ga_lds = 0; bool ga_staged = false;
     int format = 0, nchains = 0, store_mask = -1;
     avdsp_chain *d_chains = nullptr;
     int *d_sec_coef = nullptr, *d_sec_state = nullptr;
@@ -1022,6 +1058,7 @@ int avdsp_hip_prog_add_plan(avdsp_hip_prog *prog, const avdsp_plan_desc *d)
 
 /* LDS budget of the generic path: frame (when small) + staged mirror, one workgroup per CU at most */
 static const int kGenericFrameLds = 4096;            /* words */
+static const int kGenericBatchLds = 8192;            /* words: input + output rows of one batch of frames */
 static const size_t kGenericLdsMax = 144 * 1024;     /* bytes */
 
 int avdsp_hip_prog_add_generic(avdsp_hip_prog *prog, const avdsp_generic_desc *d)
@@ -1040,7 +1077,7 @@ int avdsp_hip_prog_add_generic(avdsp_hip_prog *prog, const avdsp_generic_desc *d
     a.freq_index = d->freq_index; a.num_freq = d->num_freq;
     a.biquad_skip = d->biquad_freq_skip; a.biquad_offset = d->biquad_freq_offset;
     a.delay_factor = d->delay_line_factor;
-    /* one samples[] frame per program, shared by its cores; small frames are worked on in LDS */
+    /* one samples[] frame per program, shared by its cores */
     const int want = std::max(d->io_span, kGenericFrameLds);
     if (prog->frame_words < want) {
         for (auto &o : prog->plans) if (o.generic) return set_err("generic plan: IO span %d after a core with a smaller frame", d->io_span);
@@ -1051,21 +1088,29 @@ int avdsp_hip_prog_add_generic(avdsp_hip_prog *prog, const avdsp_generic_desc *d
     }
     a.scratch = prog->d_frame;
     a.scratch_len = prog->frame_words;
-    a.frame_in_lds = prog->frame_words <= kGenericFrameLds;
-    a.frame_lds = a.frame_in_lds ? prog->frame_words : 0;
-    const size_t staged = ((size_t)a.frame_lds + prog->total_words) * 4;
-    if (staged <= kGenericLdsMax) { a.stage_words = prog->total_words; a.keep_words = (int)(sizeof(dspHeader_t) / 4); }
-    pl.ga_lds = a.stage_words ? staged : (size_t)a.frame_lds * 4;
-    const void *fn = nullptr;
-    switch (d->format) {
-    case 2: fn = (const void *)interp_core<2>; break;
-    case 3: fn = (const void *)interp_core<3>; break;
-    case 4: fn = (const void *)interp_core<4>; break;
-    case 5: fn = (const void *)interp_core<5>; break;
-    default: fn = (const void *)interp_core<6>; break;
+    /* staged: LDS = [frame][mirror][batch rows], everything the interpreter touches per opcode is LDS;
+     * otherwise (program or IO span too large) LDS = [batch rows] and it works out of HBM */
+    const size_t staged_bytes = ((size_t)prog->frame_words + prog->total_words + kGenericBatchLds) * 4;
+    pl.ga_staged = staged_bytes <= kGenericLdsMax;
+    if (pl.ga_staged) {
+        a.frame_lds = prog->frame_words;
+        a.stage_words = prog->total_words; a.keep_words = (int)(sizeof(dspHeader_t) / 4);
+        a.batch_lds = a.frame_lds + a.stage_words;
+        pl.ga_lds = staged_bytes;
+    } else {
+        a.frame_lds = 0; a.stage_words = 0; a.batch_lds = 0;
+        pl.ga_lds = (size_t)kGenericBatchLds * 4;
     }
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGenericLdsMax);
-    if (e != hipSuccess) { free_plan(pl); return set_err("hipFuncSetAttribute(generic LDS): %s", hipGetErrorString(e)); }
+    static bool lds_opt_in = false;
+    if (!lds_opt_in) {
+        const void *fns[] = { (const void *)interp_core<2, true>, (const void *)interp_core<3, true>, (const void *)interp_core<4, true>,
+                              (const void *)interp_core<5, true>, (const void *)interp_core<6, true> };
+        for (const void *fn : fns) {
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGenericLdsMax);
+            if (e != hipSuccess) return set_err("hipFuncSetAttribute(generic LDS): %s", hipGetErrorString(e));
+        }
+        lds_opt_in = true;
+    }
     prog->plans.push_back(pl);
     return (int)prog->plans.size() - 1;
 }
@@ -1085,13 +1130,17 @@ static int launch_generic(avdsp_hip_prog *prog, Plan &pl, BlockIO io, hipStream_
     GenericArgs a = pl.ga;
     a.io = io;
     const dim3 grid(1), block(64);
+#define AVDSP_LAUNCH_INTERP(F) \
+    if (pl.ga_staged) hipLaunchKernelGGL((interp_core<F, true>), grid, block, pl.ga_lds, stream, a); \
+    else              hipLaunchKernelGGL((interp_core<F, false>), grid, block, pl.ga_lds, stream, a)
     switch (pl.format) {
-    case 2:  hipLaunchKernelGGL(interp_core<2>, grid, block, pl.ga_lds, stream, a); break;
-    case 3:  hipLaunchKernelGGL(interp_core<3>, grid, block, pl.ga_lds, stream, a); break;
-    case 4:  hipLaunchKernelGGL(interp_core<4>, grid, block, pl.ga_lds, stream, a); break;
-    case 5:  hipLaunchKernelGGL(interp_core<5>, grid, block, pl.ga_lds, stream, a); break;
-    default: hipLaunchKernelGGL(interp_core<6>, grid, block, pl.ga_lds, stream, a); break;
+    case 2:  AVDSP_LAUNCH_INTERP(2); break;
+    case 3:  AVDSP_LAUNCH_INTERP(3); break;
+    case 4:  AVDSP_LAUNCH_INTERP(4); break;
+    case 5:  AVDSP_LAUNCH_INTERP(5); break;
+    default: AVDSP_LAUNCH_INTERP(6); break;
     }
+#undef AVDSP_LAUNCH_INTERP
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1174,6 +1223,9 @@ int avdsp_hip_run_block(avdsp_hip_prog *prog, int plan, const void *d_in, int in
         io.in = (const unsigned *)d_in;  io.in_stride = in_stride;   io.in_base = in_io_base;
         io.out = (unsigned *)d_out;      io.out_stride = out_stride; io.out_base = out_io_base;
         io.nframes = nframes; io.store_mask = -1;
+        if (in_stride + out_stride > kGenericBatchLds)
+            return set_err("sample windows of %d + %d words per frame exceed the interpreter's batch buffer (%d)", in_stride, out_stride, kGenericBatchLds);
+        pl.ga.batch_frames = std::max(1, std::min(64, kGenericBatchLds / std::max(1, in_stride + out_stride)));
         return launch_generic(prog, pl, io, (hipStream_t)stream);
     }
     for (int f0 = 0; f0 < nframes; f0 += kFirChunk) {
@@ -1216,6 +1268,53 @@ int avdsp_hip_run_block_host(avdsp_hip_prog *prog, int plan, const void *h_in, i
     }
     HIP_TRY(hipMemcpy(prog->d_in, h_in, in_words * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(prog->d_out, h_out, out_words * 4, hipMemcpyHostToDevice));   /* unstored slots keep their content */
+    if (avdsp_hip_run_block(prog, plan, prog->d_in, in_stride, in_io_base, prog->d_out, out_stride, out_io_base,
+                            nframes, fir_impl, biquad_impl, nullptr)) return -1;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(h_out, prog->d_out, out_words * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int avdsp_hip_unpack_pcm(avdsp_hip_prog *prog, int pcm, const void *d_src, void *d_dst, size_t nsamples, void *stream)
+{
+    if (pcm != AVDSP_PCM_S24_3LE && pcm != AVDSP_PCM_S16) return set_err("unpack: PCM kind %d needs no conversion or is unknown", pcm);
+    if (reinterpret_cast<size_t>(d_dst) & 15) return set_err("unpack: destination must be 16-byte aligned");
+    if (!nsamples) return 0;
+    ProfileScope scope(prog, (hipStream_t)stream, AVDSP_KERNEL_UNPACK);
+    UnpackArgs a{(const unsigned char *)d_src, (unsigned *)d_dst, nsamples};
+    const int grid = (int)std::min<size_t>((nsamples / 4 + kBlock - 1) / kBlock + 1, 8192);
+    if (pcm == AVDSP_PCM_S24_3LE) hipLaunchKernelGGL(pcm_unpack<AVDSP_PCM_S24_3LE>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a);
+    else                          hipLaunchKernelGGL(pcm_unpack<AVDSP_PCM_S16>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int avdsp_hip_run_block_pcm_host(avdsp_hip_prog *prog, int plan, int pcm, const void *h_src, int in_stride, int in_io_base,
+                                 void *h_out, int out_stride, int out_io_base, int nframes,
+                                 int fir_impl, int biquad_impl)
+{
+    if (plan < 0 || plan >= (int)prog->plans.size()) return set_err("bad plan id %d", plan);
+    if (pcm == AVDSP_PCM_S32)
+        return avdsp_hip_run_block_host(prog, plan, h_src, in_stride, in_io_base, h_out, out_stride, out_io_base, nframes, fir_impl, biquad_impl);
+    if (pcm != AVDSP_PCM_S24_3LE && pcm != AVDSP_PCM_S16) return set_err("unknown PCM kind %d", pcm);
+    if (prog->plans[plan].format > 4) return set_err("packed PCM input feeds the int-sample formats 2, 3, 4 only");
+    if (nframes <= 0) return 0;
+    const size_t nsamples = (size_t)nframes * in_stride, out_words = (size_t)nframes * out_stride;
+    const size_t raw_bytes = nsamples * (pcm == AVDSP_PCM_S16 ? 2 : 3), raw_words = (raw_bytes + 3) / 4;
+    /* staging: [unpacked samples | raw bytes] in d_in, output rows in d_out */
+    const size_t unpacked = (nsamples + 3) & ~(size_t)3;
+    if (prog->in_cap < unpacked + raw_words) {
+        (void)hipFree(prog->d_in); prog->d_in = nullptr; prog->in_cap = 0;
+        HIP_TRY(hipMalloc((void **)&prog->d_in, (unpacked + raw_words) * 4)); prog->in_cap = unpacked + raw_words;
+    }
+    if (prog->out_cap < out_words) {
+        (void)hipFree(prog->d_out); prog->d_out = nullptr; prog->out_cap = 0;
+        HIP_TRY(hipMalloc((void **)&prog->d_out, out_words * 4)); prog->out_cap = out_words;
+    }
+    unsigned *d_raw = prog->d_in + unpacked;
+    HIP_TRY(hipMemcpy(d_raw, h_src, raw_bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(prog->d_out, h_out, out_words * 4, hipMemcpyHostToDevice));
+    if (avdsp_hip_unpack_pcm(prog, pcm, d_raw, prog->d_in, nsamples, nullptr)) return -1;
     if (avdsp_hip_run_block(prog, plan, prog->d_in, in_stride, in_io_base, prog->d_out, out_stride, out_io_base,
                             nframes, fir_impl, biquad_impl, nullptr)) return -1;
     HIP_TRY(hipDeviceSynchronize());

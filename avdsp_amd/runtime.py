@@ -27,13 +27,13 @@ EXPORTED = [
     "dspHeaderPtr", "dspBiquadFreqSkip", "dspMantissa", "dspOpcodeText", "dspQNM", "dspQM64", "dspQM32",
     # block extension (include/avdsp_runtime.h)
     "dspRuntimeBlock_2", "dspRuntimeBlock_3", "dspRuntimeBlock_4", "dspRuntimeBlock_5", "dspRuntimeBlock_6",
-    "dspRuntimeBlockDevice",
+    "dspRuntimeBlockDevice", "dspRuntimeBlockPcm", "dspRuntimeUnpackPcmDevice",
     "dspRuntimeSyncState", "dspRuntimeUploadState", "dspRuntimeSetOption", "dspRuntimeGetOption",
     "dspRuntimeCoreInfo", "dspRuntimeKernelTime", "dspRuntimeLastError", "dspRuntimeRelease",
     # thin HIP ABI (include/avdsp_hip.h)
     "avdsp_hip_device_count", "avdsp_hip_set_device", "avdsp_hip_prog_create", "avdsp_hip_prog_destroy",
     "avdsp_hip_prog_add_plan", "avdsp_hip_prog_add_generic", "avdsp_hip_tpdf_reset", "avdsp_hip_upload_words", "avdsp_hip_download_words", "avdsp_hip_zero_words",
-    "avdsp_hip_run_block", "avdsp_hip_run_block_host", "avdsp_hip_profile_enable", "avdsp_hip_profile_read",
+    "avdsp_hip_run_block", "avdsp_hip_run_block_host", "avdsp_hip_unpack_pcm", "avdsp_hip_run_block_pcm_host", "avdsp_hip_profile_enable", "avdsp_hip_profile_read",
     "avdsp_hip_synchronize", "avdsp_hip_last_error",
 ]
 
@@ -93,6 +93,10 @@ def lib() -> C.CDLL:
             f = getattr(L, n); f.restype = i32; f.argtypes = [vp, vp, vp, i32, i32, vp, i32, i32, i32]
         L.dspRuntimeBlockDevice.restype = i32
         L.dspRuntimeBlockDevice.argtypes = [i32, vp, vp, vp, i32, i32, vp, i32, i32, i32, vp]
+        L.dspRuntimeBlockPcm.restype = i32
+        L.dspRuntimeBlockPcm.argtypes = [i32, vp, vp, i32, vp, i32, i32, vp, i32, i32, i32]
+        L.dspRuntimeUnpackPcmDevice.restype = i32
+        L.dspRuntimeUnpackPcmDevice.argtypes = [i32, vp, vp, C.c_longlong, vp]
         L.dspRuntimeSyncState.restype = i32; L.dspRuntimeSyncState.argtypes = [vp]
         L.dspRuntimeUploadState.restype = i32; L.dspRuntimeUploadState.argtypes = [vp]
         L.dspRuntimeSetOption.restype = i32; L.dspRuntimeSetOption.argtypes = [C.c_char_p, i32]
@@ -111,6 +115,9 @@ def lib() -> C.CDLL:
         L.avdsp_hip_synchronize.restype = i32; L.avdsp_hip_synchronize.argtypes = [vp]
         _lib = L
     return _lib
+
+
+PCM_S32, PCM_S24_3LE, PCM_S16 = 0, 1, 2       # include/avdsp_hip.h AVDSP_PCM_*
 
 
 def sample_dtype(fmt: int):
@@ -189,6 +196,22 @@ class Runtime:
             for core in self.cores:
                 self._check(f(core, self.rundata, x[b0:b1].ctypes.data, in_stride, in_io_base,
                               out[b0:b1].ctypes.data, out_stride, out_io_base, b1 - b0))
+        return out
+
+    def run_block_pcm(self, pcm: int, raw: np.ndarray, nframes: int, in_stride: int, out_stride: int,
+                      in_io_base: int, out_io_base: int = 0, block: int | None = None) -> np.ndarray:
+        """dspRuntimeBlockPcm: `raw` = packed PCM bytes (uint8) of nframes x in_stride samples."""
+        raw = np.ascontiguousarray(raw, dtype=np.uint8)
+        width = {PCM_S32: 4, PCM_S24_3LE: 3, PCM_S16: 2}[pcm]
+        assert raw.size == nframes * in_stride * width
+        out = np.zeros((nframes, out_stride), dtype=np.int32)
+        block = block or nframes
+        for b0 in range(0, nframes, block):
+            b1 = min(b0 + block, nframes)
+            src = raw[b0 * in_stride * width:b1 * in_stride * width]
+            for core in self.cores:
+                self._check(self.L.dspRuntimeBlockPcm(self.fmt, core, self.rundata, pcm, src.ctypes.data, in_stride,
+                                                      in_io_base, out[b0:b1].ctypes.data, out_stride, out_io_base, b1 - b0))
         return out
 
     def run_block_device(self, d_in_ptr: int, in_stride: int, in_io_base: int, d_out_ptr: int,

@@ -98,10 +98,20 @@ int avdsp_hip_run_block_host(avdsp_hip_prog *prog, int plan, const void *h_in, i
                              void *h_out, int out_stride, int out_io_base, int nframes,
                              int fir_impl, int biquad_impl);
 
+/* Host sample formats of linux/avdsp_plugin.c:103-121 in front of a block: packed little-endian PCM,
+ * frame-interleaved, unpacked on the device to the 32-bit s.31 words the int-sample formats (2, 3, 4) load:
+ * S32 as is, S24_3LE bytes b0 b1 b2 -> b0<<8 | b1<<16 | b2<<24, S16 -> sample << 16.                    */
+enum { AVDSP_PCM_S32 = 0, AVDSP_PCM_S24_3LE = 1, AVDSP_PCM_S16 = 2 };
+int avdsp_hip_unpack_pcm(avdsp_hip_prog *prog, int pcm, const void *d_src, void *d_dst, size_t nsamples, void *stream);
+/* host buffers: src packed PCM [nframes][in_stride], dst int32 [nframes][out_stride] */
+int avdsp_hip_run_block_pcm_host(avdsp_hip_prog *prog, int plan, int pcm, const void *h_src, int in_stride, int in_io_base,
+                                 void *h_out, int out_stride, int out_io_base, int nframes,
+                                 int fir_impl, int biquad_impl);
+
 /* Per-kernel timing: when enabled, every kernel launch of run_block is bracketed by a HIP event pair
  * recorded on the launch stream; profile_read waits for the recorded pairs of one kind, returns
  * the summed duration and the number of launches, and forgets them.                              */
-enum { AVDSP_KERNEL_BIQUAD = 0, AVDSP_KERNEL_FIR = 1, AVDSP_KERNEL_PASS = 2, AVDSP_KERNEL_GENERIC = 3 };
+enum { AVDSP_KERNEL_BIQUAD = 0, AVDSP_KERNEL_FIR = 1, AVDSP_KERNEL_PASS = 2, AVDSP_KERNEL_GENERIC = 3, AVDSP_KERNEL_UNPACK = 4 };
 int avdsp_hip_profile_enable(avdsp_hip_prog *prog, int on);
 int avdsp_hip_profile_read(avdsp_hip_prog *prog, int kind, double *total_ms, int *launches);
 

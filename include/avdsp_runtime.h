@@ -96,6 +96,15 @@ int dspRuntimeBlockDevice(int format, opcode_t *core, int *rundata,
                           const void *d_in, int in_stride, int in_io_base,
                           void *d_out, int out_stride, int out_io_base, int nframes, void *stream);
 
+/* The host's sample-format step (linux/avdsp_plugin.c:103-121): `src` holds packed little-endian PCM,
+ * frame-interleaved [nframes][in_stride]; pcm = AVDSP_PCM_S32 | AVDSP_PCM_S24_3LE | AVDSP_PCM_S16
+ * (include/avdsp_hip.h).  The unpacking to s.31 words happens on the device; output is S32 like the
+ * plugin's.  format = 2, 3 or 4 (the int-sample models).  dspRuntimeUnpackPcmDevice is the same
+ * conversion alone, for producers whose PCM already sits in HBM (d_dst 16-byte aligned).          */
+int dspRuntimeBlockPcm(int format, opcode_t *core, int *rundata, int pcm, const void *src, int in_stride, int in_io_base,
+                       int *dst, int out_stride, int out_io_base, int nframes);
+int dspRuntimeUnpackPcmDevice(int pcm, const void *d_src, int *d_dst, long long nsamples, void *stream);
+
 /* device state -> rundata (the buffer stays the checkpoint) / rundata -> device state (restore).
  * Sync also brings back the program words (DSP_STORE_MEM writes into the program's parameter
  * section, dsp_runtime.c:755-760).  A host that edits parameters in the program words afterwards
@@ -109,7 +118,7 @@ int dspRuntimeSetOption(const char *key, int value);
 int dspRuntimeGetOption(const char *key);
 
 /* Kernel timing with HIP events on the launch stream: enable with dspRuntimeSetOption("profile", 1);
- * kind 0 = biquad cascade, 1 = FIR, 2 = pass-through, 3 = general interpreter.  Returns the summed duration (ms) and launch
+ * kind 0 = biquad cascade, 1 = FIR, 2 = pass-through, 3 = general interpreter, 4 = PCM unpack.  Returns the summed duration (ms) and launch
  * count of the launches recorded since the previous read.                                        */
 int dspRuntimeKernelTime(int kind, double *total_ms, int *launches);
 

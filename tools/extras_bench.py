@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Side measurements for DESIGN.md (not the bench.py metric): the PCM unpack kernel against the HBM
+roofline, and the general interpreter's frame rate on the reference's committed programs.
+Run on the GPU box:  python tools/extras_bench.py"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from avdsp_amd import progbuilder as pb      # noqa: E402
+from avdsp_amd import runtime as rt          # noqa: E402
+
+HBM_GBS = 8000.0
+
+
+def unpack():
+    r = rt.Runtime(2, pb.synth_program(2, 2, 1))
+    r.run_block(np.zeros((1, 2), dtype=np.int32), 2, 2)
+    r.set_option("profile", 1)
+    for name, pcm, width in (("S16", rt.PCM_S16, 2), ("S24_3LE", rt.PCM_S24_3LE, 3)):
+        for n in (4096 * 1024, 64 * 1024 * 1024):
+            src = torch.randint(0, 255, (n * width,), dtype=torch.uint8, device="cuda")
+            dst = torch.empty(n, dtype=torch.int32, device="cuda")
+            for _ in range(3):
+                r.L.dspRuntimeUnpackPcmDevice(pcm, src.data_ptr(), dst.data_ptr(), n, None)
+            torch.cuda.synchronize()
+            r.kernel_time(4)
+            reps = 20
+            for _ in range(reps):
+                r.L.dspRuntimeUnpackPcmDevice(pcm, src.data_ptr(), dst.data_ptr(), n, None)
+            torch.cuda.synchronize()
+            ms, k = r.kernel_time(4)
+            us = ms * 1e3 / k
+            gbs = n * (width + 4) / (us * 1e-6) / 1e9
+            print(f"unpack {name:8s} {n:>9d} samples: {us:8.1f} us/launch  {gbs:7.0f} GB/s  frac {gbs / HBM_GBS:.3f}")
+    r.L.dspRuntimeRelease()
+
+
+def interpreter():
+    gold = os.path.join(ROOT, "tests", "golden")
+    for name, fmt, frames in (("crossoverLV6.bin", 2, 48000), ("dacdiy1.bin", 2, 48000), ("tour_float.bin", 6, 48000),
+                              ("tour_float.bin", 3, 48000)):
+        prog = np.fromfile(os.path.join(gold, name), dtype=np.uint32)
+        tour = name.startswith("tour")
+        r = rt.Runtime(fmt, prog, fs=48000, random=1, dither=24)
+        x = pb.lcg_input(frames, 16, fmt in (5, 6), seed=5)
+        in_base, out_stride = (32, 32) if tour else (8, 32)
+        r.run_block(x[:64], out_stride, in_base)                         # plans, staging buffers
+        r.set_option("profile", 1)
+        r.kernel_time(3)
+        t0 = time.perf_counter()
+        r.run_block(x, out_stride, in_base)
+        wall = time.perf_counter() - t0
+        ms, k = r.kernel_time(3)
+        print(f"interp {name:18s} fmt {fmt}: {len(r.cores)} cores, {frames} frames: kernels {ms:8.2f} ms "
+              f"({ms * 1e3 / frames:6.2f} us/frame, {frames / (ms * 1e-3) / 48000:6.1f}x real time at 48 kHz), wall {wall * 1e3:.1f} ms")
+        r.L.dspRuntimeRelease()
+
+
+if __name__ == "__main__":
+    unpack()
+    interpreter()
