@@ -17,7 +17,7 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libavdsp_mi355x.so")
+LIB_PATH = os.environ.get("AVDSP_LIB") or os.path.join(HERE, "lib", "libavdsp_mi355x.so")
 CSRC = os.path.join(HERE, "csrc")
 
 EXPORTED = [
