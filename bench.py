@@ -189,16 +189,23 @@ def main():
         cpu = cpu_baseline(fmt, S, T, B)
     if not torch.cuda.is_available():
         sys.exit("bench.py: no GPU visible; the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # one rank per GPU on a real node; AVDSP_DIST_BACKEND=gloo lets several ranks rehearse the N > 1 path on
+    # one card (RCCL refuses two ranks on the same device)
+    backend = os.environ.get("AVDSP_DIST_BACKEND", "nccl")
+    device_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend=backend)
     # weak scaling: the job is C*world channels, this rank owns the contiguous slice [rank*C, (rank+1)*C)
     prog, ch_lo, ch_hi = sh.shard_program(fmt, C * world, S, T, world, rank)
     assert ch_hi - ch_lo == C
     r = rt.Runtime(fmt, prog)
     if r.rc < 0:
         sys.exit(f"dspRuntimeInit failed: {r.rc} {r.last_error()}")
-    r.set_option("device", local_rank)
+    r.set_option("device", device_index)
     r.set_option("fir_impl", args.fir_impl)
     r.set_option("biquad_impl", args.biquad_impl)
     r.set_option("profile", 1)
@@ -226,7 +233,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

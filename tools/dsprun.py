@@ -18,11 +18,9 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from avdsp_amd import runtime as rt      # noqa: E402
 
-IN_OFFSET, OUT_OFFSET, IO_MAX = 8, 0, 16       # dsprun.c:17-19
-
-
 def io_maps(r):
-    """usedInputs / usedOutputs of every DSP_CORE (dsprun.c:103-131)."""
+    """usedInputs / usedOutputs of every DSP_CORE (dsprun.c:103-131, with all 32 mask bits instead of 16):
+    returns (first input IO, input channels, first output IO, output channels)."""
     ins, outs = 0, 0
     base = r.buf.ctypes.data
     k = 1
@@ -33,9 +31,9 @@ def io_maps(r):
         at = (p - base) // 4
         ins |= int(r.buf[at + 1]); outs |= int(r.buf[at + 2])
         k += 1
-    nin = max([ch - IN_OFFSET + 1 for ch in range(IO_MAX) if ins >> ch & 1] + [0])
-    nout = max([ch - OUT_OFFSET + 1 for ch in range(IO_MAX) if outs >> ch & 1] + [0])
-    return nin, nout
+    i = [ch for ch in range(32) if ins >> ch & 1] or [0]
+    o = [ch for ch in range(32) if outs >> ch & 1] or [0]
+    return i[0], i[-1] - i[0] + 1, o[0], o[-1] - o[0] + 1
 
 
 def main():
@@ -58,8 +56,8 @@ def main():
     r = rt.Runtime(a.format, prog, fs=a.fs, random=0, dither=a.dither)
     if r.rc < 0:
         sys.exit(f"dspRuntimeInit: {r.rc} ({r.last_error()})")
-    nin, nout = io_maps(r)
-    nin = max(a.channels or nin, 1); nout = max(nout, 1)
+    in_base, nin, out_base, nout = io_maps(r)
+    nin = a.channels or nin
     pcm = {"s32": rt.PCM_S32, "s24_3le": rt.PCM_S24_3LE, "s16": rt.PCM_S16}[a.pcm]
     width = {rt.PCM_S32: 4, rt.PCM_S24_3LE: 3, rt.PCM_S16: 2}[pcm]
     if a.raw:
@@ -80,14 +78,15 @@ def main():
     if a.frames:
         frames = min(frames, a.frames)
     out = r.run_block_pcm(pcm, raw[:frames * nin * {rt.PCM_S32: 4, rt.PCM_S24_3LE: 3, rt.PCM_S16: 2}[pcm]], frames, nin, nout,
-                          IN_OFFSET, OUT_OFFSET, block=a.block)
+                          in_base, out_base, block=a.block)
     if a.out.endswith(".wav"):
         with wave.open(a.out, "wb") as w:
             w.setnchannels(nout); w.setsampwidth(4); w.setframerate(a.fs)
             w.writeframes(out.astype("<i4").tobytes())
     else:
         out.astype("<i4").tofile(a.out)
-    print(f"{len(r.cores)} core(s), {nin} in / {nout} out, {frames} frames at {a.fs} Hz -> {a.out}")
+    print(f"{len(r.cores)} core(s), inputs IO {in_base}..{in_base + nin - 1}, outputs IO {out_base}..{out_base + nout - 1}, "
+          f"{frames} frames at {a.fs} Hz -> {a.out}")
 
 
 if __name__ == "__main__":
