@@ -107,8 +107,9 @@ __device__ __forceinline__ double saturate_double_0db(double d)
     return d;
 }
 
-/* dsp_ieee754.h:85-107: truncate toward zero to s.31, |d| >= 1 -> +/-0x7FFFFFFF.  The reference is
- * undefined for |d| < 2^-42 (shift count >= 64); 0 is produced there, as in the oracle.        */
+/* dsp_ieee754.h:85-107: truncate toward zero to s.31, |d| >= 1 -> +/-0x7FFFFFFF.  For |d| < 2^-42 the
+ * reference shifts by >= 64 (undefined in C); its x86-64 binaries take the count modulo 64 and so
+ * do the golden vectors, the oracle and this function.                                          */
 __device__ __forceinline__ int s31_from_double(double d)
 {
     long long u = __double_as_longlong(d);
@@ -116,7 +117,7 @@ __device__ __forceinline__ int s31_from_double(double d)
     if (e == 0) return 0;
     long long m = (u & 0xFFFFFFFFFFFFFll) | (1ll << 52);
     int n = 1044 - e;
-    if (n > 21) m = n < 64 ? (m >> n) : 0;
+    if (n > 21) m >>= (n & 63);
     else m = 0x7FFFFFFF;
     if (u < 0) m = -m;
     return (int)m;

@@ -111,14 +111,17 @@ int oracle_s31_from_float(float f)
     if (e == 0) return 0;
     uint32_t m = ((u & 0x7FFFFFu) | 0x800000u) << 8;
     int n = 127 - e;
-    if (n > 0) m = (n < 32) ? (m >> n) : 0;      /* reference: shift count >= 32 is undefined */
+    /* |f| < 2^-32: the reference shifts a 32-bit value by >= 32, undefined in C; its binaries on x86-64
+     * (and AArch64) take the count modulo 32, which is what the golden vectors contain */
+    if (n > 0) m >>= (n & 31);
     else m = 0x7FFFFFFFu;
     if (u & 0x80000000u) m = 0u - m;
     return (int)m;
 }
 
 /* dsp_ieee754.h:85-107 -- truncation toward zero; |d| >= 1 gives +/-0x7FFFFFFF; exponent 0 gives 0.
- * For |d| < 2^-42 the reference shifts a 64-bit value by >= 64 (undefined); 0 is returned here. */
+ * For |d| < 2^-42 the reference shifts a 64-bit value by >= 64: undefined in C, count modulo 64 in its
+ * x86-64 / AArch64 binaries, and therefore here. */
 int oracle_s31_from_double(double d)
 {
     uint64_t u = f64_bits(d);
@@ -126,7 +129,7 @@ int oracle_s31_from_double(double d)
     if (e == 0) return 0;
     int64_t m = (int64_t)((u & ((1ull << 52) - 1)) | (1ull << 52));
     int n = 1044 - e;
-    if (n > 21) m = (n < 64) ? (m >> n) : 0;
+    if (n > 21) m >>= (n & 63);
     else m = 0x7FFFFFFF;
     if ((int64_t)u < 0) m = -m;
     return (int)m;

@@ -34,6 +34,7 @@ REF = os.environ.get("AVDSP_REFERENCE", "/root/reference") + "/module_avdsp"
 REFBIN = po.REF_DIR
 
 
+FUZZ_SEEDS = 12
 ENC_SWEEP_VARIANTS = [(2, 4, 9), (6, 4, 7), (6, 0, 13), (2, 5, 5)]     # (encoding, freqMin index, freqMax index)
 
 
@@ -106,6 +107,21 @@ def main():
                 run_case(f"{fname[:-4]}_f{fmt}_fs{fs}_b{block}", fmt, dict(kind="file", name=fname),
                          lcg(1200, 16, seed=77), 32, 32, 0, fs=fs, random=12345, dither=24, block=block,
                          scratch=48, full=full, manifest=manifest)
+
+    # ---- random well-formed programs (tests/fuzz_programs.py), all five models: several cores, X/Y
+    #      arithmetic, filters, delay lines, meters, dither ... in random order.  Before the fixtures are
+    #      written the same programs are encoded with the REFERENCE encoder as well and must come out
+    #      byte-identical (the generator itself drives this repository's encoder).
+    print("random programs")
+    from tests.fuzz_programs import random_program, N_IN, IN_BASE, N_OUT
+    ref_encoder = os.path.join(REFBIN, "libavdspencoder.so")
+    for seed in range(FUZZ_SEEDS):
+        for fmt in (2, 3, 4, 5, 6):
+            mine, theirs = random_program(seed, fmt), random_program(seed, fmt, ref_encoder)
+            assert len(mine) == len(theirs) and (mine == theirs).all(), ("encoder mismatch", seed, fmt)
+            run_case(f"fuzz_s{seed}_f{fmt}", fmt, dict(kind="fuzz", seed=seed, fmt=fmt), lcg(700, N_IN, seed=seed + 5),
+                     N_OUT, IN_BASE, 0, fs=[48000, 48000, 96000][seed % 3], random=seed * 7 + 1, dither=24,
+                     block=[1, 64, 700][seed % 3], scratch=48, full=seed < 2, manifest=manifest)
 
     # ---- encoder workout (oracle/enc_sweep.c) through the reference encoder: byte fixtures for
     #      avdsp_amd/csrc/avdsp_encoder.c (tests/test_encoder.py) ----

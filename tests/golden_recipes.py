@@ -24,6 +24,9 @@ def make_program(recipe: dict) -> np.ndarray:
         return pb.synth_program(recipe["fmt"], recipe["channels"], recipe["sections"],
                                 recipe.get("taps", 0), recipe.get("fmin", pb.F48000),
                                 recipe.get("fmax", pb.F48000), recipe.get("gain", 1.0))
+    if kind == "fuzz":                 # random well-formed program, see tests/fuzz_programs.py
+        from tests.fuzz_programs import random_program
+        return random_program(recipe["seed"], recipe["fmt"])
     raise ValueError(kind)
 
 

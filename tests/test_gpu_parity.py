@@ -28,9 +28,10 @@ with open(os.path.join(GOLDEN_DIR, "manifest.json")) as _f:
 
 DEVICE_CASES = [c for c in MANIFEST["cases"] if c["fmt"] in (2, 4, 6) and c["program"]["kind"] == "synth"]
 # the general device interpreter: every committed / reference-encoded program (none of them is a pure
-# set of chains), and the synthetic chain programs forced through it (formats 3 and 5 have no other path);
+# set of chains), the random programs of tests/fuzz_programs.py in all five arithmetic models, and the
+# synthetic chain programs forced through it (formats 3 and 5 have no other path);
 # the long-FIR cases would take minutes on one lane
-GENERAL_CASES = [c for c in MANIFEST["cases"] if c["program"]["kind"] == "file" or
+GENERAL_CASES = [c for c in MANIFEST["cases"] if c["program"]["kind"] in ("file", "fuzz") or
                  (c["nframes"] * max(c["program"].get("taps", 0), 1) * c["program"].get("channels", 1) <= 2_000_000)]
 
 

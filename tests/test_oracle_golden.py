@@ -73,9 +73,9 @@ def test_kernel_vectors():
     got = np.array([L.oracle_int_to_double_scaled(int(v), 31) for v in iv])
     assert (got.view(np.uint64) == k["int_to_double_scaled"].view(np.uint64)).all()
     dv = k["dv"]
-    defined = (np.abs(dv) >= 2.0 ** -42) | (dv == 0)       # below that the reference shifts by >= 64 bits (UB)
+    # |v| < 2^-42 shifts by >= 64 bits in the reference: undefined in C, count modulo 64 in its binaries and here
     got = np.array([L.oracle_s31_from_double(float(v)) for v in dv], dtype=np.int32)
-    assert (got[defined] == k["s31_from_double"][defined]).all()
+    assert (got == k["s31_from_double"]).all()
     got = np.array([L.oracle_saturate_double(float(v)) for v in dv])
     assert (got.view(np.uint64) == k["saturate_double"].view(np.uint64)).all()
     got = np.array([L.oracle_truncate_double(float(v), 24) for v in dv])
