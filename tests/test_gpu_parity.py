@@ -231,6 +231,31 @@ def test_golden_general_interpreter(case):
         r.set_option("generic", 0)
 
 
+@pytest.mark.parametrize("seed", range(12, 72))
+def test_random_programs_vs_oracle(seed):
+    """More random programs than there are goldens: the interpreter against the oracle (itself held to the
+    compiled reference on these generators, tests/golden/make_goldens.py and 800+ runs while developing),
+    all five arithmetic models, outputs and the whole buffer (state, STORE_MEM targets) bit for bit."""
+    from tests.fuzz_programs import IN_BASE, N_IN, N_OUT, random_program
+    for fmt in (2, 3, 4, 5, 6):
+        prog = random_program(seed, fmt)
+        fs, block = [48000, 48000, 96000][seed % 3], [1, 64, 500][seed % 3]
+        x = pb.lcg_input(500, N_IN, fmt in (5, 6), seed=seed)
+        o = po.OracleProgram(fmt, prog, fs=fs, random=seed, dither=24)
+        r = rt.Runtime(fmt, prog, fs=fs, random=seed, dither=24)
+        assert r.rc == o.rc
+        if r.rc < 0:
+            continue
+        want = o.run_block(x, N_OUT, IN_BASE, 0, scratch_len=48, block=block)
+        got = r.run_block(x, N_OUT, IN_BASE, 0, block=block)
+        bad = np.nonzero((got.view(np.uint32) != want.view(np.uint32)).any(axis=0))[0]
+        assert bad.size == 0, f"seed {seed} DSP_FORMAT {fmt}: output columns {list(bad)} differ"
+        r.sync_state()
+        n = int(prog[1]) + int(prog[2])
+        assert (r.buf[12:n] == o.buf[12:n]).all(), f"seed {seed} DSP_FORMAT {fmt}: buffer differs after the run"
+        r.release()
+
+
 def test_general_interpreter_single_frame_and_store_mem():
     """dspRuntime_N on a non-chain program: samples[] in place, frame by frame, equals the block call;
     DSP_STORE_MEM results come back into the program words with dspRuntimeSyncState."""
