@@ -77,6 +77,19 @@ __device__ __forceinline__ float flush_f32(float v)
 }
 __device__ __forceinline__ double mulop(float v) { return (double)flush_f32(v); }
 
+/* The reference runs with MXCSR.FTZ and MXCSR.DAZ set (it is built -Ofast; loading it switches the thread):
+ * a double -> float conversion that lands in the subnormal range gives signed zero, a float -> double
+ * conversion reads a subnormal as signed zero.  Every (float)acc of the cascade, the FIR input, the
+ * float store and the float sample load go through here; a filter decaying into silence ends in
+ * exact zeros the way the reference's does (oracle: ORC_FTZ_DAZ_ON, avdsp_oracle.c).                */
+__device__ __forceinline__ float ftz_f32(float v)
+{
+    const unsigned u = __float_as_uint(v);
+    return (u & 0x7F800000u) ? v : __uint_as_float(u & 0x80000000u);
+}
+__device__ __forceinline__ float  narrow_f32(double d) { return ftz_f32((float)d); }
+__device__ __forceinline__ double widen_f32(float v)   { return (double)ftz_f32(v); }
+
 /* dsp_ieee754.h:204-250: int -> float, magnitude TRUNCATED to 24 bits, times 2^-31.  INT_MIN leaves
  * the reference's 7-step normaliser one step short: mantissa 0, exponent 126, i.e. -0.5.       */
 __device__ __forceinline__ float int_to_float_scaled31(int x)
@@ -148,8 +161,8 @@ __device__ __forceinline__ typename Alu<FMT>::type load_stage(unsigned raw, int 
             return mulop(int_to_float_scaled31((int)raw)) * mulop(__uint_as_float(gain_bits));
         return int_to_double_scaled31((int)raw);                                      /* :575 */
     } else {
-        double x = (double)__uint_as_float(raw);                                      /* :580, :603-604 */
-        return mode == AVDSP_LOAD_GAIN ? x * (double)__uint_as_float(gain_bits) : x;
+        double x = widen_f32(__uint_as_float(raw));                                   /* :580, :603-604 */
+        return mode == AVDSP_LOAD_GAIN ? x * widen_f32(__uint_as_float(gain_bits)) : x;
     }
 }
 
@@ -158,7 +171,7 @@ template <int FMT>
 __device__ __forceinline__ unsigned narrow_stage(typename Alu<FMT>::type X)
 {
     if constexpr (FMT == 2) return (unsigned)(int)(X >> 28);                          /* dspShiftInt, :831 */
-    else return __float_as_uint((float)X);
+    else return __float_as_uint(narrow_f32(X));
 }
 
 /* [DSP_SAT0DB] + DSP_STORE -> raw 32-bit sample word */
@@ -171,7 +184,7 @@ __device__ __forceinline__ unsigned store_stage(typename Alu<FMT>::type X, int s
     } else {
         if (sat) X = saturate_double_0db(X);
         if constexpr (FMT == 4) return (unsigned)(s31_from_double(X) & mask);         /* :622-627 */
-        else return __float_as_uint((float)X);                                        /* :629-630 */
+        else return __float_as_uint(narrow_f32(X));                                   /* :629-630 */
     }
 }
 
@@ -264,7 +277,7 @@ __device__ __forceinline__ Hand<FMT> hand_from_sample(unsigned raw, const avdsp_
     Hand<FMT> h;
     h.y = narrow_stage<FMT>(load_stage<FMT>(raw, c.load_mode, c.gain_bits));
     if constexpr (FMT != 2) {
-        const unsigned long long d = (unsigned long long)__double_as_longlong(mulop(__uint_as_float(h.y)));
+        const unsigned long long d = (unsigned long long)__double_as_longlong((double)__uint_as_float(h.y));   /* h.y is flushed already */
         h.lo = (unsigned)d; h.hi = (unsigned)(d >> 32);
     }
     return h;
@@ -396,9 +409,9 @@ __global__ __launch_bounds__(kBlock) void biquad_pipe(const BiquadArgs a)
                 acc = __builtin_fma(dx2, cd[2], acc);
                 acc = __builtin_fma(dy1, cd[3], acc);
                 acc = __builtin_fma(dy2, cd[4], acc);
-                const float yn = (float)acc;
+                const float yn = narrow_f32(acc);
                 x2 = x1; x1 = xin.y; y2 = y1; y1 = __float_as_uint(yn);
-                dx2 = dx1; dx1 = dxin; dy2 = dy1; dy1 = mulop(yn);
+                dx2 = dx1; dx1 = dxin; dy2 = dy1; dy1 = (double)yn;      /* yn is already flushed: +-0.0 adds nothing, like mulop's +0.0 */
                 const unsigned long long dd = (unsigned long long)__double_as_longlong(dy1);
                 hy.y = y1; hy.lo = (unsigned)dd; hy.hi = (unsigned)(dd >> 32);
             }
@@ -496,7 +509,7 @@ __global__ __launch_bounds__(64) void biquad_simple(const BiquadArgs a)
                 acc = __builtin_fma(mulop(__uint_as_float(y1)), mulop(__int_as_float(co[3])), acc);
                 acc = __builtin_fma(mulop(__uint_as_float(y2)), mulop(__int_as_float(co[4])), acc);
                 X = acc; keep = (unsigned long long)__double_as_longlong(acc);
-                yn = __float_as_uint((float)acc);
+                yn = __float_as_uint(narrow_f32(acc));
             }
             st[0] = (int)(unsigned)keep; st[1] = (int)(unsigned)(keep >> 32);
             st[2] = (int)xin; st[3] = (int)x1; st[4] = (int)yn; st[5] = (int)y1;

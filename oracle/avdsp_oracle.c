@@ -72,6 +72,18 @@ float oracle_mul_float_float(float a, float b)
     return f32_from(hi);
 }
 
+/* acc += a*b for a float accumulator (dspMaccFloatFloat, dsp_ieee754.h:412-417).  When the product takes
+ * one of dspMulFloatFloat's "return 0.0" exits, the reference's build does not add at all (-Ofast implies
+ * -fno-signed-zeros, x + 0.0 is x): an accumulator holding -0.0 -- a flushed negative underflow -- stays
+ * -0.0 where an IEEE addition of +0.0 would turn it into +0.0. */
+static inline float macc_float_float(float acc, float a, float b)
+{
+    uint32_t ua = f32_bits(a), ub = f32_bits(b);
+    int ea = (ua >> 23) & 255, eb = (ub >> 23) & 255;
+    if (ea == 0 || eb == 0 || ea + eb - 127 < 1) return acc;
+    return acc + oracle_mul_float_float(a, b);
+}
+
 /* dsp_ieee754.h:204-250 -- int -> float with the magnitude truncated to 24 bits, scaled by
  * 2^-shift.  INT_MIN takes the reference's 7-step normalisation one step short and comes out
  * as mantissa 0 with exponent 157-shift (i.e. -0.5 for shift 31).                            */
@@ -284,11 +296,11 @@ static float biquads_float(float xn, const float *coef, float *state, int num, i
         coef += skip;
         acc = state[0];
         float x1 = state[2], x2 = state[3], y1 = state[4], y2 = state[5];
-        acc += oracle_mul_float_float(xn, b0);
-        acc += oracle_mul_float_float(x1, b1);
-        acc += oracle_mul_float_float(x2, b2);
-        acc += oracle_mul_float_float(y1, a1);
-        acc += oracle_mul_float_float(y2, a2);
+        acc = macc_float_float(acc, xn, b0);
+        acc = macc_float_float(acc, x1, b1);
+        acc = macc_float_float(acc, x2, b2);
+        acc = macc_float_float(acc, y1, a1);
+        acc = macc_float_float(acc, y2, a2);
         state[0] = acc;
         state[2] = xn; state[3] = x1; state[5] = y1;
         state[4] = acc;
@@ -317,7 +329,7 @@ static float fir_float(float xn, const float *coef, float *state, int num)
     for (int i = 0; i < num; i++) {
         float prev = state[i];
         state[i] = xn;
-        acc += oracle_mul_float_float(xn, coef[i]);
+        acc = macc_float_float(acc, xn, coef[i]);
         xn = prev;
     }
     return acc;
@@ -583,16 +595,33 @@ int oracle_init(oracle_ctx *c, opcode_t *code, int maxSize, int fs, int random, 
 #include "oracle_interp.inc"
 #undef ORC_FMT
 
+/* The reference is built -Ofast (CMakeLists.txt:7, runtime/Makefile:13): its shared object carries gcc's
+ * crtfastmath start-up code, which sets MXCSR.FTZ and MXCSR.DAZ in the thread that loads it.  Every SSE
+ * arithmetic or conversion instruction of the runtime therefore reads subnormal operands as signed zero and
+ * flushes subnormal results to signed zero -- the tail of every decaying filter goes through that.  The
+ * oracle is compiled without fast-math and runs its frames under the same two MXCSR bits instead. */
+#if defined(__x86_64__) || defined(__i386__)
+  #include <xmmintrin.h>
+  #define ORC_FTZ_DAZ_ON(saved)  do { (saved) = _mm_getcsr(); _mm_setcsr((saved) | 0x8040u); } while (0)
+  #define ORC_FTZ_DAZ_OFF(saved) _mm_setcsr(saved)
+#else
+  #error "the oracle mirrors the x86 MXCSR flush modes of the reference build; port ORC_FTZ_DAZ_* for this host"
+#endif
+
 int oracle_run(oracle_ctx *c, opcode_t *core, int *rundata, void *samples)
 {
+    unsigned saved;
+    int rc = -1;
+    ORC_FTZ_DAZ_ON(saved);
     switch (c->format) {
-    case 2: return run_frame_2(c, core, rundata, (int *)samples);
-    case 3: return run_frame_3(c, core, rundata, (int *)samples);
-    case 4: return run_frame_4(c, core, rundata, (int *)samples);
-    case 5: return run_frame_5(c, core, rundata, (float *)samples);
-    case 6: return run_frame_6(c, core, rundata, (float *)samples);
+    case 2: rc = run_frame_2(c, core, rundata, (int *)samples); break;
+    case 3: rc = run_frame_3(c, core, rundata, (int *)samples); break;
+    case 4: rc = run_frame_4(c, core, rundata, (int *)samples); break;
+    case 5: rc = run_frame_5(c, core, rundata, (float *)samples); break;
+    case 6: rc = run_frame_6(c, core, rundata, (float *)samples); break;
     }
-    return -1;
+    ORC_FTZ_DAZ_OFF(saved);
+    return rc;
 }
 
 int oracle_run_block(oracle_ctx *c, opcode_t *core, int *rundata,

@@ -114,11 +114,17 @@ def main():
     #      byte-identical (the generator itself drives this repository's encoder).
     print("random programs")
     from tests.fuzz_programs import random_program, N_IN, IN_BASE, N_OUT
-    ref_encoder = os.path.join(REFBIN, "libavdspencoder.so")
+    # (in a child process: the reference library is built -Ofast, and merely loading it switches the loading
+    # thread to flush-to-zero arithmetic, which would corrupt the subnormal test inputs made further down)
+    check = ("import sys; sys.path.insert(0, %r); from tests.fuzz_programs import random_program\n"
+             "for seed in range(%d):\n"
+             "    for fmt in (2, 6):\n"
+             "        a, b = random_program(seed, fmt), random_program(seed, fmt, %r)\n"
+             "        assert len(a) == len(b) and (a == b).all(), ('encoder mismatch', seed, fmt)\n"
+             % (ROOT, FUZZ_SEEDS, os.path.join(REFBIN, "libavdspencoder.so")))
+    subprocess.check_call([sys.executable, "-c", check])
     for seed in range(FUZZ_SEEDS):
         for fmt in (2, 3, 4, 5, 6):
-            mine, theirs = random_program(seed, fmt), random_program(seed, fmt, ref_encoder)
-            assert len(mine) == len(theirs) and (mine == theirs).all(), ("encoder mismatch", seed, fmt)
             run_case(f"fuzz_s{seed}_f{fmt}", fmt, dict(kind="fuzz", seed=seed, fmt=fmt), lcg(700, N_IN, seed=seed + 5),
                      N_OUT, IN_BASE, 0, fs=[48000, 48000, 96000][seed % 3], random=seed * 7 + 1, dither=24,
                      block=[1, 64, 700][seed % 3], scratch=48, full=seed < 2, manifest=manifest)
@@ -129,6 +135,22 @@ def main():
     for fmt, fmin, fmax in ENC_SWEEP_VARIANTS:
         subprocess.check_call([os.path.join(REFBIN, "enc_sweep"), str(fmt), str(fmin), str(fmax),
                                os.path.join(OUT, f"enc_sweep_{fmt}_{fmin}_{fmax}.bin")], stdout=subprocess.DEVNULL)
+
+    # ---- the subnormal range: the reference is built -Ofast and runs with MXCSR.FTZ/DAZ.  An impulse
+    #      followed by a long silence lets every section decay through the smallest normal numbers into
+    #      flushed, signed zeros; "denormals" feeds subnormal samples directly. ----
+    print("decay into silence / subnormal inputs")
+    for fmt in (2, 3, 4, 5, 6):
+        enc_fmt = 2 if fmt == 2 else 6
+        run_case(f"decay_c2_s3_f{fmt}", fmt, synth(enc_fmt, 2, 3), dict(kind="impulse", frames=40000, channels=2, value_f=0.5, value_i=1 << 30),
+                 2, 2, block=4000, full=False, manifest=manifest)
+        run_case(f"denormals_c2_s2_f{fmt}", fmt, synth(enc_fmt, 2, 2), dict(kind="denormals", frames=96, channels=2),
+                 2, 2, block=96, manifest=manifest)
+        if fmt != 2:
+            run_case(f"decay_fir_c2_s2_t33_f{fmt}", fmt, synth(6, 2, 2, 33), dict(kind="impulse", frames=3000, channels=2, value_f=-0.5, value_i=-(1 << 30)),
+                     2, 2, block=1000, manifest=manifest)
+            run_case(f"denormals_fir_c2_s1_t9_f{fmt}", fmt, synth(6, 2, 1, 9), dict(kind="denormals", frames=96, channels=2),
+                     2, 2, block=96, manifest=manifest)
 
     # ---- reference-encoder byte identity for progbuilder.py ----
     print("reference encoder programs")

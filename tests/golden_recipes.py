@@ -40,6 +40,13 @@ def make_input(recipe: dict, fmt: int) -> np.ndarray:
         t = np.arange(frames * ch).reshape(frames, ch)
         sq = np.sign(np.sin(t * 0.37))
         return (sq * 0.999).astype(np.float32) if fl else (sq * 2147483000).astype(np.int32)
+    if kind == "denormals":            # subnormal / barely-normal samples, both signs: the FTZ/DAZ corner of the reference's build
+        x = np.zeros((frames, ch), dtype=np.float32 if fl else np.int32)
+        vals_f = [1e-40, 3e-39, 1.5e-38, -2e-41, 1e-37, -1.2e-38, 5e-45, -1e-30]
+        vals_i = [1, -3, 100, -1, 7, -100, 2, -2]
+        for k in range(min(frames, 24)):
+            x[k, k % ch] = vals_f[k % 8] if fl else vals_i[k % 8]
+        return x
     if kind == "impulse":
         x = np.zeros((frames, ch), dtype=np.float32 if fl else np.int32)
         x[0, :] = recipe["value_f"] if fl else recipe["value_i"]
