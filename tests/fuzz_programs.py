@@ -200,3 +200,35 @@ def random_program(seed: int, fmt: int, encoder_path: str | None = None) -> np.n
         _Builder(lib, rng, 2 if fmt == 2 else 6, fmin, fmax).build()
 
     return enc.encode(build, 2 if fmt == 2 else 6, fmin, fmax, max_io=48, capacity=1 << 15, path=encoder_path)
+
+
+def stress_input(rng, n: int, ch: int, float_samples: bool) -> np.ndarray:
+    """Samples that visit the corners: exact and negative zeros, full scale, beyond full scale (float),
+    barely-normal and subnormal magnitudes, small integers."""
+    kind = rng.integers(0, 8, (n, ch))
+    if float_samples:
+        base = rng.uniform(-1, 1, (n, ch)).astype(np.float32)
+        x = np.where(kind == 0, 0.0, base)
+        x = np.where(kind == 1, base * 4.0, x)
+        x = np.where(kind == 2, base * 1e-38, x)
+        x = np.where(kind == 3, base * 1e-30, x)
+        x = np.where(kind == 4, np.sign(base) * 1.0, x)
+        x = np.where(kind == 5, -0.0, x)
+        return x.astype(np.float32)
+    base = rng.integers(-2**31, 2**31, (n, ch), dtype=np.int64)
+    x = np.where(kind == 0, 0, base)
+    x = np.where(kind == 1, base >> 20, x)
+    x = np.where(kind == 2, np.where(base > 0, 2**31 - 1, -2**31), x)
+    x = np.where(kind == 3, base >> 30, x)
+    return x.astype(np.int32)
+
+
+def random_chain_case(seed: int):
+    """(channels, sections, taps, fmin, fmax, gain, fs, frames, dither, block) of a random chain program."""
+    rng = np.random.default_rng(seed)
+    C, S, T = int(rng.integers(1, 5)), int(rng.integers(0, 6)), int(rng.choice([0, 0, 1, 2, 7, 33, 100]))
+    fmin = int(rng.integers(4, 8)); fmax = int(rng.integers(fmin, min(fmin + 3, 10)))
+    gain = float(rng.choice([0.1, 0.5, 1.0, 2.0, 7.9]))
+    fs = [8000, 16000, 24000, 32000, 44100, 48000, 88200, 96000, 176400, 192000][int(rng.integers(fmin, fmax + 1))]
+    n = int(rng.integers(50, 400)); dither = int(rng.choice([16, 24, 31]))
+    return rng, C, S, T, fmin, fmax, gain, fs, n, dither
