@@ -227,3 +227,37 @@ def test_unpack_on_device_misaligned_source():
             got = dst.cpu().numpy()
             assert (got[:x.size] == _unpack_like_the_plugin(raw, pcm)).all()
             assert (got[x.size:] == 0).all()
+
+
+# ---------------------------------------------------------------------------------------------
+# a C host linked against the library (the drop-in boundary used from C, not through ctypes)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("fmt,which", [(2, "crossoverLV6"), (6, "synth"), (4, "synth")])
+def test_c_host_links_and_matches_the_oracle(tmp_path, fmt, which):
+    """examples/host_demo.c uses the reference's API (dspRuntimeInit, dspFindCore, dspFindCoreBegin) plus
+    dspRuntimeBlock_N, selected by -DDSP_FORMAT like the reference's hosts; built with gcc, linked with
+    -lavdsp_mi355x, run as its own process."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "host_demo")
+    subprocess.check_call(["gcc", "-std=gnu99", "-Wall", f"-I{root}/include", f"-DDSP_FORMAT={fmt}",
+                           f"{root}/examples/host_demo.c", f"-L{root}/avdsp_amd/lib", "-lavdsp_mi355x",
+                           f"-Wl,-rpath,{root}/avdsp_amd/lib", "-o", exe])
+    if which == "crossoverLV6":
+        prog = np.fromfile(os.path.join(root, "tests", "golden", "crossoverLV6.bin"), dtype=np.uint32)
+        nin, in_base, nout, out_base = 8, 16, 8, 24
+    else:
+        prog = pb.synth_program(6, 3, 2, 17)
+        nin, in_base, nout, out_base = 3, 3, 3, 0
+    x = pb.lcg_input(700, nin, fmt == 6, seed=11)
+    (tmp_path / "p.bin").write_bytes(prog.tobytes())
+    (tmp_path / "in.raw").write_bytes(x.tobytes())
+    res = subprocess.run([exe, str(tmp_path / "p.bin"), "48000", str(tmp_path / "in.raw"), str(nin), str(in_base),
+                          str(tmp_path / "out.raw"), str(nout), str(out_base), "256"], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    got = np.fromfile(str(tmp_path / "out.raw"), dtype=x.dtype).reshape(700, nout)
+    o = po.OracleProgram(fmt, prog, fs=48000, random=12345, dither=24)
+    want = o.run_block(x, nout, in_base, out_base, scratch_len=40, block=256)
+    assert (got.view(np.uint32) == want.view(np.uint32)).all()
+    words = res.stdout.split("state[0..3]=")[1].split()
+    assert [int(w, 16) for w in words[:4]] == [int(v) for v in o.state[:4]]
