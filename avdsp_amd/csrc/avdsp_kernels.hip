@@ -986,7 +986,8 @@ avdsp_hip_prog *avdsp_hip_prog_create(int total_words)
 {
     auto *p = new avdsp_hip_prog();
     p->total_words = total_words;
-    hipError_t e = hipMalloc((void **)&p->d_buf, (size_t)(total_words > 0 ? total_words : 1) * sizeof(int));
+    /* + 2 words: the interpreter fetches the two words behind every head word, also behind the last one */
+    hipError_t e = hipMalloc((void **)&p->d_buf, ((size_t)(total_words > 0 ? total_words : 1) + 2) * sizeof(int));
     if (e != hipSuccess) { set_err("hipMalloc(mirror, %d words): %s", total_words, hipGetErrorString(e)); delete p; return nullptr; }
     return p;
 }
@@ -1115,15 +1116,12 @@ int avdsp_hip_prog_add_generic(avdsp_hip_prog *prog, const avdsp_generic_desc *d
         a.frame_lds = 0; a.stage_words = 0; a.batch_lds = 0;
         pl.ga_lds = (size_t)kGenericBatchLds * 4;
     }
-    static bool lds_opt_in = false;
-    if (!lds_opt_in) {
-        const void *fns[] = { (const void *)interp_core<2, true>, (const void *)interp_core<3, true>, (const void *)interp_core<4, true>,
-                              (const void *)interp_core<5, true>, (const void *)interp_core<6, true> };
-        for (const void *fn : fns) {
-            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGenericLdsMax);
-            if (e != hipSuccess) return set_err("hipFuncSetAttribute(generic LDS): %s", hipGetErrorString(e));
-        }
-        lds_opt_in = true;
+    if (pl.ga_staged) {   /* per plan creation, like the FIR: nothing in the launch path may touch function attributes */
+        const void *fn = d->format == 2 ? (const void *)interp_core<2, true> : d->format == 3 ? (const void *)interp_core<3, true>
+                       : d->format == 4 ? (const void *)interp_core<4, true> : d->format == 5 ? (const void *)interp_core<5, true>
+                                                                                              : (const void *)interp_core<6, true>;
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGenericLdsMax);
+        if (e != hipSuccess) return set_err("hipFuncSetAttribute(generic LDS): %s", hipGetErrorString(e));
     }
     prog->plans.push_back(pl);
     return (int)prog->plans.size() - 1;
