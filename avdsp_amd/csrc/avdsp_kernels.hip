@@ -69,14 +69,24 @@ constexpr int kBlock      = 256;
  * device helpers: arithmetic of the load / store stages
  * ---------------------------------------------------------------------------------------- */
 
-/* An operand whose biased exponent is 0 counts as +0 in the reference's float products
- * (dspMulFloatDouble, dsp_ieee754.h:383-386).                                               */
+/* The operand of the reference's float products (dspMulFloatDouble, dsp_ieee754.h:377-410), which are
+ * assembled from the bit fields: a biased exponent of 0 (zero, subnormal) counts as +0 (:383-386), and
+ * Inf / NaN are not recognised -- exponent 255 is read like any other, i.e. as 1.m x 2^128.        */
 __device__ __forceinline__ float flush_f32(float v)
 {
     return (__float_as_uint(v) & 0x7F800000u) ? v : 0.0f;
 }
-__device__ __forceinline__ double mulop(float v) { return (double)flush_f32(v); }
-
+__device__ __forceinline__ double widen_exp255(unsigned u)              /* 1.m x 2^128 with the sign of u */
+{
+    const unsigned hi = (u & 0x80000000u) | (1151u << 20) | ((u & 0x7FFFFFu) >> 3);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | (unsigned long long)(u << 29)));
+}
+__device__ __forceinline__ double mulop(float v)
+{
+    const unsigned u = __float_as_uint(v);
+    if ((u & 0x7F800000u) == 0x7F800000u) return widen_exp255(u);
+    return (double)flush_f32(v);
+}
 /* The reference runs with MXCSR.FTZ and MXCSR.DAZ set (it is built -Ofast; loading it switches the thread):
  * a double -> float conversion that lands in the subnormal range gives signed zero, a float -> double
  * conversion reads a subnormal as signed zero.  Every (float)acc of the cascade, the FIR input, the
@@ -277,7 +287,7 @@ __device__ __forceinline__ Hand<FMT> hand_from_sample(unsigned raw, const avdsp_
     Hand<FMT> h;
     h.y = narrow_stage<FMT>(load_stage<FMT>(raw, c.load_mode, c.gain_bits));
     if constexpr (FMT != 2) {
-        const unsigned long long d = (unsigned long long)__double_as_longlong((double)__uint_as_float(h.y));   /* h.y is flushed already */
+        const unsigned long long d = (unsigned long long)__double_as_longlong((double)__uint_as_float(h.y));   /* h.y is flushed already; Inf / NaN: see the cascade step */
         h.lo = (unsigned)d; h.hi = (unsigned)(d >> 32);
     }
     return h;
@@ -409,9 +419,15 @@ __global__ __launch_bounds__(kBlock) void biquad_pipe(const BiquadArgs a)
                 acc = __builtin_fma(dx2, cd[2], acc);
                 acc = __builtin_fma(dy1, cd[3], acc);
                 acc = __builtin_fma(dy2, cd[4], acc);
+                /* (float)acc flushed like the reference's cvtsd2ss under FTZ; its product operand is then simply
+                 * the widened value (+-0.0 adds nothing, like mulop's +0.0).  NOT mirrored here: an Inf / NaN
+                 * travelling down the cascade.  The reference's bit-field product reads exponent 255 as
+                 * 1.m x 2^128 (mulop); honouring that for every section input and output costs this kernel
+                 * 7 % (measured) for samples no audio stream contains.  biquad_impl 0, the FIR and the
+                 * general interpreter do mirror it.                                                       */
                 const float yn = narrow_f32(acc);
                 x2 = x1; x1 = xin.y; y2 = y1; y1 = __float_as_uint(yn);
-                dx2 = dx1; dx1 = dxin; dy2 = dy1; dy1 = (double)yn;      /* yn is already flushed: +-0.0 adds nothing, like mulop's +0.0 */
+                dx2 = dx1; dx1 = dxin; dy2 = dy1; dy1 = (double)yn;
                 const unsigned long long dd = (unsigned long long)__double_as_longlong(dy1);
                 hy.y = y1; hy.lo = (unsigned)dd; hy.hi = (unsigned)(dd >> 32);
             }
