@@ -165,6 +165,13 @@ int dspRuntimeReset(const int fs, int random, int defaultDither)
     G.dither = defaultDither;
     /* dsp_tpdf.h:55-59: mask = -1 << (32 - dither) */
     G.store_mask = (int)(0xFFFFFFFFu << ((32 - defaultDither) & 31));
+    /* the reference zeroes the data area only (:141): words that DSP_STORE_MEM wrote into the program's
+     * parameter sections survive a reset, so fetch them before the device copy is dropped */
+    if (G.dev && G.dev_state_valid) {
+        const int first = (int)(sizeof(dspHeader_t) / sizeof(int));
+        if (avdsp_hip_download_words(G.dev, (int32_t *)G.code, first, dspHeaderPtr->totalLength - first))
+            return fail(-10, "%s", avdsp_hip_last_error());
+    }
     int *data = (int *)dspHeaderPtr + dspHeaderPtr->totalLength;
     memset(data, 0, (size_t)dspHeaderPtr->dataSize * sizeof(int));
     /* plans embed the rate-dependent coefficient addresses and the store mask: rebuild lazily */

@@ -283,3 +283,21 @@ def test_inf_and_nan_samples_follow_the_reference_products():
         finally:
             r.set_option("generic", 0)
             r.release()
+
+
+def test_reset_keeps_store_mem_words_like_the_reference():
+    """dspRuntimeReset zeroes the data area only (dsp_runtime.c:141): what DSP_STORE_MEM wrote into the
+    program's parameter section is still there afterwards, also when the host never synced in between."""
+    prog = np.fromfile(os.path.join(os.path.dirname(__file__), "golden", "dacdiy1.bin"), dtype=np.uint32)
+    x = pb.lcg_input(64, 16, False, seed=9)
+    o = po.OracleProgram(2, prog, fs=48000, random=3, dither=24)
+    r = rt.Runtime(2, prog, fs=48000, random=3, dither=24)
+    o.run_block(x, 32, 8, 0, scratch_len=40, block=64)
+    r.run_block(x, 32, 8, 0, block=64)
+    assert o.reset(96000, 5, 24) == 0 and r.reset(96000, 5, 24) == 0
+    n = int(prog[1])
+    assert (r.buf[:n] == o.buf[:n]).all() and (r.buf[:n] != prog[:n]).any()
+    want = o.run_block(x, 32, 8, 0, scratch_len=40, block=64)
+    got = r.run_block(x, 32, 8, 0, block=64)
+    assert (got == want).all()
+    assert (r.sync_state() == o.state).all()
