@@ -759,6 +759,21 @@ int dspRuntimeSyncState(int *rundata)
     return 0;
 }
 
+/* Live parameter control: the reference reads gains, coefficients, delays ... from the program words on
+ * every frame, so a host may edit them in place between frames.  Here the words live in the device mirror
+ * and some are folded into the plans; this call carries the host's edits over without touching the state. */
+int dspRuntimeUploadParams(void)
+{
+    if (!dspHeaderPtr) return fail(-1, "no program loaded");
+    if (!G.dev) return 0;                                     /* nothing on the device yet: the next block uploads everything */
+    const int first = (int)(sizeof(dspHeader_t) / sizeof(int));
+    if (avdsp_hip_prog_clear_plans(G.dev) ||
+        avdsp_hip_upload_words(G.dev, (const int32_t *)G.code, first, dspHeaderPtr->totalLength - first))
+        return fail(-10, "%s", avdsp_hip_last_error());
+    G.nplans = 0;                                             /* cores are lowered again at their next block */
+    return 0;
+}
+
 int dspRuntimeUploadState(const int *rundata)
 {
     if (!dspHeaderPtr) return fail(-1, "no program loaded");

@@ -1203,6 +1203,16 @@ static int mirror_to_rings(avdsp_hip_prog *p)
     return 0;
 }
 
+int avdsp_hip_prog_clear_plans(avdsp_hip_prog *p)
+{
+    HIP_TRY(hipDeviceSynchronize());
+    if (rings_to_mirror(p)) return -1;
+    HIP_TRY(hipDeviceSynchronize());
+    for (auto &pl : p->plans) free_plan(pl);
+    p->plans.clear();
+    return 0;
+}
+
 int avdsp_hip_upload_words(avdsp_hip_prog *p, const int32_t *host_buf, int first, int n)
 {
     if (check_range(p, first, n)) return -1;

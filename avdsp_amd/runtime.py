@@ -28,11 +28,11 @@ EXPORTED = [
     # block extension (include/avdsp_runtime.h)
     "dspRuntimeBlock_2", "dspRuntimeBlock_3", "dspRuntimeBlock_4", "dspRuntimeBlock_5", "dspRuntimeBlock_6",
     "dspRuntimeBlockDevice", "dspRuntimeBlockPcm", "dspRuntimeUnpackPcmDevice",
-    "dspRuntimeSyncState", "dspRuntimeUploadState", "dspRuntimeSetOption", "dspRuntimeGetOption",
+    "dspRuntimeSyncState", "dspRuntimeUploadState", "dspRuntimeUploadParams", "dspRuntimeSetOption", "dspRuntimeGetOption",
     "dspRuntimeCoreInfo", "dspRuntimeKernelTime", "dspRuntimeLastError", "dspRuntimeRelease",
     # thin HIP ABI (include/avdsp_hip.h)
     "avdsp_hip_device_count", "avdsp_hip_set_device", "avdsp_hip_prog_create", "avdsp_hip_prog_destroy",
-    "avdsp_hip_prog_add_plan", "avdsp_hip_prog_add_generic", "avdsp_hip_tpdf_reset", "avdsp_hip_upload_words", "avdsp_hip_download_words", "avdsp_hip_zero_words",
+    "avdsp_hip_prog_add_plan", "avdsp_hip_prog_add_generic", "avdsp_hip_prog_clear_plans", "avdsp_hip_tpdf_reset", "avdsp_hip_upload_words", "avdsp_hip_download_words", "avdsp_hip_zero_words",
     "avdsp_hip_run_block", "avdsp_hip_run_block_host", "avdsp_hip_unpack_pcm", "avdsp_hip_run_block_pcm_host", "avdsp_hip_profile_enable", "avdsp_hip_profile_read",
     "avdsp_hip_synchronize", "avdsp_hip_last_error",
 ]
@@ -235,6 +235,10 @@ class Runtime:
 
     def upload_state(self):
         self._check(self.L.dspRuntimeUploadState(self.rundata))
+
+    def upload_params(self):
+        """After editing parameter words in self.buf in place."""
+        self._check(self.L.dspRuntimeUploadParams())
 
     def release(self):
         self.L.dspRuntimeRelease()

@@ -82,6 +82,10 @@ int             avdsp_hip_prog_add_generic(avdsp_hip_prog *prog, const avdsp_gen
 /* dspTpdfInit (dsp_tpdf.h:85-99) on the device copy of the dither generator's globals */
 int             avdsp_hip_tpdf_reset(avdsp_hip_prog *prog, int seed, int default_dither);
 
+/* forget every plan but keep the mirror (the FIR histories are written back into it first): the host
+ * has edited parameters in the program words and will lower its cores again */
+int             avdsp_hip_prog_clear_plans(avdsp_hip_prog *prog);
+
 /* mirror maintenance: word ranges of the caller's buffer */
 int avdsp_hip_upload_words(avdsp_hip_prog *prog, const int32_t *host_buf, int first_word, int nwords);
 int avdsp_hip_download_words(avdsp_hip_prog *prog, int32_t *host_buf, int first_word, int nwords);

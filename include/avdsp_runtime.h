@@ -107,10 +107,12 @@ int dspRuntimeUnpackPcmDevice(int pcm, const void *d_src, int *d_dst, long long 
 
 /* device state -> rundata (the buffer stays the checkpoint) / rundata -> device state (restore).
  * Sync also brings back the program words (DSP_STORE_MEM writes into the program's parameter
- * section, dsp_runtime.c:755-760).  A host that edits parameters in the program words afterwards
- * calls dspRuntimeReset (plans are rebuilt from the buffer at the next block).                   */
+ * section, dsp_runtime.c:755-760).                                                              */
 int dspRuntimeSyncState(int *rundata);
 int dspRuntimeUploadState(const int *rundata);
+/* The host edited parameters (gains, biquad coefficients, delay values, bypass flags, taps) in the program
+ * words, as the reference allows between any two frames: carry the edits to the device.  State is kept. */
+int dspRuntimeUploadParams(void);
 
 /* Tunables: "fir_impl" 0 = plain tap loop, 1 = MFMA (default); "biquad_impl" 0 = lane per channel,
  * 1 = section-pipelined (default); "device" = HIP device ordinal (before the first block).      */

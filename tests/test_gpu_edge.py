@@ -301,3 +301,61 @@ def test_reset_keeps_store_mem_words_like_the_reference():
     got = r.run_block(x, 32, 8, 0, block=64)
     assert (got == want).all()
     assert (r.sync_state() == o.state).all()
+
+
+@pytest.mark.parametrize("fmt", [2, 6])
+def test_live_parameter_edits(fmt):
+    """The reference reads parameters from the program words on every frame; a host may change a gain, a
+    biquad coefficient, a tap or a bypass flag between two frames.  dspRuntimeUploadParams carries such
+    edits to the device and keeps every filter's state (FIR histories included)."""
+    taps = 0 if fmt == 2 else 40
+    prog = pb.synth_program(fmt, 3, 3, taps)
+    x = pb.lcg_input(300, 3, fmt == 6, seed=4)
+    o = po.OracleProgram(fmt, prog)
+    r = rt.Runtime(fmt, prog)
+    assert_close(r.run_block(x[:100], 3, 3), o.run_block(x[:100], 3, 3), fmt)
+
+    def find(op, nth=0):
+        i, seen = 0, 0
+        while True:
+            word = int(prog[i]); code, skip = word >> 16, word & 0xFFFF
+            if code == op:
+                if seen == nth:
+                    return i
+                seen += 1
+            i += skip
+
+    lg = find(35, 1)                                   # DSP_LOAD_GAIN of channel 1: [io][offset -> gain word]
+    gain_at = lg + int(np.int32(prog[lg + 2]))
+    bq = find(50, 0)                                   # DSP_BIQUADS of channel 0: [state][offset -> bank]
+    bank = bq + int(np.int32(prog[bq + 2]))
+    edits = {gain_at: np.float32(0.37).view(np.uint32) if fmt == 6 else np.uint32(int(0.37 * (1 << 28))),
+             bank + 5: prog[bank + 5] ^ np.uint32(0x00010000),          # b0 of the first section, slightly different
+             find(50, 2) + int(np.int32(prog[find(50, 2) + 2])) + 1: np.uint32(0)}   # bypass the bank of channel 2
+    if taps:
+        fir = find(51, 1)
+        imp = fir + int(np.int32(prog[fir + 1]))
+        edits[imp + 3] = np.float32(0.125).view(np.uint32)               # one tap of channel 1
+    for at, v in edits.items():
+        r.buf[at] = v
+        o.buf[at] = v
+    r.upload_params()
+    assert_close(r.run_block(x[100:200], 3, 3), o.run_block(x[100:200], 3, 3), fmt, what="after the edits")
+    assert_close(r.run_block(x[200:], 3, 3), o.run_block(x[200:], 3, 3), fmt, what="next block")
+    assert (r.sync_state() == o.state).all()
+
+
+def test_live_parameter_edit_in_an_interpreted_core():
+    prog = np.fromfile(os.path.join(os.path.dirname(__file__), "golden", "crossoverLV6.bin"), dtype=np.uint32)
+    x = pb.lcg_input(120, 16, False, seed=12)
+    o = po.OracleProgram(2, prog, fs=48000, random=2, dither=24)
+    r = rt.Runtime(2, prog, fs=48000, random=2, dither=24)
+    assert (r.run_block(x[:60], 32, 8, 0, block=30) == o.run_block(x[:60], 32, 8, 0, scratch_len=40, block=30)).all()
+    i = 0
+    while (int(prog[i]) >> 16) != 41:                  # first DSP_GAIN: [offset -> Q28 gain]
+        i += int(prog[i]) & 0xFFFF
+    at = i + int(np.int32(prog[i + 1]))
+    r.buf[at] = o.buf[at] = np.uint32(1 << 26)         # 0.25
+    r.upload_params()
+    assert (r.run_block(x[60:], 32, 8, 0, block=30) == o.run_block(x[60:], 32, 8, 0, scratch_len=40, block=30)).all()
+    assert (r.sync_state() == o.state).all()
