@@ -87,18 +87,24 @@ __device__ __forceinline__ double mulop(float v)
     if ((u & 0x7F800000u) == 0x7F800000u) return widen_exp255(u);
     return (double)flush_f32(v);
 }
-/* The reference runs with MXCSR.FTZ and MXCSR.DAZ set (it is built -Ofast; loading it switches the thread):
- * a double -> float conversion that lands in the subnormal range gives signed zero, a float -> double
- * conversion reads a subnormal as signed zero.  Every (float)acc of the cascade, the FIR input, the
- * float store and the float sample load go through here; a filter decaying into silence ends in
- * exact zeros the way the reference's does (oracle: ORC_FTZ_DAZ_ON, avdsp_oracle.c).                */
-__device__ __forceinline__ float ftz_f32(float v)
+/* Subnormal floats.  The reference runs with MXCSR.FTZ and MXCSR.DAZ set (it is built -Ofast; loading it
+ * switches the thread): every SSE conversion and arithmetic instruction reads a subnormal float as signed
+ * zero and flushes a subnormal result.  The wave's MODE register has the same two switches for single
+ * precision, and the chain kernels turn them on at entry (tools/denorm_mode_probe.hip: v_cvt_f32_f64 then
+ * flushes its result, v_cvt_f64_f32 its operand, signs kept).  (float)acc and (double)sample in those
+ * kernels therefore ARE the reference's cvtsd2ss / cvtss2sd, at no instruction cost, and a filter decaying
+ * into silence ends in the same signed zeros (oracle: ORC_FTZ_DAZ_ON, avdsp_oracle.c).  Double-precision
+ * subnormals (< 2.2e-308) are out of reach.  The general interpreter keeps the default mode (its float
+ * division relies on it) and flushes in software (avdsp_interp.inc).                                  */
+__device__ __forceinline__ void flush_f32_subnormals_like_the_reference()
 {
-    const unsigned u = __float_as_uint(v);
-    return (u & 0x7F800000u) ? v : __uint_as_float(u & 0x80000000u);
+    __builtin_amdgcn_s_setreg(1 /* HW_REG_MODE */ | (4 << 6) /* FP_DENORM: single precision */ | (1 << 11) /* 2 bits */, 0);
 }
-__device__ __forceinline__ float  narrow_f32(double d) { return ftz_f32((float)d); }
-__device__ __forceinline__ double widen_f32(float v)   { return (double)ftz_f32(v); }
+__device__ __forceinline__ float  narrow_f32(double d) { return (float)d; }     /* under the flush MODE only */
+__device__ __forceinline__ double widen_f32(float v)   { return (double)v; }
+/* the same flush in software, for fir_mfma: there the MODE switch costs the MFMA loop 2.5 % (measured A/B,
+ * reason unknown), while its few conversions -- one per output sample -- are off the critical path */
+__device__ __forceinline__ unsigned ftz_bits(unsigned u) { return (u & 0x7F800000u) ? u : (u & 0x80000000u); }
 
 /* dsp_ieee754.h:204-250: int -> float, magnitude TRUNCATED to 24 bits, times 2^-31.  INT_MIN leaves
  * the reference's 7-step normaliser one step short: mantissa 0, exponent 126, i.e. -0.5.       */
@@ -304,6 +310,7 @@ __device__ __forceinline__ Hand<FMT> hand_rotate(Hand<FMT> h)
 template <int FMT, int P>
 __global__ __launch_bounds__(kBlock) void biquad_pipe(const BiquadArgs a)
 {
+    if constexpr (FMT != 2) flush_f32_subnormals_like_the_reference();
     using alu_t = typename Alu<FMT>::type;
     constexpr int NB = P < 16 ? P : 16;                 /* steps per IO batch */
     constexpr int CPB = kBlock / P;                     /* chains per block */
@@ -488,6 +495,7 @@ __global__ __launch_bounds__(kBlock) void biquad_pipe(const BiquadArgs a)
 template <int FMT>
 __global__ __launch_bounds__(64) void biquad_simple(const BiquadArgs a)
 {
+    if constexpr (FMT != 2) flush_f32_subnormals_like_the_reference();
     using alu_t = typename Alu<FMT>::type;
     const int slot = blockIdx.x * 64 + threadIdx.x;
     if (slot >= a.ngroup) return;
@@ -575,8 +583,11 @@ __device__ __forceinline__ void fir_append_input(const FirArgs &a, const avdsp_c
 {
     const int B = a.io.nframes;
     const unsigned *inp = a.io.in + (c.in_io - a.io.in_base);
-    for (int q = threadIdx.x; q < B; q += blockDim.x)
-        *ring_at(a.ring, cid, q) = __uint_as_float(narrow_stage<FMT>(load_stage<FMT>(inp[(size_t)q * a.io.in_stride], c.load_mode, c.gain_bits)));
+    for (int q = threadIdx.x; q < B; q += blockDim.x) {
+        unsigned raw = inp[(size_t)q * a.io.in_stride];
+        if constexpr (FMT == 6) raw = ftz_bits(raw);           /* fir_mfma runs in the default MODE: flush by hand */
+        *ring_at(a.ring, cid, q) = __uint_as_float(ftz_bits(narrow_stage<FMT>(load_stage<FMT>(raw, c.load_mode, c.gain_bits))));
+    }
     __syncthreads();
 }
 
@@ -704,7 +715,11 @@ __global__ __launch_bounds__(kBlock, 4) void fir_mfma(const FirArgs a)
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int n = 16 * (16 * wave + ij) + k + 4 * r;
-        if (n < B) emit_out(a.io, c, n, store_stage<FMT>(acc[r], c.sat, a.io.store_mask));
+        if (n < B) {
+            unsigned word = store_stage<FMT>(acc[r], c.sat, a.io.store_mask);
+            if constexpr (FMT == 6) word = ftz_bits(word);      /* default MODE here: flush the float by hand */
+            emit_out(a.io, c, n, word);
+        }
     }
 }
 
@@ -713,6 +728,7 @@ __global__ __launch_bounds__(kBlock, 4) void fir_mfma(const FirArgs a)
 template <int FMT>
 __global__ __launch_bounds__(kBlock) void fir_plain(const FirArgs a)
 {
+    if constexpr (FMT != 2) flush_f32_subnormals_like_the_reference();
     const int slot = xcd_remap(blockIdx.x, a.per_xcd);
     if (slot >= a.ngroup) return;
     const int cid = a.group[slot];
@@ -760,6 +776,7 @@ struct PassArgs {
 template <int FMT>
 __global__ __launch_bounds__(kBlock) void passthrough(const PassArgs a)
 {
+    if constexpr (FMT != 2) flush_f32_subnormals_like_the_reference();
     const long long total = (long long)a.ngroup * a.io.nframes;
     for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
         const int slot = (int)(g % a.ngroup), n = (int)(g / a.ngroup);
