@@ -560,8 +560,9 @@ struct FirArgs {
     BlockIO         io;
 };
 
-constexpr int kNG  = 2;              /* groups of 16 tap positions per operand set (8 MFMAs) */
-constexpr int kMaxGpc = 78;          /* 1248 tap positions per chunk: <= 29 KB of LDS, 5 workgroups per CU */
+constexpr int kNG  = 1;              /* groups of 16 tap positions per operand set (4 MFMAs): small sets keep the kernel at
+                                        96 VGPRs = 5 waves per SIMD, which beats deeper prefetch at 4 (A/B: -3 %) */
+constexpr int kMaxGpc = 56;          /* 896 tap positions per chunk: <= 27 KB of LDS, 5 workgroups per CU, no spills */
 constexpr int kFirPad = 1024;        /* frames per launch the window image is laid out for (4 tiles) */
 
 /* the operand prefetch runs up to kNG + 1 groups past the end of a chunk: both images carry that margin */
@@ -646,7 +647,7 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
  * walked in LDS chunks while the accumulators stay in registers; the small chunk images let five
  * workgroups share a CU, so one workgroup's staging hides under the others' MFMAs.               */
 template <int FMT>
-__global__ __launch_bounds__(kBlock, 4) void fir_mfma(const FirArgs a)
+__global__ __launch_bounds__(kBlock, 5) void fir_mfma(const FirArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int slot = xcd_remap(blockIdx.x, a.per_xcd);
