@@ -282,20 +282,16 @@ __device__ __forceinline__ unsigned from_prev_lane(unsigned old, unsigned v)
     else return (unsigned)__shfl_up((int)v, 1, 64);
 }
 
-template <int FMT> struct Hand;                          /* what travels from section to section */
-template <> struct Hand<2> { unsigned y; };              /* (int)(acc >> 28) */
-template <> struct Hand<4> { unsigned y, lo, hi; };      /* float bits of (float)acc and its flushed double */
-template <> struct Hand<6> { unsigned y, lo, hi; };
+/* what travels from section to section (and down the input batch): the 32-bit result only -- (int)(acc >> 28)
+ * or the bits of (float)acc.  The float models widen it where it is used: one v_cvt_f64_f32 in the receiving
+ * lane is cheaper than moving the double's two halves through DPP as well (8 -> 4 DPP moves per step). */
+template <int FMT> struct Hand { unsigned y; };
 
 template <int FMT>
 __device__ __forceinline__ Hand<FMT> hand_from_sample(unsigned raw, const avdsp_chain &c)
 {
     Hand<FMT> h;
     h.y = narrow_stage<FMT>(load_stage<FMT>(raw, c.load_mode, c.gain_bits));
-    if constexpr (FMT != 2) {
-        const unsigned long long d = (unsigned long long)__double_as_longlong((double)__uint_as_float(h.y));   /* h.y is flushed already; Inf / NaN: see the cascade step */
-        h.lo = (unsigned)d; h.hi = (unsigned)(d >> 32);
-    }
     return h;
 }
 
@@ -303,7 +299,6 @@ template <int FMT, int CTRL>
 __device__ __forceinline__ Hand<FMT> hand_rotate(Hand<FMT> h)
 {
     h.y = dpp_mov<CTRL>(h.y, h.y);
-    if constexpr (FMT != 2) { h.lo = dpp_mov<CTRL>(h.lo, h.lo); h.hi = dpp_mov<CTRL>(h.hi, h.hi); }
     return h;
 }
 
@@ -385,14 +380,12 @@ __global__ __launch_bounds__(kBlock) void biquad_pipe(const BiquadArgs a)
 
     Hand<FMT> hy;                                       /* this lane's latest result, offered to lane+1 */
     hy.y = y1;
-    if constexpr (FMT != 2) { hy.lo = 0; hy.hi = 0; }
     unsigned ob_lo = 0, ob_hi = 0;                      /* rotating output batch (accumulator bits) */
 
     auto step = [&](Hand<FMT> &ib, int t, auto masked) {
         /* operand from the previous section, or the next input sample for section 0 */
         Hand<FMT> xin;
         xin.y = from_prev_lane<P>(ib.y, hy.y);
-        if constexpr (FMT != 2) { xin.lo = from_prev_lane<P>(ib.lo, hy.lo); xin.hi = from_prev_lane<P>(ib.hi, hy.hi); }
         if constexpr (P != 16) {                        /* section-0 lanes that do not sit at a row start */
             if (first) xin = ib;
         }
@@ -420,7 +413,7 @@ __global__ __launch_bounds__(kBlock) void biquad_pipe(const BiquadArgs a)
                 hy.y = y1;
             } else {
                 /* dsp_biquadSTD.h:87-117: exact float x float products, five sequential f64 adds */
-                const double dxin = __longlong_as_double((long long)(((unsigned long long)xin.hi << 32) | xin.lo));
+                const double dxin = (double)__uint_as_float(xin.y);     /* flushed by the MODE like mulop's exponent-0 rule */
                 acc = __builtin_fma(dxin, cd[0], acc);
                 acc = __builtin_fma(dx1, cd[1], acc);
                 acc = __builtin_fma(dx2, cd[2], acc);
@@ -435,8 +428,7 @@ __global__ __launch_bounds__(kBlock) void biquad_pipe(const BiquadArgs a)
                 const float yn = narrow_f32(acc);
                 x2 = x1; x1 = xin.y; y2 = y1; y1 = __float_as_uint(yn);
                 dx2 = dx1; dx1 = dxin; dy2 = dy1; dy1 = (double)yn;
-                const unsigned long long dd = (unsigned long long)__double_as_longlong(dy1);
-                hy.y = y1; hy.lo = (unsigned)dd; hy.hi = (unsigned)(dd >> 32);
+                hy.y = y1;
             }
             if (last) {
                 unsigned long long bits;
