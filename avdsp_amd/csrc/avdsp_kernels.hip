@@ -136,6 +136,15 @@ __device__ __forceinline__ double saturate_double_0db(double d)
     return d;
 }
 
+/* dsp_ieee754.h:171-184, the float form of the same clamp: (float)saturate(acc) == saturate((float)acc) */
+__device__ __forceinline__ float saturate_f32_0db(float f)
+{
+    const int e = (int)__float_as_uint(f) >> 23;               /* arithmetic shift: the sign stays on top */
+    if (e >= 127) return 1.0f;
+    if (e < 0 && e >= -129) return -1.0f;
+    return f;
+}
+
 /* dsp_ieee754.h:85-107: truncate toward zero to s.31, |d| >= 1 -> +/-0x7FFFFFFF.  For |d| < 2^-42 the
  * reference shifts by >= 64 (undefined in C); its x86-64 binaries take the count modulo 64 and so
  * do the golden vectors, the oracle and this function.                                          */
@@ -391,7 +400,7 @@ __global__ __launch_bounds__(kBlock) void biquad_pipe(const BiquadArgs a)
         }
         ib = hand_rotate<FMT, kRowRor15>(ib);
         ob_lo = dpp_mov<kRowRor1>(ob_lo, ob_lo);
-        ob_hi = dpp_mov<kRowRor1>(ob_hi, ob_hi);
+        if constexpr (FMT == 4) ob_hi = dpp_mov<kRowRor1>(ob_hi, ob_hi);
         bool act = true;
         if constexpr (decltype(masked)::value) { const int n = t - s; act = lane_on && n >= 0 && n < B; }
         if (act) {
@@ -431,10 +440,15 @@ __global__ __launch_bounds__(kBlock) void biquad_pipe(const BiquadArgs a)
                 hy.y = y1;
             }
             if (last) {
-                unsigned long long bits;
-                if constexpr (FMT == 2) bits = (unsigned long long)acc;
-                else bits = (unsigned long long)__double_as_longlong(acc);
-                ob_lo = (unsigned)bits; ob_hi = (unsigned)(bits >> 32);
+                /* What leaves the cascade.  Only DSP_FORMAT 4 needs the whole accumulator later (31 bits of it go
+                 * into the int sample); the float sample of format 6 is a function of (float)acc alone -- SAT0DB
+                 * before or after the rounding gives the same float -- and the int64 store is either the low word
+                 * of acc or, behind SAT0DB, acc >> 28, which the section has just formed.                     */
+                if constexpr (FMT == 4) {
+                    const unsigned long long bits = (unsigned long long)__double_as_longlong(acc);
+                    ob_lo = (unsigned)bits; ob_hi = (unsigned)(bits >> 32);
+                } else if constexpr (FMT == 6) ob_lo = y1;
+                else ob_lo = c.sat ? y1 : (unsigned)(unsigned long long)acc;
             }
         }
     };
@@ -464,11 +478,15 @@ __global__ __launch_bounds__(kBlock) void biquad_pipe(const BiquadArgs a)
         /* flush the output batch: this lane holds the result of step tb + ostep of chain `ocid` */
         const int n = tb + ostep - (nsec - 1);
         if (owner && n >= 0 && n < B) {
-            const unsigned long long bits = ((unsigned long long)ob_hi << 32) | ob_lo;
-            alu_t X;
-            if constexpr (FMT == 2) X = (long long)bits; else X = __longlong_as_double((long long)bits);
-            if (oc.fir_taps) *ring_at(a.ring, ocid, n) = __uint_as_float(narrow_stage<FMT>(X));
-            else emit_out(a.io, oc, n, store_stage<FMT>(X, oc.sat, a.io.store_mask));
+            if constexpr (FMT == 4) {
+                const double X = __longlong_as_double((long long)(((unsigned long long)ob_hi << 32) | ob_lo));
+                if (oc.fir_taps) *ring_at(a.ring, ocid, n) = __uint_as_float(narrow_stage<FMT>(X));
+                else emit_out(a.io, oc, n, store_stage<FMT>(X, oc.sat, a.io.store_mask));
+            } else if constexpr (FMT == 6) {
+                if (oc.fir_taps) *ring_at(a.ring, ocid, n) = __uint_as_float(ob_lo);
+                else emit_out(a.io, oc, n, oc.sat ? __float_as_uint(saturate_f32_0db(__uint_as_float(ob_lo))) : ob_lo);
+            } else
+                emit_out(a.io, oc, n, ob_lo & (unsigned)a.io.store_mask);
         }
     }
 
