@@ -22,7 +22,7 @@
  *                       reference's order; only independent work is overlapped.  State and
  *                       coefficients live in registers for the whole block.
  *   biquad_simple<FMT>  one lane per channel, sections in a loop, state in memory (cross-check path)
- *   fir_mfma<FMT>       one workgroup per channel; taps and the input window staged in LDS; the
+ *   fir_mfma<FMT,NG>    one workgroup per channel; taps and the input window staged in LDS; the
  *                       block's outputs are a dense (16 x K) x (K x 16) contraction per 256-frame
  *                       tile on v_mfma_f64_16x16x4_f64: Y[i][a] = sum_m h[m+i] * x[16a-m].
  *                       Products of two floats are exact in f64 and the K index ascends with the
@@ -570,8 +570,11 @@ struct FirArgs {
     BlockIO         io;
 };
 
-constexpr int kNG  = 1;              /* groups of 16 tap positions per operand set (4 MFMAs): small sets keep the kernel at
-                                        96 VGPRs = 5 waves per SIMD, which beats deeper prefetch at 4 (A/B: -3 %) */
+/* groups of 16 tap positions per operand set: NG = 1 (4 MFMAs) keeps the kernel at 96 VGPRs = 5 waves per
+ * SIMD, which beats deeper prefetch when the grid fills the GPU (A/B: -3 %); with at most two workgroups per
+ * CU there is nothing to interleave and sets of 2 hide more LDS latency.  The images carry the margin of the
+ * deeper variant.                                                                                           */
+constexpr int kNG  = 2;
 constexpr int kMaxGpc = 56;          /* 896 tap positions per chunk: <= 27 KB of LDS, 5 workgroups per CU, no spills */
 constexpr int kFirPad = 1024;        /* frames per launch the window image is laid out for (4 tiles) */
 
@@ -656,8 +659,8 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
  * One workgroup (4 waves) per channel, one wave per column tile of 16 (256 frames).  The tap range is
  * walked in LDS chunks while the accumulators stay in registers; the small chunk images let five
  * workgroups share a CU, so one workgroup's staging hides under the others' MFMAs.               */
-template <int FMT>
-__global__ __launch_bounds__(kBlock, 5) void fir_mfma(const FirArgs a)
+template <int FMT, int NG>
+__global__ __launch_bounds__(kBlock, NG == 1 ? 5 : 4) void fir_mfma(const FirArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int slot = xcd_remap(blockIdx.x, a.per_xcd);
@@ -679,16 +682,16 @@ __global__ __launch_bounds__(kBlock, 5) void fir_mfma(const FirArgs a)
     for (int s = 0; s < 4; s++) xp[s] = xs + win_pos(f0 - 4 * s, row) + ij;
     v4f64 acc = {0.0, 0.0, 0.0, 0.0};
 
-    double ha[4 * kNG], xa[4 * kNG], hb[4 * kNG], xb[4 * kNG];
+    double ha[4 * NG], xa[4 * NG], hb[4 * NG], xb[4 * NG];
     auto load_set = [&](double *h, double *x, int g) {
 #pragma unroll
-        for (int q = 0; q < kNG; q++)
+        for (int q = 0; q < NG; q++)
 #pragma unroll
             for (int s = 0; s < 4; s++) { h[4 * q + s] = hp[16 * (g + q) + 4 * s]; x[4 * q + s] = xp[s][-(g + q)]; }
     };
     auto mfma_set = [&](const double *h, const double *x) {
 #pragma unroll
-        for (int u = 0; u < 4 * kNG; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(h[u], x[u], acc, 0, 0, 0);
+        for (int u = 0; u < 4 * NG; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(h[u], x[u], acc, 0, 0, 0);
     };
 
     const int total_groups = (T + 15 + 15) >> 4;        /* tap positions m = -15 .. T-1 in groups of 16 */
@@ -696,7 +699,7 @@ __global__ __launch_bounds__(kBlock, 5) void fir_mfma(const FirArgs a)
      * their chunk boundaries (barriers + LDS refill, no MFMA) in lockstep.  A first chunk of 1/4 .. 4/4
      * of the normal size, chosen by dispatch round, keeps their refills apart.                     */
     const int phase = (blockIdx.x >> 8) & 3;
-    int glen = max(kNG, (gpc * (phase + 1) / 4) / kNG * kNG);
+    int glen = max(NG, (gpc * (phase + 1) / 4) / NG * NG);
     ChunkRegs regs;
     fir_chunk_fetch(a, c, cid, -15, regs);
     for (int g0 = 0; g0 < total_groups; g0 += glen, glen = gpc) {
@@ -706,15 +709,15 @@ __global__ __launch_bounds__(kBlock, 5) void fir_mfma(const FirArgs a)
         if (g0 + glen < total_groups) fir_chunk_fetch(a, c, cid, -15 + 16 * (g0 + glen), regs);
         if (busy) {
             const int ng = min(glen, total_groups - g0);
-            const int nsets = (ng + kNG - 1) / kNG;
+            const int nsets = (ng + NG - 1) / NG;
             load_set(ha, xa, 0);
             int st = 0;
             for (; st + 2 <= nsets; st += 2) {
-                load_set(hb, xb, kNG * (st + 1));
+                load_set(hb, xb, NG * (st + 1));
                 __builtin_amdgcn_sched_barrier(0);
                 mfma_set(ha, xa);
                 __builtin_amdgcn_sched_barrier(0);
-                load_set(ha, xa, kNG * (st + 2));
+                load_set(ha, xa, NG * (st + 2));
                 __builtin_amdgcn_sched_barrier(0);
                 mfma_set(hb, xb);
                 __builtin_amdgcn_sched_barrier(0);
@@ -978,7 +981,8 @@ int launch_fir(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, BlockIO io
         a.gpc = pl.fir_gpc;
         size_t lds = 0;
         if (fir_impl) lds = fir_lds_bytes(a.gpc, &a.hs_cap, &a.win_row);
-        auto kern = fir_impl ? fir_mfma<FMT> : fir_plain<FMT>;      /* LDS opt-in was done at plan creation */
+        /* LDS opt-in was done at plan creation.  Few workgroups per CU: the deeper operand sets */
+        auto kern = !fir_impl ? fir_plain<FMT> : (n <= 2 * 256 ? fir_mfma<FMT, 2> : fir_mfma<FMT, 1>);
         hipLaunchKernelGGL(kern, dim3(a.per_xcd * 8), dim3(64 * nwaves), lds, stream, a);
         HIP_TRY(hipGetLastError());
         return 0;
@@ -1098,9 +1102,12 @@ int avdsp_hip_prog_add_plan(avdsp_hip_prog *prog, const avdsp_plan_desc *d)
         {   /* nothing in the launch path may touch function attributes (stream capture) */
             int hs_cap, row;
             const int lds = (int)fir_lds_bytes(pl.fir_gpc, &hs_cap, &row);
-            hipError_t e = d->format == 4 ? hipFuncSetAttribute((const void *)fir_mfma<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)
-                                          : hipFuncSetAttribute((const void *)fir_mfma<6>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            if (e != hipSuccess) { free_plan(pl); return set_err("hipFuncSetAttribute(LDS %d): %s", lds, hipGetErrorString(e)); }
+            const void *variants[2] = { d->format == 4 ? (const void *)fir_mfma<4, 1> : (const void *)fir_mfma<6, 1>,
+                                        d->format == 4 ? (const void *)fir_mfma<4, 2> : (const void *)fir_mfma<6, 2> };
+            for (const void *fn : variants) {
+                hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                if (e != hipSuccess) { free_plan(pl); return set_err("hipFuncSetAttribute(LDS %d): %s", lds, hipGetErrorString(e)); }
+            }
         }
         pl.ring_R = pow2ceil(pl.max_taps + kFirChunk + 16 * pl.fir_gpc + 16 * (kNG + 4) + 64);
         static_assert(kFirChunk == kFirPad, "one FIR launch covers exactly the frames the window image is laid out for");
