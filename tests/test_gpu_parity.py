@@ -231,7 +231,7 @@ def test_golden_general_interpreter(case):
         r.set_option("generic", 0)
 
 
-@pytest.mark.parametrize("seed", list(range(12, 72)) + [344, 373, 416, 462])     # the last four: NaN payloads through float adds
+@pytest.mark.parametrize("seed", list(range(12, 72)) + [344, 373, 416, 462, 2260])     # the last five: NaN payloads through float / double adds
 def test_random_programs_vs_oracle(seed):
     """More random programs than there are goldens: the interpreter against the oracle (itself held to the
     compiled reference on these generators, tests/golden/make_goldens.py and 800+ runs while developing),
