@@ -23,6 +23,9 @@ import numpy as np
 
 from avdsp_amd import encoder as enc
 
+import os
+
+NAN_HEAVY = bool(int(os.environ.get("AVDSP_FUZZ_NAN_HEAVY", "0")))
 F44100, F48000, F96000, F192000 = 4, 5, 7, 9
 N_IN, IN_BASE, N_OUT = 8, 32, 24           # inputs IO 32..39, outputs IO 0..23
 
@@ -97,6 +100,8 @@ class _Builder:
                "pwrxy", "mem", "value", "tpdf", "white_mix", "table"]
         if self.ns2_ok: ops.append("ns2")
         if not self.int_mode: ops += ["square_sqrt", "generator"]
+        if NAN_HEAVY:                                   # development switch: DSP_DITHER manufactures NaN in the float models
+            ops += ["dither"] * 8 + ["addxy", "subxy", "subyx", "addyx", "avgxy", "avgyx", "dcblock", "rms", "bq"] * 2
         op = str(r.choice(ops))
         if op == "bq": L.dsp_BIQUADS(self.banks[int(r.integers(0, len(self.banks)))])
         elif op == "gain": L.dsp_GAIN_Fixed(float(r.uniform(0.2, 1.0)))
