@@ -60,9 +60,9 @@ static struct {
     int             dev_state_valid;     /* device mirror holds the authoritative state */
     core_plan       plans[MAX_CORE_PLANS];
     int             nplans;
-    int             opt_fir_impl, opt_biquad_impl, opt_device, opt_profile, opt_generic;
+    int             opt_fir_impl, opt_biquad_impl, opt_device, opt_profile, opt_generic, opt_interp_impl;
     int             device_selected;
-} G = { .opt_fir_impl = 1, .opt_biquad_impl = 1, .opt_device = -1 };
+} G = { .opt_fir_impl = 1, .opt_biquad_impl = 1, .opt_device = -1, .opt_interp_impl = 1 };
 
 static char g_err[512];
 static int  g_err_code;
@@ -101,6 +101,7 @@ int dspRuntimeSetOption(const char *key, int value)
     if (!strcmp(key, "biquad_impl")) { G.opt_biquad_impl = value; return 0; }
     if (!strcmp(key, "device"))      { G.opt_device = value; G.device_selected = 0; return 0; }
     if (!strcmp(key, "generic"))     { G.opt_generic = value; drop_device(); return 0; }
+    if (!strcmp(key, "interp_impl")) { G.opt_interp_impl = value; drop_device(); return 0; }
     if (!strcmp(key, "profile")) {
         G.opt_profile = value;
         if (G.dev) avdsp_hip_profile_enable(G.dev, value);
@@ -116,6 +117,7 @@ int dspRuntimeGetOption(const char *key)
     if (!strcmp(key, "device"))      return G.opt_device;
     if (!strcmp(key, "profile"))     return G.opt_profile;
     if (!strcmp(key, "generic"))     return G.opt_generic;
+    if (!strcmp(key, "interp_impl")) return G.opt_interp_impl;
     return -1;
 }
 
@@ -368,11 +370,94 @@ static int lower_core(int format, opcode_t *core, lowered *L)
  * ---------------------------------------------------------------------------------------- */
 #define GENERIC_IO_LIMIT 65536
 
+/* Frame-parallel eligibility (avdsp_interp.inc, interp_wave): the device may run 64 frames of a block side
+ * by side, opcode by opcode, only if nothing but opcode-private state passes from one frame to the next.
+ * While the opcodes are walked in program order this records what a frame reads before it has written it:
+ *  - frame slots (samples[]) that are also stored later in the frame: they must then come from the caller's
+ *    windows -- decided per block call, the slots are handed over as a bitmap;
+ *  - mirror words used as per-frame variables (STORE_MEM / LOAD_MEM, the result words of LOAD_MUX, TPDF,
+ *    TPDF_CALC read by LOAD_MEM_DATA): written-then-read words get a per-lane copy; a word read first and
+ *    written later in the frame is last frame's value = not eligible;
+ *  - the TPDF generator: DSP_TPDF_CALC must run before anything that uses its value or the global mask;
+ *  - private state areas of two opcodes must not overlap (the encoder never shares them).               */
+#define WAVE_IO_LIMIT 256
+typedef struct {
+    int ok;
+    unsigned char written[WAVE_IO_LIMIT], early[WAVE_IO_LIMIT];
+    int nwr, wr_word[64];
+    int nearly, early_word[64];
+    int nranges; struct { long long lo, hi; } range[512];
+    int tpdf_calc_seen, tpdf_user_seen;
+} wscan;
+
 typedef struct {
     int format, aw, prog_words, data_words, at;
     unsigned skip;
     avdsp_generic_desc *d;
+    wscan w;
 } gscan;
+
+static void ws_read_io(gscan *s, int io)
+{
+    if (io < 0 || io >= WAVE_IO_LIMIT) { s->w.ok = 0; return; }
+    if (!s->w.written[io]) s->w.early[io] = 1;
+}
+static void ws_write_io(gscan *s, int io)
+{
+    if (io < 0 || io >= WAVE_IO_LIMIT) { s->w.ok = 0; return; }
+    s->w.written[io] = 1;
+}
+static void ws_mem_write(gscan *s, int word)
+{
+    for (int k = 0; k < s->w.nwr; k++) if (s->w.wr_word[k] == word) return;
+    if (s->w.nwr == 64) { s->w.ok = 0; return; }
+    s->w.wr_word[s->w.nwr++] = word;
+}
+static void ws_mem_read(gscan *s, int word, int needs_writer)
+{
+    for (int k = 0; k < s->w.nwr; k++)
+        if (s->w.wr_word[k] == word) {
+            avdsp_generic_desc *d = s->d;
+            for (int j = 0; j < d->nvm; j++) if (d->vm_word[j] == word) return;
+            if (d->nvm == 16) { s->w.ok = 0; return; }
+            d->vm_word[d->nvm++] = word;
+            return;
+        }
+    if (needs_writer) { s->w.ok = 0; return; }       /* LOAD_MEM_DATA of a word nothing in this frame has written yet */
+    if (s->w.nearly == 64) { s->w.ok = 0; return; }
+    s->w.early_word[s->w.nearly++] = word;
+}
+static void ws_state(gscan *s, int off, long long n)
+{
+    if (n <= 0) return;
+    if (s->w.nranges == 512) { s->w.ok = 0; return; }
+    s->w.range[s->w.nranges].lo = off; s->w.range[s->w.nranges].hi = off + n; s->w.nranges++;
+}
+static void ws_tpdf_user(gscan *s) { s->w.tpdf_user_seen = 1; }
+static void ws_finish(gscan *s)
+{
+    wscan *w = &s->w;
+    /* a slot read first and stored later in the frame carries last frame's value, unless the caller's rows
+     * overwrite it every frame (per call); a slot this core only reads is constant during its block */
+    for (int io = 0; io < WAVE_IO_LIMIT; io++)
+        if (w->early[io] && w->written[io]) s->d->carried_io[io >> 5] |= 1u << (io & 31);
+    for (int i = 0; i < w->nearly && w->ok; i++)
+        for (int k = 0; k < w->nwr; k++) if (w->wr_word[k] == w->early_word[i]) { w->ok = 0; break; }
+    /* values are aw words wide: two different keys closer than that would alias */
+    for (int i = 0; i < w->nwr && w->ok; i++) {
+        for (int k = 0; k < w->nwr; k++) { int dlt = w->wr_word[i] - w->wr_word[k]; if (dlt && dlt > -s->aw && dlt < s->aw) w->ok = 0; }
+        for (int k = 0; k < w->nearly; k++) { int dlt = w->wr_word[i] - w->early_word[k]; if (dlt && dlt > -s->aw && dlt < s->aw) w->ok = 0; }
+    }
+    for (int i = 0; i < w->nranges && w->ok; i++)
+        for (int k = i + 1; k < w->nranges; k++)
+            if (w->range[i].lo < w->range[k].hi && w->range[k].lo < w->range[i].hi) { w->ok = 0; break; }
+    /* a result word (data area) inside some opcode's private state would be the same kind of sharing */
+    for (int i = 0; i < w->nwr && w->ok; i++) {
+        long long off = (long long)w->wr_word[i] - s->prog_words;
+        if (off < 0) continue;
+        for (int k = 0; k < w->nranges; k++) if (off < w->range[k].hi && off + s->aw > w->range[k].lo) { w->ok = 0; break; }
+    }
+}
 
 static int gs_payload(const gscan *s, int need)
 {
@@ -409,9 +494,11 @@ static int scan_generic(int format, opcode_t *core, avdsp_generic_desc *d)
     const int alu_int = (format == DSP_FORMAT_INT64);
     const int nf = G.num_freq, fi = G.freq_index;
     gscan S;
+    memset(&S, 0, sizeof S);
     S.format = format; S.aw = (format == 3 || format == 5) ? 1 : 2;
     S.prog_words = dspHeaderPtr->totalLength; S.data_words = dspHeaderPtr->dataSize; S.d = d;
     memset(d, 0, sizeof *d);
+    S.w.ok = G.opt_interp_impl != 0;
     d->io_in_min = d->io_out_min = GENERIC_IO_LIMIT; d->io_in_max = d->io_out_max = -1;
     opcode_t *p = dspFindCoreBegin(core);
     d->format = format;
@@ -436,25 +523,47 @@ static int scan_generic(int format, opcode_t *core, avdsp_generic_desc *d)
         case DSP_SWAPXY: case DSP_COPYXY: case DSP_COPYYX: case DSP_CLRXY:
         case DSP_ADDXY: case DSP_ADDYX: case DSP_SUBXY: case DSP_SUBYX: case DSP_NEGX: case DSP_NEGY:
         case DSP_MULXY: case DSP_DIVXY: case DSP_DIVYX: case DSP_AVGXY: case DSP_AVGYX:
-        case DSP_SQRTX: case DSP_SAT0DB: case DSP_SAT0DB_TPDF: case DSP_WHITE:
+        case DSP_SQRTX: case DSP_SAT0DB:
             break;
+        case DSP_SAT0DB_TPDF: case DSP_WHITE:
+            ws_tpdf_user(&S); break;
         case DSP_SHIFT: case DSP_MUL_VALUE: case DSP_DIV_VALUE: case DSP_MUL_VALUE_INT: case DSP_DIV_VALUE_INT:
         case DSP_AND_VALUE_INT: case DSP_CLIP:
             rc = gs_payload(&S, 1); break;
-        case DSP_LOAD:  rc = gs_payload(&S, 1) || gs_io(&S, a[0], 0); break;
-        case DSP_STORE: rc = gs_payload(&S, 1) || gs_io(&S, a[0], 1); break;
-        case DSP_LOAD_GAIN: rc = gs_payload(&S, 2) || gs_io(&S, a[0], 0) || gs_prog(&S, a[1], 1); break;
+        case DSP_LOAD:  rc = gs_payload(&S, 1) || gs_io(&S, a[0], 0); if (!rc) ws_read_io(&S, a[0]); break;
+        case DSP_STORE: rc = gs_payload(&S, 1) || gs_io(&S, a[0], 1); if (!rc) { ws_write_io(&S, a[0]); ws_tpdf_user(&S); } break;
+        case DSP_LOAD_GAIN: rc = gs_payload(&S, 2) || gs_io(&S, a[0], 0) || gs_prog(&S, a[1], 1); if (!rc) ws_read_io(&S, a[0]); break;
         case DSP_LOAD_STORE:
-            for (unsigned k = 0; k + 2 <= skip - 1 && !rc; k += 2) rc = gs_io(&S, a[k], 0) || gs_io(&S, a[k + 1], 1);
+            for (unsigned k = 0; k + 2 <= skip - 1 && !rc; k += 2) {
+                rc = gs_io(&S, a[k], 0) || gs_io(&S, a[k + 1], 1);
+                if (!rc) { ws_read_io(&S, a[k]); ws_write_io(&S, a[k + 1]); }
+            }
             break;
-        case DSP_GAIN: case DSP_SAT0DB_GAIN: case DSP_SAT0DB_TPDF_GAIN: case DSP_VALUE: case DSP_VALUE_INT:
+        case DSP_SAT0DB_TPDF_GAIN:
+            ws_tpdf_user(&S);
+            /* fall through */
+        case DSP_GAIN: case DSP_SAT0DB_GAIN: case DSP_VALUE: case DSP_VALUE_INT:
             rc = gs_payload(&S, 1) || gs_prog(&S, a[0], 1); break;
-        case DSP_LOAD_MEM: case DSP_STORE_MEM:
-            rc = gs_payload(&S, 1) || gs_prog(&S, a[0], S.aw); break;
-        case DSP_TPDF_CALC: case DSP_TPDF:
-            rc = gs_payload(&S, 2) || gs_data(&S, a[1], S.aw); break;
-        case DSP_DELAY_1: case DSP_LOAD_MEM_DATA:
-            rc = gs_payload(&S, 1) || gs_data(&S, a[0], S.aw); break;
+        case DSP_LOAD_MEM:
+            rc = gs_payload(&S, 1) || gs_prog(&S, a[0], S.aw); if (!rc) ws_mem_read(&S, at + a[0], 0); break;
+        case DSP_STORE_MEM:
+            rc = gs_payload(&S, 1) || gs_prog(&S, a[0], S.aw); if (!rc) ws_mem_write(&S, at + a[0]); break;
+        case DSP_TPDF_CALC:
+            rc = gs_payload(&S, 2) || gs_data(&S, a[1], S.aw);
+            if (!rc) {
+                if (S.w.tpdf_calc_seen || S.w.tpdf_user_seen) S.w.ok = 0;
+                S.w.tpdf_calc_seen = 1;
+                ws_mem_write(&S, S.prog_words + a[1]);
+            }
+            break;
+        case DSP_TPDF:
+            rc = gs_payload(&S, 2) || gs_data(&S, a[1], S.aw);
+            if (!rc) { ws_tpdf_user(&S); ws_mem_write(&S, S.prog_words + a[1]); }
+            break;
+        case DSP_DELAY_1:
+            rc = gs_payload(&S, 1) || gs_data(&S, a[0], S.aw); if (!rc) ws_state(&S, a[0], S.aw); break;
+        case DSP_LOAD_MEM_DATA:
+            rc = gs_payload(&S, 1) || gs_data(&S, a[0], S.aw); if (!rc) ws_mem_read(&S, S.prog_words + a[0], 1); break;
         case DSP_DELAY: case DSP_DELAY_DP:
             rc = gs_payload(&S, 3);
             if (!rc && a[0] < 0) rc = fail(-8, "word %d: negative delay size", at);
@@ -463,6 +572,7 @@ static int scan_generic(int format, opcode_t *core, avdsp_generic_desc *d)
                  * (fixed delay) it is microseconds and the length follows from the sample rate */
                 long long n = a[2] ? (long long)a[0] : (long long)(((unsigned long long)(unsigned)a[0] * d->delay_line_factor) >> 32);
                 rc = gs_data(&S, a[1], 1 + n * (op == DSP_DELAY ? 1 : S.aw));
+                if (!rc) ws_state(&S, a[1], 1 + n * (op == DSP_DELAY ? 1 : S.aw));
             }
             if (!rc && a[2]) rc = gs_prog(&S, a[2], 1);
             break;
@@ -473,6 +583,7 @@ static int scan_generic(int format, opcode_t *core, avdsp_generic_desc *d)
             const int num = (short)bank[0].i32;
             if (num < 1) { rc = fail(-8, "word %d: biquad bank with %d sections", at, num); break; }
             rc = gs_prog(&S, a[1], G.biquad_offset + (num - 1) * dspBiquadFreqSkip + 5) || gs_data(&S, a[0], 6ll * num);
+            if (!rc) ws_state(&S, a[0], 6ll * num);
             break; }
         case DSP_LOAD_MUX: {
             rc = gs_payload(&S, 2) || gs_prog(&S, a[0], 1) || gs_data(&S, a[1], S.aw);
@@ -480,12 +591,14 @@ static int scan_generic(int format, opcode_t *core, avdsp_generic_desc *d)
             const opcode_t *t = p + a[0];
             const int n = (short)t[0].i32;
             if (n > 0) rc = gs_prog(&S, a[0], 1 + 2 * n);
-            for (int k = 0; k < n && !rc; k++) rc = gs_io(&S, t[1 + 2 * k].i32, 0);
+            for (int k = 0; k < n && !rc; k++) { rc = gs_io(&S, t[1 + 2 * k].i32, 0); if (!rc) ws_read_io(&S, t[1 + 2 * k].i32); }
+            if (!rc) ws_mem_write(&S, S.prog_words + a[1]);
             break; }
         case DSP_DATA_TABLE:
             rc = gs_payload(&S, 5);
             if (!rc && (a[2] < 1 || a[1] < 0 || a[1] > a[2])) rc = fail(-8, "word %d: data table size %d / step %d", at, a[2], a[1]);
             if (!rc) rc = gs_data(&S, a[3], 1) || gs_prog(&S, a[4], a[2]);
+            if (!rc) ws_state(&S, a[3], 1);
             break;
         case DSP_FIR: {
             rc = gs_payload(&S, nf + 1);
@@ -495,29 +608,34 @@ static int scan_generic(int format, opcode_t *core, avdsp_generic_desc *d)
             rc = gs_prog(&S, off, 1);
             if (rc) break;
             const int length = p[off].i32, delay = length >> 16;
-            if (delay) rc = gs_data(&S, a[nf], 1 + (long long)delay);
+            if (delay) { rc = gs_data(&S, a[nf], 1 + (long long)delay); if (!rc) ws_state(&S, a[nf], 1 + (long long)delay); }
             else if (length > 0) {
                 if (alu_int)
                     rc = fail(-8, "word %d: DSP_FIR in int64 mode is undefined behaviour in the reference "
                                   "(dsp_firSTD.h:8-35) and is not provided", at);
                 else rc = gs_prog(&S, off, 1 + length) || gs_data(&S, a[nf], length);
+                if (!rc) { ws_state(&S, a[nf], length); if (length + 64 > d->seq_words) d->seq_words = length + 64; }
             }
             break; }
         case DSP_RMS:
             rc = gs_payload(&S, 2 + 2 * nf);
             if (!rc && a[1] < 0) rc = fail(-8, "word %d: negative RMS delay", at);
             if (!rc) rc = gs_data(&S, a[0], 5 + 2ll * S.aw + (long long)a[1] * S.aw);
+            if (!rc) ws_state(&S, a[0], 5 + 2ll * S.aw + (long long)a[1] * S.aw);
             break;
         case DSP_DCBLOCK:
-            rc = gs_payload(&S, 1 + nf) || gs_data(&S, a[0], S.aw + 2); break;
+            rc = gs_payload(&S, 1 + nf) || gs_data(&S, a[0], S.aw + 2); if (!rc) ws_state(&S, a[0], S.aw + 2); break;
         case DSP_DITHER:
-            rc = gs_payload(&S, 1) || gs_data(&S, a[0], 3ll * S.aw); break;
+            rc = gs_payload(&S, 1) || gs_data(&S, a[0], 3ll * S.aw); if (!rc) { ws_state(&S, a[0], 3ll * S.aw); ws_tpdf_user(&S); } break;
         case DSP_DITHER_NS2:
-            rc = gs_payload(&S, 2) || gs_data(&S, a[0], 3) || gs_prog(&S, a[1] + fi * 3, 3); break;
+            rc = gs_payload(&S, 2) || gs_data(&S, a[0], 3) || gs_prog(&S, a[1] + fi * 3, 3);
+            if (!rc) { ws_state(&S, a[0], 3); ws_tpdf_user(&S); }
+            break;
         case DSP_DISTRIB:
             rc = gs_payload(&S, 3);
             if (!rc && a[1] < 2) rc = fail(-8, "word %d: DISTRIB with %d bins", at, a[1]);
             if (!rc) rc = gs_io(&S, a[0], 1) || gs_data(&S, a[2], 1 + (long long)a[1]);
+            if (!rc) { ws_write_io(&S, a[0]); ws_state(&S, a[2], 1 + (long long)a[1]); }
             break;
         case DSP_DIRAC: case DSP_SQUAREWAVE: case DSP_SINE:
             if (alu_int) {
@@ -526,6 +644,7 @@ static int scan_generic(int format, opcode_t *core, avdsp_generic_desc *d)
                 break;
             }
             rc = gs_payload(&S, 2 + nf) || gs_data(&S, a[0], op == DSP_SINE ? 2 * S.aw : 1);
+            if (!rc) ws_state(&S, a[0], op == DSP_SINE ? 2 * S.aw : 1);
             break;
         default:
             rc = fail(-8, "word %d: unknown opcode %d", at, op);
@@ -534,6 +653,9 @@ static int scan_generic(int format, opcode_t *core, avdsp_generic_desc *d)
         p += skip;
     }
     if (d->io_span == 0) d->io_span = 1;
+    if (d->io_span > WAVE_IO_LIMIT) S.w.ok = 0;
+    if (S.w.ok) ws_finish(&S);
+    d->wave_ok = S.w.ok;
     return 0;
 }
 

@@ -858,6 +858,7 @@ struct Plan {
     float *d_ring = nullptr; int ring_R = 0, wpos = 0;
     int fir_gpc = 0;                  /* groups of 16 tap positions per LDS chunk */
     int io_in_min = 0, io_in_max = -1, io_out_min = 0, io_out_max = -1;
+    bool wave_ok = false; unsigned carried_io[8] = {0, 0, 0, 0, 0, 0, 0, 0};      /* frame-parallel interpreter */
 };
 
 }  // namespace
@@ -1167,6 +1168,18 @@ int avdsp_hip_prog_add_generic(avdsp_hip_prog *prog, const avdsp_generic_desc *d
         a.frame_lds = 0; a.stage_words = 0; a.batch_lds = 0;
         pl.ga_lds = (size_t)kGenericBatchLds * 4;
     }
+    pl.wave_ok = d->wave_ok != 0 && d->nvm >= 0 && d->nvm <= 16;
+    if (pl.wave_ok) {
+        for (int k = 0; k < 8; k++) pl.carried_io[k] = d->carried_io[k];
+        a.nvm = d->nvm;
+        for (int k = 0; k < d->nvm; k++) a.vm_word[k] = d->vm_word[k];
+        a.seq_words = std::max(d->seq_words, 128);
+        const void *fn = d->format == 2 ? (const void *)interp_wave<2> : d->format == 3 ? (const void *)interp_wave<3>
+                       : d->format == 4 ? (const void *)interp_wave<4> : d->format == 5 ? (const void *)interp_wave<5>
+                                                                                        : (const void *)interp_wave<6>;
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGenericLdsMax);
+        if (e != hipSuccess) return set_err("hipFuncSetAttribute(frame-parallel LDS): %s", hipGetErrorString(e));
+    }
     if (pl.ga_staged) {   /* per plan creation, like the FIR: nothing in the launch path may touch function attributes */
         const void *fn = d->format == 2 ? (const void *)interp_core<2, true> : d->format == 3 ? (const void *)interp_core<3, true>
                        : d->format == 4 ? (const void *)interp_core<4, true> : d->format == 5 ? (const void *)interp_core<5, true>
@@ -1187,12 +1200,47 @@ int avdsp_hip_tpdf_reset(avdsp_hip_prog *prog, int seed, int default_dither)
     return 0;
 }
 
+/* The frame-parallel kernel runs the block when the core allows it (plan) and this call's windows do:
+ * every slot the core reads before storing must come from the caller, and the per-lane frames must fit */
+static bool wave_plan_fits(const avdsp_hip_prog *prog, const Plan &pl, const BlockIO &io, GenericArgs &a)
+{
+    if (!pl.wave_ok) return false;
+    const int span = std::max(pl.io_span, std::max(io.in_base + io.in_stride, io.out_base + io.out_stride));
+    if (span > 256) return false;
+    for (int s = 0; s < 256; s++)
+        if (pl.carried_io[s >> 5] >> (s & 31) & 1u) {
+            const bool in_win = s >= io.in_base && s < io.in_base + io.in_stride;
+            const bool out_win = s >= io.out_base && s < io.out_base + io.out_stride;
+            if (!in_win && !out_win) return false;
+        }
+    const size_t words = (size_t)span * 64 + prog->total_words + 2 + 128 + (size_t)a.nvm * 128 + a.seq_words;
+    if (words * 4 > kGenericLdsMax) return false;
+    a.wave_span = span;
+    a.frame_lds = span * 64;
+    a.stage_words = prog->total_words; a.keep_words = (int)(sizeof(dspHeader_t) / 4);
+    a.batch_lds = a.frame_lds + a.stage_words + 2;
+    return true;
+}
+
 static int launch_generic(avdsp_hip_prog *prog, Plan &pl, BlockIO io, hipStream_t stream)
 {
-    ProfileScope scope(prog, stream, AVDSP_KERNEL_GENERIC);
     GenericArgs a = pl.ga;
     a.io = io;
     const dim3 grid(1), block(64);
+    if (wave_plan_fits(prog, pl, io, a)) {
+        ProfileScope scope(prog, stream, AVDSP_KERNEL_GENERIC_WAVE);
+        const size_t lds = ((size_t)a.batch_lds + 128 + (size_t)a.nvm * 128 + a.seq_words) * 4;
+        switch (pl.format) {
+        case 2:  hipLaunchKernelGGL((interp_wave<2>), grid, block, lds, stream, a); break;
+        case 3:  hipLaunchKernelGGL((interp_wave<3>), grid, block, lds, stream, a); break;
+        case 4:  hipLaunchKernelGGL((interp_wave<4>), grid, block, lds, stream, a); break;
+        case 5:  hipLaunchKernelGGL((interp_wave<5>), grid, block, lds, stream, a); break;
+        default: hipLaunchKernelGGL((interp_wave<6>), grid, block, lds, stream, a); break;
+        }
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+    ProfileScope scope(prog, stream, AVDSP_KERNEL_GENERIC);
 #define AVDSP_LAUNCH_INTERP(F) \
     if (pl.ga_staged) hipLaunchKernelGGL((interp_core<F, true>), grid, block, pl.ga_lds, stream, a); \
     else              hipLaunchKernelGGL((interp_core<F, false>), grid, block, pl.ga_lds, stream, a)
@@ -1281,10 +1329,12 @@ int avdsp_hip_run_block(avdsp_hip_prog *prog, int plan, const void *d_in, int in
     if (plan < 0 || plan >= (int)prog->plans.size()) return set_err("bad plan id %d", plan);
     Plan &pl = prog->plans[plan];
     if (nframes <= 0) return 0;
-    /* the kernels index the sample blocks with the chains' IO numbers: check the windows once here */
-    if (pl.io_in_max >= pl.io_in_min && (pl.io_in_min < in_io_base || pl.io_in_max >= in_io_base + in_stride))
+    /* the chain kernels index the sample blocks with the chains' IO numbers: check the windows once here.
+     * (The interpreter keeps a whole samples[] frame: slots outside the caller's windows are the frame's
+     * own, persistent like the host's array, e.g. values one strand leaves for the next frame.) */
+    if (!pl.generic && pl.io_in_max >= pl.io_in_min && (pl.io_in_min < in_io_base || pl.io_in_max >= in_io_base + in_stride))
         return set_err("input window IO [%d,%d) does not cover the IOs the core loads [%d,%d]", in_io_base, in_io_base + in_stride, pl.io_in_min, pl.io_in_max);
-    if (pl.io_out_max >= pl.io_out_min && (pl.io_out_min < out_io_base || pl.io_out_max >= out_io_base + out_stride))
+    if (!pl.generic && pl.io_out_max >= pl.io_out_min && (pl.io_out_min < out_io_base || pl.io_out_max >= out_io_base + out_stride))
         return set_err("output window IO [%d,%d) does not cover the IOs the core stores [%d,%d]", out_io_base, out_io_base + out_stride, pl.io_out_min, pl.io_out_max);
     if (pl.generic) {
         /* the scratch frame is indexed by IO number: both windows must lie inside it */

@@ -66,6 +66,15 @@ typedef struct avdsp_generic_desc {
     uint32_t delay_line_factor;      /* 2^32 * fs / 10^6, :82-90,108                             */
     int32_t  io_span;                /* highest IO number the core touches + 1                   */
     int32_t  io_in_min, io_in_max, io_out_min, io_out_max;   /* for the window check (max < min = none) */
+    /* Frame-parallel execution (avdsp_interp.inc, interp_wave: 64 frames of a block side by side, one per
+     * lane).  wave_ok = the host found nothing that one frame hands to the next outside opcode-private
+     * state; the remaining condition is checked per block call, against the caller's windows:           */
+    int32_t  wave_ok;
+    uint32_t carried_io[8];          /* bit io: the core reads samples[io] before it stores it; such a slot must lie
+                                        in the block's input or output window (else it is last frame's value)   */
+    int32_t  nvm, vm_word[16];       /* mirror words written and read back inside one frame (STORE_MEM -> LOAD_MEM,
+                                        LOAD_MUX / TPDF result -> LOAD_MEM_DATA): kept per lane                */
+    int32_t  seq_words;              /* longest DSP_FIR impulse + 64 (0 = no FIR)                              */
 } avdsp_generic_desc;
 
 /* A loaded program on the device: the mirror of the caller's buffer plus one plan per lowered core */
@@ -115,7 +124,7 @@ int avdsp_hip_run_block_pcm_host(avdsp_hip_prog *prog, int plan, int pcm, const 
 /* Per-kernel timing: when enabled, every kernel launch of run_block is bracketed by a HIP event pair
  * recorded on the launch stream; profile_read waits for the recorded pairs of one kind, returns
  * the summed duration and the number of launches, and forgets them.                              */
-enum { AVDSP_KERNEL_BIQUAD = 0, AVDSP_KERNEL_FIR = 1, AVDSP_KERNEL_PASS = 2, AVDSP_KERNEL_GENERIC = 3, AVDSP_KERNEL_UNPACK = 4 };
+enum { AVDSP_KERNEL_BIQUAD = 0, AVDSP_KERNEL_FIR = 1, AVDSP_KERNEL_PASS = 2, AVDSP_KERNEL_GENERIC = 3, AVDSP_KERNEL_UNPACK = 4, AVDSP_KERNEL_GENERIC_WAVE = 5 };
 int avdsp_hip_profile_enable(avdsp_hip_prog *prog, int on);
 int avdsp_hip_profile_read(avdsp_hip_prog *prog, int kind, double *total_ms, int *launches);
 

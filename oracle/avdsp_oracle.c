@@ -624,14 +624,15 @@ int oracle_run(oracle_ctx *c, opcode_t *core, int *rundata, void *samples)
     return rc;
 }
 
-int oracle_run_block(oracle_ctx *c, opcode_t *core, int *rundata,
-                     const void *in, int in_stride, int in_io_base,
-                     void *out, int out_stride, int out_io_base,
-                     int nframes, int scratch_len)
+/* the host loop over one block with the caller's samples[] array: what the frame holds outside the two
+ * windows stays from frame to frame and from call to call (linux/avdsp_plugin.c:93 inputOutput[]) */
+int oracle_run_block_frame(oracle_ctx *c, opcode_t *core, int *rundata,
+                           const void *in, int in_stride, int in_io_base,
+                           void *out, int out_stride, int out_io_base,
+                           int nframes, void *frame)
 {
     /* samples are 32 bits wide in every format, so the gather/scatter is format-agnostic */
-    uint32_t *scratch = (uint32_t *)calloc((size_t)scratch_len, 4);
-    if (!scratch) return -1;
+    uint32_t *scratch = (uint32_t *)frame;
     const uint32_t *src = (const uint32_t *)in;
     uint32_t *dst = (uint32_t *)out;
     for (int n = 0; n < nframes; n++) {
@@ -640,6 +641,17 @@ int oracle_run_block(oracle_ctx *c, opcode_t *core, int *rundata,
         oracle_run(c, core, rundata, scratch);
         memcpy(dst + (size_t)n * out_stride, scratch + out_io_base, (size_t)out_stride * 4);
     }
-    free(scratch);
     return 0;
+}
+
+int oracle_run_block(oracle_ctx *c, opcode_t *core, int *rundata,
+                     const void *in, int in_stride, int in_io_base,
+                     void *out, int out_stride, int out_io_base,
+                     int nframes, int scratch_len)
+{
+    uint32_t *scratch = (uint32_t *)calloc((size_t)scratch_len, 4);
+    if (!scratch) return -1;
+    int rc = oracle_run_block_frame(c, core, rundata, in, in_stride, in_io_base, out, out_stride, out_io_base, nframes, scratch);
+    free(scratch);
+    return rc;
 }

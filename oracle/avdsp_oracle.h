@@ -53,6 +53,11 @@ int oracle_run(oracle_ctx *ctx, opcode_t *core, int *rundata, void *samples);
  * samples[out_io_base + k].  Output slots the core never stores keep their previous content.
  * scratch_len = size of the scratch frame (must exceed every IO number the core touches).
  */
+/* same loop over a frame the caller keeps (slots outside the windows persist between frames and calls) */
+int oracle_run_block_frame(oracle_ctx *ctx, opcode_t *core, int *rundata,
+                           const void *in, int in_stride, int in_io_base,
+                           void *out, int out_stride, int out_io_base,
+                           int nframes, void *frame);
 int oracle_run_block(oracle_ctx *ctx, opcode_t *core, int *rundata,
                      const void *in, int in_stride, int in_io_base,
                      void *out, int out_stride, int out_io_base,

@@ -45,6 +45,8 @@ def lib() -> C.CDLL:
         L.oracle_run.restype = i32; L.oracle_run.argtypes = [vp, vp, vp, vp]
         L.oracle_run_block.restype = i32
         L.oracle_run_block.argtypes = [vp, vp, vp, vp, i32, i32, vp, i32, i32, i32, i32]
+        L.oracle_run_block_frame.restype = i32
+        L.oracle_run_block_frame.argtypes = [vp, vp, vp, vp, i32, i32, vp, i32, i32, i32, vp]
         L.oracle_mul_float_double.restype = f64; L.oracle_mul_float_double.argtypes = [f32, f32]
         L.oracle_mul_float_float.restype = f32; L.oracle_mul_float_float.argtypes = [f32, f32]
         L.oracle_int_to_float_scaled.restype = f32; L.oracle_int_to_float_scaled.argtypes = [i32, i32]
@@ -111,8 +113,11 @@ class OracleProgram:
 
     def run_block(self, x: np.ndarray, out_stride: int, in_io_base: int, out_io_base: int = 0,
                   scratch_len: int | None = None, block: int | None = None,
-                  out: np.ndarray | None = None) -> np.ndarray:
-        """Host loop of linux/avdsp_plugin.c:95-142: per block, cores outer, frames inner."""
+                  out: np.ndarray | None = None, frame: np.ndarray | None = None) -> np.ndarray:
+        """Host loop of linux/avdsp_plugin.c:95-142: per block, cores outer, frames inner.
+        `frame` (uint32, at least the IO span): the samples[] array kept by the caller, so that slots
+        outside the two windows persist from frame to frame, between cores and between calls; without
+        it every call starts from a zeroed frame."""
         x = np.ascontiguousarray(x, dtype=sample_dtype(self.fmt))
         nframes, in_stride = x.shape
         if out is None:
@@ -123,6 +128,13 @@ class OracleProgram:
         for b0 in range(0, nframes, block):
             b1 = min(b0 + block, nframes)
             for core in self.cores:
+                if frame is not None:
+                    assert frame.dtype == np.uint32 and frame.flags.c_contiguous
+                    self.L.oracle_run_block_frame(self.ctx, core, self.data_ptr,
+                                                  x[b0:b1].ctypes.data, in_stride, in_io_base,
+                                                  out[b0:b1].ctypes.data, out_stride, out_io_base,
+                                                  b1 - b0, frame.ctypes.data)
+                    continue
                 self.L.oracle_run_block(self.ctx, core, self.data_ptr,
                                         x[b0:b1].ctypes.data, in_stride, in_io_base,
                                         out[b0:b1].ctypes.data, out_stride, out_io_base,

@@ -1,0 +1,216 @@
+"""The frame-parallel form of the general interpreter (avdsp_interp.inc, interp_wave: 64 frames of a block
+side by side, one per lane) against the oracle: the forms that differ from the frame-by-frame code
+(delay lines of every length around the batch size, DELAY_1, DELAY_DP, cascades longer than a wave,
+DSP_FIR, per-lane memories, the TPDF sequence), block lengths around the batch size, and the host's
+eligibility analysis (avdsp_host.c scan_generic): cores that hand a value from one frame to the next
+must take the frame-by-frame kernel, and both must give the reference's result."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from avdsp_amd import encoder as enc, progbuilder as pb, runtime as rt
+from oracle import pyoracle as po
+from tests.fuzz_programs import _prototypes
+
+pytestmark = pytest.mark.gpu
+
+F48000 = 5
+IN = 32                     # input window: IO 32..39
+DSP_LOAD_MEM_DATA = 60      # dsp_header.h:126 (no emitter in the reference's encoder API)
+FPEAK = 74
+KIND_SCALAR, KIND_WAVE = 3, 5
+
+
+def encode(build, fmt, max_io=48):
+    L = enc.lib()
+    _prototypes(L)
+    return enc.encode(lambda lib: build(lib), 2 if fmt == 2 else 6, F48000, F48000, max_io=max_io, capacity=1 << 15)
+
+
+def run_both(fmt, prog, x, out_stride, in_base, out_base, block, expect_wave, span=48, impl=1):
+    """device vs oracle, both with a persistent samples[] frame; returns (wave launches, scalar launches)"""
+    o = po.OracleProgram(fmt, prog, fs=48000, random=11, dither=24)
+    r = rt.Runtime(fmt, prog, fs=48000, random=11, dither=24)
+    assert r.rc == o.rc and r.rc > 0
+    r.set_option("interp_impl", impl)
+    r.set_option("profile", 1)
+    try:
+        frame = np.zeros(max(span, 4096), dtype=np.uint32)
+        want = o.run_block(x, out_stride, in_base, out_base, block=block, frame=frame)
+        got = r.run_block(x, out_stride, in_base, out_base, block=block)
+        wave, scalar = r.kernel_time(KIND_WAVE)[1], r.kernel_time(KIND_SCALAR)[1]
+        bad = np.nonzero((got.view(np.uint32) != want.view(np.uint32)).any(axis=0))[0]
+        first = np.nonzero((got.view(np.uint32) != want.view(np.uint32)).any(axis=1))[0]
+        assert bad.size == 0, f"DSP_FORMAT {fmt} block {block}: output columns {list(bad)} differ from frame {first[0]}"
+        r.sync_state()
+        n = int(prog[1]) + int(prog[2])
+        words = np.nonzero(r.buf[12:n] != o.buf[12:n])[0] + 12
+        assert words.size == 0, f"DSP_FORMAT {fmt} block {block}: buffer words {list(words[:8])} differ after the run"
+        if expect_wave is True:
+            assert wave > 0 and scalar == 0, (wave, scalar)
+        elif expect_wave is False:
+            assert wave == 0 and scalar > 0, (wave, scalar)
+        return wave, scalar
+    finally:
+        r.set_option("profile", 0)
+        r.set_option("interp_impl", 1)
+        r.release()
+
+
+def forms_program(fmt):
+    rng = np.random.default_rng(7)
+    taps = {n: rng.uniform(-0.2, 0.2, n).astype(np.float32) for n in (1, 5, 64, 100, 300)}
+
+    def build(L):
+        L.dsp_PARAM()
+        big = L.dspBiquad_Sections(70)                      # longer than a wave: two passes of the section pipeline
+        for k in range(70):
+            L.dsp_Filter2ndOrder(FPEAK, 100.0 + 97.0 * k, 0.7 + 0.01 * k, 1.0 + 0.002 * (k % 5 - 2))
+        small = L.dspBiquad_Sections(3)
+        for k in range(3):
+            L.dsp_Filter2ndOrder(FPEAK, 300.0 * (k + 1), 1.2, 0.9)
+        dly = L.dspDelay_MicroSec_Max_Default(5000, 4167)   # 200 samples
+        firs = {}
+        if fmt != 2:
+            for n, t in taps.items():
+                firs[n] = L.dspFir_Impulses()
+                L.dspFir_ImpulseData(t.ctypes.data_as(C.POINTER(C.c_float)), n)
+        fdel = L.dspFir_Impulses()
+        L.dspFir_Delay(10)                                   # DSP_FIR used as a plain delay (:940-955)
+        mux = L.dspLoadMux_Inputs(2)
+        L.dspLoadMux_Data(IN + 0, 0.3)
+        L.dspLoadMux_Data(IN + 7, -0.3)
+        mem = L.dspMem_LocationMultiple(2)
+
+        L.dsp_CORE()
+        L.dsp_TPDF_CALC(0)
+        for k, us in enumerate((21, 1312, 1334, 1355)):      # 1, 62, 64, 65 samples at 48 kHz
+            L.dsp_LOAD_GAIN_Fixed(IN + k, 0.5); L.dsp_DELAY_FixedMicroSec(us); L.dsp_STORE(k)
+        L.dsp_LOAD(IN + 4); L.dsp_DELAY(dly); L.dsp_SAT0DB_TPDF(); L.dsp_STORE(4)
+        L.dsp_LOAD(IN + 5)
+        for us in (21, 1334, 2100):
+            L.dsp_DELAY_DP_FixedMicroSec(us)
+        L.dsp_STORE(5)
+        L.dsp_LOAD_GAIN_Fixed(IN + 6, 0.25); L.dsp_BIQUADS(big); L.dsp_SAT0DB(); L.dsp_STORE(6)
+        L.dsp_LOAD(IN + 7); L.dsp_DELAY_1(); L.dsp_DELAY_1(); L.dsp_BIQUADS(small); L.dsp_SAT0DB(); L.dsp_STORE(7)
+        mux_result = L.dsp_LOAD_MUX(mux)
+        L.dsp_STORE_MEM_Index(mem, 1)
+        L.dsp_STORE(8)
+        L.dsp_LOAD_GAIN_Fixed(IN + 1, 0.5)
+        L.dsp_LOAD_MEM_Index(mem, 1)                         # written earlier in the frame: this frame's value
+        L.dsp_ADDXY(); L.dsp_SAT0DB(); L.dsp_STORE(9)
+        L.addCode((DSP_LOAD_MEM_DATA << 16) | 2); L.addCode(mux_result)
+        L.dsp_STORE(10)
+        L.dsp_LOAD(IN + 2); L.dsp_FIR(fdel); L.dsp_STORE(11)
+        for k, n in enumerate(sorted(firs)):
+            L.dsp_LOAD_GAIN_Fixed(IN + (k % 8), 0.5); L.dsp_FIR(firs[n]); L.dsp_SAT0DB_TPDF_GAIN_Fixed(0.9); L.dsp_STORE(12 + k)
+        L.dsp_LOAD(8)                                        # a slot stored earlier in this frame
+        L.dsp_GAIN_Fixed(0.5)
+        L.dsp_STORE(20)
+
+    return encode(build, fmt)
+
+
+@pytest.mark.parametrize("fmt", [2, 3, 4, 5, 6])
+@pytest.mark.parametrize("block", [1, 3, 64, 65, 130, 700])
+def test_frame_parallel_forms(fmt, block):
+    prog = forms_program(fmt)
+    nframes = 700 if block > 3 else 150
+    x = pb.lcg_input(nframes, 8, fmt in (5, 6), seed=3)
+    run_both(fmt, prog, x, 24, IN, 0, block, expect_wave=True)
+    # and the frame-by-frame kernel on the same program
+    if block in (3, 700):
+        run_both(fmt, prog, x, 24, IN, 0, block, expect_wave=False, impl=0)
+
+
+def carried_programs():
+    """name -> (builder, carried?) : what one frame leaves for the next, in every way the opcode set offers"""
+    def slot_feedback(L):                # IO 40 is read before it is stored: last frame's value
+        L.dsp_CORE()
+        L.dsp_LOAD(40); L.dsp_GAIN_Fixed(0.5); L.dsp_COPYXY()
+        L.dsp_LOAD_GAIN_Fixed(IN + 0, 0.5); L.dsp_ADDXY(); L.dsp_SAT0DB(); L.dsp_STORE(40); L.dsp_STORE(0)
+
+    def slot_feed_forward(L):            # stored, then loaded: this frame's value
+        L.dsp_CORE()
+        L.dsp_LOAD_GAIN_Fixed(IN + 0, 0.5); L.dsp_STORE(40); L.dsp_STORE(1)
+        L.dsp_LOAD(40); L.dsp_GAIN_Fixed(0.5); L.dsp_STORE(0)
+
+    def mem_feedback(L):                 # LOAD_MEM before the STORE_MEM of the same word
+        L.dsp_PARAM(); m = L.dspMem_Location()
+        L.dsp_CORE()
+        L.dsp_LOAD_GAIN_Fixed(IN + 1, 0.5); L.dsp_COPYXY(); L.dsp_LOAD_MEM(m); L.dsp_GAIN_Fixed(0.5); L.dsp_ADDXY()
+        L.dsp_SAT0DB(); L.dsp_STORE_MEM(m); L.dsp_STORE(0)
+
+    def mem_feed_forward(L):
+        L.dsp_PARAM(); m = L.dspMem_Location()
+        L.dsp_CORE()
+        L.dsp_LOAD_GAIN_Fixed(IN + 1, 0.5); L.dsp_STORE_MEM(m); L.dsp_STORE(1)
+        L.dsp_LOAD_GAIN_Fixed(IN + 2, 0.5); L.dsp_COPYXY(); L.dsp_LOAD_MEM(m); L.dsp_ADDXY(); L.dsp_SAT0DB(); L.dsp_STORE(0)
+
+    def mem_read_then_overwritten(L):    # reads this frame's value, then a later strand overwrites: still this frame's
+        L.dsp_PARAM(); m = L.dspMem_Location()
+        L.dsp_CORE()
+        L.dsp_LOAD_GAIN_Fixed(IN + 1, 0.5); L.dsp_STORE_MEM(m)
+        L.dsp_LOAD_MEM(m); L.dsp_STORE(0)
+        L.dsp_LOAD_GAIN_Fixed(IN + 2, 0.25); L.dsp_STORE_MEM(m)
+        L.dsp_LOAD_MEM(m); L.dsp_STORE(1)
+
+    def tpdf_calc_late(L):               # the dither value a SAT0DB_TPDF in front of TPDF_CALC sees is last frame's
+        L.dsp_CORE()
+        L.dsp_LOAD_GAIN_Fixed(IN + 0, 0.5); L.dsp_SAT0DB_TPDF(); L.dsp_STORE(0)
+        L.dsp_TPDF_CALC(16)
+        L.dsp_LOAD_GAIN_Fixed(IN + 1, 0.5); L.dsp_SAT0DB_TPDF(); L.dsp_STORE(1)
+
+    def tpdf_calc_first_other_width(L):  # first frame ever: no draw (dsp_tpdf.h:55-80), then one per frame
+        L.dsp_CORE()
+        t = L.dsp_TPDF_CALC(16)
+        L.dsp_STORE(2)
+        L.addCode((DSP_LOAD_MEM_DATA << 16) | 2); L.addCode(t); L.dsp_STORE(3)
+        L.dsp_LOAD_GAIN_Fixed(IN + 1, 0.5); L.dsp_SAT0DB_TPDF(); L.dsp_STORE(1)
+        L.dsp_WHITE(); L.dsp_STORE(0)
+
+    def two_cores_through_the_frame(L):  # core 2 reads what core 1 stored: block by block that is the last frame of
+        L.dsp_CORE()                     # core 1's block for every frame of core 2's (a constant for core 2)
+        L.dsp_LOAD_GAIN_Fixed(IN + 0, 0.5); L.dsp_DELAY_1(); L.dsp_STORE(41); L.dsp_STORE(0)
+        L.dsp_CORE()
+        L.dsp_LOAD(41); L.dsp_GAIN_Fixed(0.5); L.dsp_STORE(1)
+
+    return {
+        "slot_feedback": (slot_feedback, True), "slot_feed_forward": (slot_feed_forward, False),
+        "mem_feedback": (mem_feedback, True), "mem_feed_forward": (mem_feed_forward, False),
+        "mem_read_then_overwritten": (mem_read_then_overwritten, False),
+        "tpdf_calc_late": (tpdf_calc_late, True), "tpdf_calc_first_other_width": (tpdf_calc_first_other_width, False),
+        "two_cores_through_the_frame": (two_cores_through_the_frame, False),
+    }
+
+
+@pytest.mark.parametrize("name", sorted(carried_programs()))
+@pytest.mark.parametrize("fmt", [2, 3, 6])
+def test_carried_values_select_the_frame_by_frame_kernel(name, fmt):
+    build, carried = carried_programs()[name]
+    prog = encode(build, fmt)
+    x = pb.lcg_input(200, 8, fmt == 6, seed=9)
+    for block in (1, 50, 200):
+        run_both(fmt, prog, x, 24, IN, 0, block, expect_wave=not carried)
+
+
+@pytest.mark.parametrize("fmt", [2, 6])
+def test_windows_decide_per_call(fmt):
+    """A slot the core reads before storing it is the caller's when the call's windows contain it (each frame
+    starts from the caller's rows) and the frame's own otherwise: the same program takes either kernel."""
+    build, _ = carried_programs()["slot_feedback"]
+    prog = encode(build, fmt)
+    x = pb.lcg_input(200, 8, fmt == 6, seed=9)
+    run_both(fmt, prog, x, 24, IN, 0, 200, expect_wave=False)          # IO 40 outside [0,24) and [32,40)
+    run_both(fmt, prog, x, 41, IN, 0, 200, expect_wave=True)           # output window [0,41) holds IO 40
+
+
+def test_reference_programs_take_the_frame_parallel_kernel():
+    """The reference's own example programs (crossoverLV6, dacdiy1) carry nothing between frames."""
+    import os
+    from tests.golden_recipes import GOLDEN_DIR
+    for name, in_stride, in_base, out_stride in (("crossoverLV6.bin", 16, 8, 32), ("dacdiy1.bin", 16, 8, 32)):
+        prog = np.fromfile(os.path.join(GOLDEN_DIR, name), dtype=np.uint32)
+        x = pb.lcg_input(300, in_stride, False, seed=5)
+        run_both(2, prog, x, out_stride, in_base, 0, 300, expect_wave=True, span=64)
