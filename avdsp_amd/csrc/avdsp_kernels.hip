@@ -1173,7 +1173,7 @@ int avdsp_hip_prog_add_generic(avdsp_hip_prog *prog, const avdsp_generic_desc *d
         for (int k = 0; k < 8; k++) pl.carried_io[k] = d->carried_io[k];
         a.nvm = d->nvm;
         for (int k = 0; k < d->nvm; k++) a.vm_word[k] = d->vm_word[k];
-        a.seq_words = std::max(d->seq_words, 128);
+        a.seq_words = std::max(d->seq_words, 256);      /* also parks the persistent frame (<= 256 slots) at start */
         const void *fn = d->format == 2 ? (const void *)interp_wave<2> : d->format == 3 ? (const void *)interp_wave<3>
                        : d->format == 4 ? (const void *)interp_wave<4> : d->format == 5 ? (const void *)interp_wave<5>
                                                                                         : (const void *)interp_wave<6>;
@@ -1213,10 +1213,10 @@ static bool wave_plan_fits(const avdsp_hip_prog *prog, const Plan &pl, const Blo
             const bool out_win = s >= io.out_base && s < io.out_base + io.out_stride;
             if (!in_win && !out_win) return false;
         }
-    const size_t words = (size_t)span * 64 + prog->total_words + 2 + 128 + (size_t)a.nvm * 128 + a.seq_words;
+    const size_t words = (size_t)span * interp::kLanePitch + prog->total_words + 2 + 128 + (size_t)a.nvm * 128 + a.seq_words;
     if (words * 4 > kGenericLdsMax) return false;
     a.wave_span = span;
-    a.frame_lds = span * 64;
+    a.frame_lds = span * interp::kLanePitch;
     a.stage_words = prog->total_words; a.keep_words = (int)(sizeof(dspHeader_t) / 4);
     a.batch_lds = a.frame_lds + a.stage_words + 2;
     return true;

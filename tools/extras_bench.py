@@ -46,21 +46,29 @@ def interpreter():
                               ("tour_float.bin", 3, 48000)):
         prog = np.fromfile(os.path.join(gold, name), dtype=np.uint32)
         tour = name.startswith("tour")
-        r = rt.Runtime(fmt, prog, fs=48000, random=1, dither=24)
         x = pb.lcg_input(frames, 16, fmt in (5, 6), seed=5)
         in_base, out_stride = (32, 32) if tour else (8, 32)
-        r.run_block(x[:64], out_stride, in_base)                         # plans, staging buffers
-        r.set_option("profile", 1)
-        r.kernel_time(3)
-        t0 = time.perf_counter()
-        r.run_block(x, out_stride, in_base)
-        wall = time.perf_counter() - t0
-        ms, k = r.kernel_time(3)
-        print(f"interp {name:18s} fmt {fmt}: {len(r.cores)} cores, {frames} frames: kernels {ms:8.2f} ms "
-              f"({ms * 1e3 / frames:6.2f} us/frame, {frames / (ms * 1e-3) / 48000:6.1f}x real time at 48 kHz), wall {wall * 1e3:.1f} ms")
-        r.L.dspRuntimeRelease()
+        for impl, label in ((1, "frame-parallel"), (0, "frame by frame")):
+            r = rt.Runtime(fmt, prog, fs=48000, random=1, dither=24)
+            r.set_option("interp_impl", impl)
+            r.run_block(x[:64], out_stride, in_base)                         # plans, staging buffers
+            r.set_option("profile", 1)
+            r.kernel_time(3); r.kernel_time(5)
+            t0 = time.perf_counter()
+            r.run_block(x, out_stride, in_base)
+            wall = time.perf_counter() - t0
+            ms3, k3 = r.kernel_time(3)
+            ms5, k5 = r.kernel_time(5)
+            ms = ms3 + ms5
+            print(f"interp {name:18s} fmt {fmt} {label:15s}: {len(r.cores)} cores, {frames} frames: kernels {ms:8.2f} ms "
+                  f"({ms * 1e3 / frames:6.3f} us/frame, {frames / (ms * 1e-3) / 48000:7.1f}x real time at 48 kHz; "
+                  f"launches frame-parallel {k5} / frame by frame {k3}), wall {wall * 1e3:.1f} ms")
+            r.set_option("profile", 0)
+            r.set_option("interp_impl", 1)
+            r.L.dspRuntimeRelease()
 
 
 if __name__ == "__main__":
-    unpack()
+    if "interp" not in sys.argv[1:]:
+        unpack()
     interpreter()
