@@ -1204,7 +1204,7 @@ int avdsp_hip_tpdf_reset(avdsp_hip_prog *prog, int seed, int default_dither)
  * every slot the core reads before storing must come from the caller, and the per-lane frames must fit */
 static bool wave_plan_fits(const avdsp_hip_prog *prog, const Plan &pl, const BlockIO &io, GenericArgs &a)
 {
-    if (!pl.wave_ok) return false;
+    if (!pl.wave_ok || io.nframes < 2) return false;     /* a single frame (dspRuntime_N) has nothing to put side by side */
     const int span = std::max(pl.io_span, std::max(io.in_base + io.in_stride, io.out_base + io.out_stride));
     if (span > 256) return false;
     for (int s = 0; s < 256; s++)

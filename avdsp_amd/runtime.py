@@ -170,6 +170,12 @@ class Runtime:
     def set_option(self, key: str, value: int):
         self._check(self.L.dspRuntimeSetOption(key.encode(), value))
 
+    @staticmethod
+    def set_global_option(key: str, value: int):
+        """dspRuntimeSetOption without a loaded program (options are process-wide, like the library's state)."""
+        if lib().dspRuntimeSetOption(key.encode(), value) < 0:
+            raise AvdspError(-1, f"unknown option {key!r}")
+
     def core_info(self, core_index: int = 0):
         a, b, c = C.c_int(), C.c_int(), C.c_int()
         self._check(self.L.dspRuntimeCoreInfo(self.fmt, self.cores[core_index], C.byref(a), C.byref(b), C.byref(c)))

@@ -71,14 +71,20 @@ int       dspQM32(double x, int m);         /* dsp_header.c:83-85 */
  *     dspRuntime_N(core, rundata, samples)
  *     out[n*out_stride + k]    = samples[out_io_base + k]     k in [0, out_stride)
  * Output slots the core never stores are left untouched.  in/out are HOST pointers here.
- * The two windows must not overlap in IO numbers (a single frame through dspRuntime_N, where both
- * are the caller's samples[] array, is the exception).
+ * For the chain kernels the two windows must not overlap in IO numbers and must contain every IO the
+ * core loads / stores.  The interpreter keeps a whole samples[] array per program, persistent like the
+ * host's: slots outside the two windows are the program's own (values one core leaves for another, or
+ * one frame for the next), and where the windows overlap the input is laid over the output.
  *
  * Two device paths sit behind these entry points.  A core that is a set of independent
  * LOAD|LOAD_GAIN -> BIQUADS* -> [FIR] -> [SAT0DB] -> STORE+ chains (formats 2, 4, 6) runs on the
  * parallel kernels (section-pipelined cascade, MFMA FIR).  Any other core -- X/Y arithmetic, TPDF
  * dither, delay lines, LOAD_MUX, RMS ..., and every core in formats 3 and 5 -- runs through the
- * general device interpreter, which is sequential over frames like the reference.  There is no CPU path. */
+ * general device interpreter.  Its frame-parallel kernel runs 64 frames of the block side by side (one
+ * per lane, opcode by opcode) whenever the core hands nothing from one frame to the next except
+ * opcode-private state (delay lines, filter state, meters ...), which is the case for every program
+ * shipped with the reference; a core that does (a frame slot or memory read before it is written, a
+ * TPDF_CALC behind its first use) runs frame by frame like the reference.  There is no CPU path. */
 int dspRuntimeBlock_2(opcode_t *core, int *rundata, const int *in, int in_stride, int in_io_base,
                       int *out, int out_stride, int out_io_base, int nframes);
 int dspRuntimeBlock_3(opcode_t *core, int *rundata, const int *in, int in_stride, int in_io_base,
@@ -115,12 +121,15 @@ int dspRuntimeUploadState(const int *rundata);
 int dspRuntimeUploadParams(void);
 
 /* Tunables: "fir_impl" 0 = plain tap loop, 1 = MFMA (default); "biquad_impl" 0 = lane per channel,
- * 1 = section-pipelined (default); "device" = HIP device ordinal (before the first block).      */
+ * 1 = section-pipelined (default); "interp_impl" 0 = interpreter always frame by frame, 1 = frame-parallel
+ * where the core allows it (default); "generic" 1 = every core through the interpreter;
+ * "device" = HIP device ordinal (before the first block).                                        */
 int dspRuntimeSetOption(const char *key, int value);
 int dspRuntimeGetOption(const char *key);
 
 /* Kernel timing with HIP events on the launch stream: enable with dspRuntimeSetOption("profile", 1);
- * kind 0 = biquad cascade, 1 = FIR, 2 = pass-through, 3 = general interpreter, 4 = PCM unpack.  Returns the summed duration (ms) and launch
+ * kind 0 = biquad cascade, 1 = FIR, 2 = pass-through, 3 = general interpreter frame by frame,
+ * 4 = PCM unpack, 5 = general interpreter frame-parallel.  Returns the summed duration (ms) and launch
  * count of the launches recorded since the previous read.                                        */
 int dspRuntimeKernelTime(int kind, double *total_ms, int *launches);
 

@@ -231,12 +231,22 @@ def test_golden_general_interpreter(case):
         r.set_option("generic", 0)
 
 
+@pytest.mark.parametrize("interp_impl", [1, 0], ids=["frame_parallel", "frame_by_frame"])
 @pytest.mark.parametrize("seed", list(range(12, 72)) + [344, 373, 416, 462, 2260])     # the last five: NaN payloads through float / double adds
-def test_random_programs_vs_oracle(seed):
+def test_random_programs_vs_oracle(seed, interp_impl):
     """More random programs than there are goldens: the interpreter against the oracle (itself held to the
     compiled reference on these generators, tests/golden/make_goldens.py and 800+ runs while developing),
-    all five arithmetic models, outputs and the whole buffer (state, STORE_MEM targets) bit for bit."""
+    all five arithmetic models, outputs and the whole buffer (state, STORE_MEM targets) bit for bit; with
+    the frame-parallel kernel wherever the host finds a core eligible, and frame by frame throughout."""
     from tests.fuzz_programs import IN_BASE, N_IN, N_OUT, random_program
+    rt.Runtime.set_global_option("interp_impl", interp_impl)
+    try:
+        _random_programs(seed, IN_BASE, N_IN, N_OUT, random_program)
+    finally:
+        rt.Runtime.set_global_option("interp_impl", 1)
+
+
+def _random_programs(seed, IN_BASE, N_IN, N_OUT, random_program):
     for fmt in (2, 3, 4, 5, 6):
         prog = random_program(seed, fmt)
         fs, block = [48000, 48000, 96000][seed % 3], [1, 64, 500][seed % 3]

@@ -118,7 +118,7 @@ def test_frame_parallel_forms(fmt, block):
     prog = forms_program(fmt)
     nframes = 700 if block > 3 else 150
     x = pb.lcg_input(nframes, 8, fmt in (5, 6), seed=3)
-    run_both(fmt, prog, x, 24, IN, 0, block, expect_wave=True)
+    run_both(fmt, prog, x, 24, IN, 0, block, expect_wave=True if block > 1 else False)    # single frames: frame by frame
     # and the frame-by-frame kernel on the same program
     if block in (3, 700):
         run_both(fmt, prog, x, 24, IN, 0, block, expect_wave=False, impl=0)
@@ -191,7 +191,7 @@ def test_carried_values_select_the_frame_by_frame_kernel(name, fmt):
     build, carried = carried_programs()[name]
     prog = encode(build, fmt)
     x = pb.lcg_input(200, 8, fmt == 6, seed=9)
-    for block in (1, 50, 200):
+    for block in (2, 50, 200):
         run_both(fmt, prog, x, 24, IN, 0, block, expect_wave=not carried)
 
 
