@@ -95,13 +95,21 @@ void dspRuntimeRelease(void)
     G.have_rate = 0;
 }
 
+/* a tunable that changes how cores are lowered: forget the plans, keep the device copy (state, TPDF globals) */
+static int replan(void)
+{
+    if (G.dev && avdsp_hip_prog_clear_plans(G.dev)) return fail(-10, "%s", avdsp_hip_last_error());
+    G.nplans = 0;
+    return 0;
+}
+
 int dspRuntimeSetOption(const char *key, int value)
 {
     if (!strcmp(key, "fir_impl"))    { G.opt_fir_impl = value; return 0; }
     if (!strcmp(key, "biquad_impl")) { G.opt_biquad_impl = value; return 0; }
     if (!strcmp(key, "device"))      { G.opt_device = value; G.device_selected = 0; return 0; }
-    if (!strcmp(key, "generic"))     { G.opt_generic = value; drop_device(); return 0; }
-    if (!strcmp(key, "interp_impl")) { G.opt_interp_impl = value; drop_device(); return 0; }
+    if (!strcmp(key, "generic"))     { G.opt_generic = value; return replan(); }
+    if (!strcmp(key, "interp_impl")) { G.opt_interp_impl = value; return replan(); }
     if (!strcmp(key, "profile")) {
         G.opt_profile = value;
         if (G.dev) avdsp_hip_profile_enable(G.dev, value);

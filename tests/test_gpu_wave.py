@@ -214,3 +214,25 @@ def test_reference_programs_take_the_frame_parallel_kernel():
         prog = np.fromfile(os.path.join(GOLDEN_DIR, name), dtype=np.uint32)
         x = pb.lcg_input(300, in_stride, False, seed=5)
         run_both(2, prog, x, out_stride, in_base, 0, 300, expect_wave=True, span=64)
+
+
+def test_switching_kernels_mid_stream_keeps_the_state():
+    """dspRuntimeSetOption("interp_impl" / "generic") between blocks only re-lowers the cores: delay lines,
+    filter state, dither generator and the persistent frame stay on the device."""
+    fmt = 6
+    prog = forms_program(fmt)
+    x = pb.lcg_input(600, 8, True, seed=4)
+    o = po.OracleProgram(fmt, prog, fs=48000, random=11, dither=24)
+    frame = np.zeros(4096, dtype=np.uint32)
+    want = o.run_block(x, 24, IN, 0, block=100, frame=frame)
+    r = rt.Runtime(fmt, prog, fs=48000, random=11, dither=24)
+    try:
+        got = np.zeros_like(want)
+        for k, b0 in enumerate(range(0, 600, 100)):
+            r.set_option("interp_impl", k % 2)
+            got[b0:b0 + 100] = r.run_block(x[b0:b0 + 100], 24, IN, 0)
+        assert (got.view(np.uint32) == want.view(np.uint32)).all()
+        assert (r.sync_state() == o.state).all()
+    finally:
+        r.set_option("interp_impl", 1)
+        r.release()
