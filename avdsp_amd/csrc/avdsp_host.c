@@ -135,7 +135,11 @@ opcode_t *dspFindCore(opcode_t *codePtr, const int numCore)
     if (codePtr->op.opcode != DSP_HEADER) return 0;
     opcode_t *p = codePtr;
     int seen = 0;
+    /* the reference follows the skips wherever they lead; inside the loaded program the walk is kept inside it
+     * (a damaged skip ends the search instead of reading past the caller's buffer) */
+    const opcode_t *end = (dspHeaderPtr && codePtr == G.code) ? G.code + dspHeaderPtr->totalLength : 0;
     for (;;) {
+        if (end && p >= end) return 0;
         unsigned skip = p->op.skip;
         if (skip == 0) return seen == 0 ? codePtr : 0;
         if (p->op.opcode == DSP_CORE && ++seen == numCore) return p;
@@ -146,11 +150,13 @@ opcode_t *dspFindCore(opcode_t *codePtr, const int numCore)
 /* ---- dsp_runtime.c:62-77 ---- */
 opcode_t *dspFindCoreBegin(opcode_t *p)
 {
+    const opcode_t *end = (dspHeaderPtr && G.code && p >= G.code && p < G.code + dspHeaderPtr->totalLength)
+                              ? G.code + dspHeaderPtr->totalLength : 0;        /* as in dspFindCore */
     if (p && p->op.opcode == DSP_CORE)
         for (;;) {
             unsigned skip = p->op.skip;
             int op = p->op.opcode;
-            if (skip == 0) return p;
+            if (skip == 0 || (end && p + skip >= end)) return p;
             if (op == DSP_CORE || op == DSP_NOP || op == DSP_PARAM || op == DSP_PARAM_NUM) p += skip;
             else break;
         }
@@ -277,6 +283,8 @@ static int check_independent(const lowered *L)
     return rc;
 }
 
+#define GENERIC_IO_LIMIT 65536            /* IO numbers a program may use (the reference's hosts use well under 100) */
+
 static int lower_core(int format, opcode_t *core, lowered *L)
 {
     const int float_alu = (format != DSP_FORMAT_INT64);
@@ -296,12 +304,22 @@ static int lower_core(int format, opcode_t *core, lowered *L)
         const unsigned skip = p->op.skip;
         const int *a = (const int *)p + 1;
         const int at = (int)(p - G.code);
+        if (at < 0 || at >= prog_words) return fail(-8, "opcode stream runs past the program (word %d)", at);
         if (skip == 0 || op == DSP_CORE) break;              /* dsp_runtime.c:321-331 */
+        if ((long long)at + skip > prog_words) return fail(-8, "word %d: opcode longer than the program", at);
+        /* the encoder is trusted by the reference; here nothing is dereferenced before it is known to lie inside
+         * the program (the device library checks the word indices of the finished plan once more) */
+#define LC_NEED(n) do { if ((unsigned)(1 + (n)) > skip) return fail(-8, "word %d: opcode payload shorter than %d words", at, (n)); } while (0)
+#define LC_PROG(off, n) do { long long lo_ = (long long)at + (off); if (lo_ < 0 || lo_ + (n) > prog_words) \
+            return fail(-8, "word %d: program offset %d (+%d) outside the program", at, (int)(off), (int)(n)); } while (0)
         switch (op) {
         case DSP_NOP: case DSP_PARAM: case DSP_PARAM_NUM: case DSP_SERIAL:
             break;
         case DSP_LOAD:                                        /* :565-583 */
         case DSP_LOAD_GAIN:                                   /* :586-607 */
+            LC_NEED(op == DSP_LOAD_GAIN ? 2 : 1);
+            if (op == DSP_LOAD_GAIN) LC_PROG(a[1], 1);
+            if (a[0] < 0 || a[0] >= GENERIC_IO_LIMIT) return fail(-8, "word %d: IO number %d outside [0,%d)", at, a[0], GENERIC_IO_LIMIT);
             if (open) {
                 if (cur.n_out == 0)
                     return fail(-8, "word %d: value replaced before any STORE (X/Y tricks are not lowered)", at);
@@ -319,8 +337,14 @@ static int lower_core(int format, opcode_t *core, lowered *L)
         case DSP_BIQUADS: {                                   /* :827-849 */
             if (!open || cur.n_out || cur.sat || cur.fir_taps)
                 return fail(-8, "word %d: BIQUADS outside the supported LOAD->BIQUADS->FIR->SAT0DB->STORE order", at);
+            LC_NEED(2);
+            LC_PROG(a[1], 2);
             const opcode_t *bank = p + a[1];
             int num = (short)bank[0].i32;                     /* callee takes `short num` */
+            if (num < 1) return fail(-8, "word %d: biquad bank with %d sections", at, num);
+            LC_PROG(a[1], G.biquad_offset + (num - 1) * dspBiquadFreqSkip + 5);
+            if (a[0] < 0 || (long long)a[0] + 6ll * num > dspHeaderPtr->dataSize)
+                return fail(-8, "word %d: data offset %d (+%d) outside the state area (%d words)", at, a[0], 6 * num, dspHeaderPtr->dataSize);
             if (bank[1].i32 != 0)                             /* 0 = bypass, :837 */
                 for (int s = 0; s < num; s++)
                     if (push_section(L, (int)(bank - G.code) + G.biquad_offset + s * dspBiquadFreqSkip,
@@ -334,13 +358,18 @@ static int lower_core(int format, opcode_t *core, lowered *L)
             if (!float_alu)
                 return fail(-8, "word %d: DSP_FIR in int64 mode is undefined behaviour in the reference "
                                 "(dsp_firSTD.h:8-35) and is not provided", at);
+            LC_NEED(G.num_freq + 1);
             int off = a[G.freq_index];
             if (off) {
+                LC_PROG(off, 1);
                 const opcode_t *imp = p + off;
                 int length = imp[0].i32;
                 if (length >> 16)
                     return fail(-8, "word %d: FIR pure-delay variant is not lowered yet", at);
                 if (length > 0) {
+                    LC_PROG(off, 1 + length);
+                    if (a[G.num_freq] < 0 || (long long)a[G.num_freq] + length > dspHeaderPtr->dataSize)
+                        return fail(-8, "word %d: data offset %d (+%d) outside the state area (%d words)", at, a[G.num_freq], length, dspHeaderPtr->dataSize);
                     if (cur.fir_taps) return fail(-8, "word %d: more than one FIR per chain", at);
                     cur.fir_taps = length;
                     cur.fir_coef_word = (int)(imp - G.code) + 1;
@@ -353,6 +382,8 @@ static int lower_core(int format, opcode_t *core, lowered *L)
             cur.sat = 1;
             break;
         case DSP_STORE:                                       /* :610-633 */
+            LC_NEED(1);
+            if (a[0] < 0 || a[0] >= GENERIC_IO_LIMIT) return fail(-8, "word %d: IO number %d outside [0,%d)", at, a[0], GENERIC_IO_LIMIT);
             if (!open) return fail(-8, "word %d: STORE without a LOAD", at);
             if (cur.n_out == AVDSP_MAX_STORES) return fail(-8, "word %d: more than %d STOREs in a chain", at, AVDSP_MAX_STORES);
             cur.out_io[cur.n_out++] = a[0];
@@ -367,6 +398,8 @@ static int lower_core(int format, opcode_t *core, lowered *L)
         if (cur.n_out == 0) return fail(-8, "core ends with a chain that is never stored");
         if (push_chain(L, &cur)) return fail(-9, "out of memory");
     }
+#undef LC_NEED
+#undef LC_PROG
     if (L->nchains == 0) return fail(-8, "core contains no LOAD..STORE chain");
     return check_independent(L);
 }
@@ -376,8 +409,6 @@ static int lower_core(int format, opcode_t *core, lowered *L)
  * general path: bounds-check every offset the interpreter will follow (dsp_runtime.c trusts the
  * encoder; a device kernel must not), collect the IO span, refuse what has no defined result
  * ---------------------------------------------------------------------------------------- */
-#define GENERIC_IO_LIMIT 65536
-
 /* Frame-parallel eligibility (avdsp_interp.inc, interp_wave): the device may run 64 frames of a block side
  * by side, opcode by opcode, only if nothing but opcode-private state passes from one frame to the next.
  * While the opcodes are walked in program order this records what a frame reads before it has written it:
@@ -493,6 +524,44 @@ static int gs_io(const gscan *s, int io, int is_out)
     return 0;
 }
 
+/* DSP_STORE_MEM is the one opcode that writes PROGRAM words (dsp_runtime.c:760-766).  The offsets checked here
+ * are only worth something if it cannot rewrite what they were checked against, so its target has to be a free
+ * word of a PARAM section: not the opcode stream, and not a parameter word some opcode reads as a count, an IO
+ * number or a length (biquad bank header, LOAD_MUX table, FIR impulse length).  map: 0 = opcode stream,
+ * 1 = free parameter word, 2 = structural parameter word; built over the whole program (all cores).      */
+static unsigned char *store_mem_map(void)
+{
+    const int total = dspHeaderPtr->totalLength, nf = G.num_freq;
+    unsigned char *map = (unsigned char *)calloc((size_t)total, 1);
+    if (!map) return 0;
+    const int *w = (const int *)G.code;
+    for (int pass = 0; pass < 2; pass++)
+        for (int at = 0; at < total;) {
+            const int op = (int)((unsigned)w[at] >> 16);
+            const int skip = w[at] & 0xFFFF;
+            if (skip == 0 || at + skip > total) break;
+            const int *a = w + at + 1;
+#define SM_MARK(x) do { long long x_ = (x); if (x_ >= 0 && x_ < total && map[x_] == 1) map[x_] = 2; } while (0)
+            if (pass == 0) {
+                if (op == DSP_PARAM || op == DSP_PARAM_NUM) memset(map + at + 1, 1, (size_t)(skip - 1));
+            } else if (op == DSP_BIQUADS && skip >= 3) {
+                SM_MARK((long long)at + a[1]); SM_MARK((long long)at + a[1] + 1);
+            } else if (op == DSP_LOAD_MUX && skip >= 3) {
+                const long long t = (long long)at + a[0];
+                if (t >= 0 && t < total) {
+                    const int n = (short)w[t];
+                    SM_MARK(t);
+                    for (int k = 0; k < n; k++) SM_MARK(t + 1 + 2 * k);
+                }
+            } else if (op == DSP_FIR && skip >= nf + 2) {
+                for (int f = 0; f < nf; f++) if (a[f]) SM_MARK((long long)at + a[f]);
+            }
+#undef SM_MARK
+            at += skip;
+        }
+    return map;
+}
+
 static int scan_generic(int format, opcode_t *core, avdsp_generic_desc *d)
 {
     if (format < 2 || format > 6) return fail(-1, "DSP_FORMAT %d is not one of 2..6", format);
@@ -502,6 +571,7 @@ static int scan_generic(int format, opcode_t *core, avdsp_generic_desc *d)
     const int alu_int = (format == DSP_FORMAT_INT64);
     const int nf = G.num_freq, fi = G.freq_index;
     gscan S;
+    unsigned char *smap = 0;                     /* store_mem_map(), built at the first STORE_MEM */
     memset(&S, 0, sizeof S);
     S.format = format; S.aw = (format == 3 || format == 5) ? 1 : 2;
     S.prog_words = dspHeaderPtr->totalLength; S.data_words = dspHeaderPtr->dataSize; S.d = d;
@@ -521,9 +591,9 @@ static int scan_generic(int format, opcode_t *core, avdsp_generic_desc *d)
         const unsigned skip = p->op.skip;
         const int *a = (const int *)p + 1;
         const int at = (int)(p - G.code);
-        if (at < 0 || at >= S.prog_words) return fail(-8, "opcode stream runs past the program (word %d)", at);
+        if (at < 0 || at >= S.prog_words) { free(smap); return fail(-8, "opcode stream runs past the program (word %d)", at); }
         if (skip == 0 || op == DSP_CORE || op == DSP_END_OF_CODE) break;
-        if ((long long)at + skip > S.prog_words) return fail(-8, "word %d: opcode longer than the program", at);
+        if ((long long)at + skip > S.prog_words) { free(smap); return fail(-8, "word %d: opcode longer than the program", at); }
         S.at = at; S.skip = skip;
         int rc = 0;
         switch (op) {
@@ -555,7 +625,16 @@ static int scan_generic(int format, opcode_t *core, avdsp_generic_desc *d)
         case DSP_LOAD_MEM:
             rc = gs_payload(&S, 1) || gs_prog(&S, a[0], S.aw); if (!rc) ws_mem_read(&S, at + a[0], 0); break;
         case DSP_STORE_MEM:
-            rc = gs_payload(&S, 1) || gs_prog(&S, a[0], S.aw); if (!rc) ws_mem_write(&S, at + a[0]); break;
+            rc = gs_payload(&S, 1) || gs_prog(&S, a[0], S.aw);
+            if (!rc) {
+                if (!smap && !(smap = store_mem_map())) { rc = fail(-9, "out of memory"); break; }
+                for (int k = 0; k < S.aw && !rc; k++)
+                    if (smap[at + a[0] + k] != 1)
+                        rc = fail(-8, "word %d: STORE_MEM target (word %d) is not a free word of a PARAM section: it would "
+                                      "rewrite %s", at, at + a[0] + k, smap[at + a[0] + k] ? "a count, IO number or length other opcodes rely on" : "the opcode stream");
+            }
+            if (!rc) ws_mem_write(&S, at + a[0]);
+            break;
         case DSP_TPDF_CALC:
             rc = gs_payload(&S, 2) || gs_data(&S, a[1], S.aw);
             if (!rc) {
@@ -657,9 +736,10 @@ static int scan_generic(int format, opcode_t *core, avdsp_generic_desc *d)
         default:
             rc = fail(-8, "word %d: unknown opcode %d", at, op);
         }
-        if (rc) return g_err_code;
+        if (rc) { free(smap); return g_err_code; }
         p += skip;
     }
+    free(smap);
     if (d->io_span == 0) d->io_span = 1;
     if (d->io_span > WAVE_IO_LIMIT) S.w.ok = 0;
     if (S.w.ok) ws_finish(&S);

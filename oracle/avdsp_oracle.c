@@ -580,6 +580,7 @@ int oracle_init(oracle_ctx *c, opcode_t *code, int maxSize, int fs, int random, 
  * the interpreter, instantiated once per arithmetic model
  * ---------------------------------------------------------------------------------------- */
 #define ORC_FMT 2
+#define ORC_STATE_INDEX(v, alloc) ((unsigned)(v) < (unsigned)(alloc) ? (v) : 0)
 #include "oracle_interp.inc"
 #undef ORC_FMT
 #define ORC_FMT 3
