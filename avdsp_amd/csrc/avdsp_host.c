@@ -41,11 +41,24 @@ const char *dspOpcodeText[DSP_MAX_OPCODE] = {
 /* dspQNM / dspQM64 / dspQM32 (dsp_header.c:75-85) live in avdsp_qformat.c, shared with the encoder library */
 
 /* ---- the one loaded program (the reference keeps the same things in file-scope statics) ---- */
+/* What a core reads and writes outside its opcode-private use of the frame: decides which cores of a program may
+ * run side by side (dspRuntimeBlockAll) and what an interpreter launch writes back.  Filled by scan_generic. */
+#define DEPS_MAX_RANGES 128
+typedef struct {
+    int      complete;                   /* 0: more than these tables hold, or a chain core: runs alone */
+    unsigned early_io[8], written_io[8]; /* frame slots (< 256) read before written in a frame / stored */
+    int      nwr, wr_word[64];           /* mirror words written as per-frame variables (STORE_MEM, result words) */
+    int      nrd, rd_word[64];           /* mirror words read before this core writes them in the frame */
+    int      nranges, range[DEPS_MAX_RANGES][2];   /* opcode-private state, mirror words [lo, hi) */
+    int      tpdf_calc, tpdf_user;
+} core_deps;
+
 typedef struct {
     opcode_t   *core;            /* key: the pointer the host passes (after dspFindCoreBegin) */
     int         format;
     int         plan_id;         /* id inside the device program, < 0 = lowering failed */
     int         nchains, max_sections, max_taps;      /* nchains 0 = general interpreter */
+    core_deps   deps;
 } core_plan;
 
 #define MAX_CORE_PLANS 64
@@ -421,7 +434,7 @@ static int lower_core(int format, opcode_t *core, lowered *L)
  *  - private state areas of two opcodes must not overlap (the encoder never shares them).               */
 #define WAVE_IO_LIMIT 256
 typedef struct {
-    int ok;
+    int ok, complete;
     unsigned char written[WAVE_IO_LIMIT], early[WAVE_IO_LIMIT];
     int nwr, wr_word[64];
     int nearly, early_word[64];
@@ -438,18 +451,18 @@ typedef struct {
 
 static void ws_read_io(gscan *s, int io)
 {
-    if (io < 0 || io >= WAVE_IO_LIMIT) { s->w.ok = 0; return; }
+    if (io < 0 || io >= WAVE_IO_LIMIT) { s->w.ok = s->w.complete = 0; return; }
     if (!s->w.written[io]) s->w.early[io] = 1;
 }
 static void ws_write_io(gscan *s, int io)
 {
-    if (io < 0 || io >= WAVE_IO_LIMIT) { s->w.ok = 0; return; }
+    if (io < 0 || io >= WAVE_IO_LIMIT) { s->w.ok = s->w.complete = 0; return; }
     s->w.written[io] = 1;
 }
 static void ws_mem_write(gscan *s, int word)
 {
     for (int k = 0; k < s->w.nwr; k++) if (s->w.wr_word[k] == word) return;
-    if (s->w.nwr == 64) { s->w.ok = 0; return; }
+    if (s->w.nwr == 64) { s->w.ok = s->w.complete = 0; return; }
     s->w.wr_word[s->w.nwr++] = word;
 }
 static void ws_mem_read(gscan *s, int word, int needs_writer)
@@ -462,14 +475,15 @@ static void ws_mem_read(gscan *s, int word, int needs_writer)
             d->vm_word[d->nvm++] = word;
             return;
         }
-    if (needs_writer) { s->w.ok = 0; return; }       /* LOAD_MEM_DATA of a word nothing in this frame has written yet */
-    if (s->w.nearly == 64) { s->w.ok = 0; return; }
+    if (needs_writer) s->w.ok = 0;                   /* LOAD_MEM_DATA of a word nothing in this frame has written yet */
+    for (int k = 0; k < s->w.nearly; k++) if (s->w.early_word[k] == word) return;
+    if (s->w.nearly == 64) { s->w.ok = s->w.complete = 0; return; }
     s->w.early_word[s->w.nearly++] = word;
 }
 static void ws_state(gscan *s, int off, long long n)
 {
     if (n <= 0) return;
-    if (s->w.nranges == 512) { s->w.ok = 0; return; }
+    if (s->w.nranges == 512) { s->w.ok = s->w.complete = 0; return; }
     s->w.range[s->w.nranges].lo = off; s->w.range[s->w.nranges].hi = off + n; s->w.nranges++;
 }
 static void ws_tpdf_user(gscan *s) { s->w.tpdf_user_seen = 1; }
@@ -496,6 +510,38 @@ static void ws_finish(gscan *s)
         if (off < 0) continue;
         for (int k = 0; k < w->nranges; k++) if (off < w->range[k].hi && off + s->aw > w->range[k].lo) { w->ok = 0; break; }
     }
+}
+
+static int cmp_range(const void *a, const void *b)
+{
+    const int *x = (const int *)a, *y = (const int *)b;
+    return (x[0] > y[0]) - (x[0] < y[0]);
+}
+
+/* what the core touches, for the device (what a launch writes back) and for dspRuntimeBlockAll (which cores may
+ * run side by side); state areas are merged: the encoder allocates them back to back */
+static void ws_export(const gscan *s, core_deps *dp)
+{
+    const wscan *w = &s->w;
+    memset(dp, 0, sizeof *dp);
+    dp->complete = w->complete;
+    for (int io = 0; io < WAVE_IO_LIMIT; io++) {
+        if (w->early[io]) dp->early_io[io >> 5] |= 1u << (io & 31);
+        if (w->written[io]) dp->written_io[io >> 5] |= 1u << (io & 31);
+    }
+    dp->nwr = w->nwr; memcpy(dp->wr_word, w->wr_word, sizeof dp->wr_word);
+    dp->nrd = w->nearly; memcpy(dp->rd_word, w->early_word, sizeof dp->rd_word);
+    dp->tpdf_calc = w->tpdf_calc_seen; dp->tpdf_user = w->tpdf_user_seen;
+    static int tmp[512][2];
+    for (int i = 0; i < w->nranges; i++) { tmp[i][0] = s->prog_words + (int)w->range[i].lo; tmp[i][1] = s->prog_words + (int)w->range[i].hi; }
+    qsort(tmp, (size_t)w->nranges, sizeof tmp[0], cmp_range);
+    int n = 0;
+    for (int i = 0; i < w->nranges; i++) {
+        if (n && tmp[i][0] <= dp->range[n - 1][1]) { if (tmp[i][1] > dp->range[n - 1][1]) dp->range[n - 1][1] = tmp[i][1]; continue; }
+        if (n == DEPS_MAX_RANGES) { dp->complete = 0; break; }
+        dp->range[n][0] = tmp[i][0]; dp->range[n][1] = tmp[i][1]; n++;
+    }
+    dp->nranges = n;
 }
 
 static int gs_payload(const gscan *s, int need)
@@ -562,7 +608,7 @@ static unsigned char *store_mem_map(void)
     return map;
 }
 
-static int scan_generic(int format, opcode_t *core, avdsp_generic_desc *d)
+static int scan_generic(int format, opcode_t *core, avdsp_generic_desc *d, core_deps *deps)
 {
     if (format < 2 || format > 6) return fail(-1, "DSP_FORMAT %d is not one of 2..6", format);
     if ((format == DSP_FORMAT_INT64) != (dspHeaderPtr->format != 0))
@@ -577,6 +623,7 @@ static int scan_generic(int format, opcode_t *core, avdsp_generic_desc *d)
     S.prog_words = dspHeaderPtr->totalLength; S.data_words = dspHeaderPtr->dataSize; S.d = d;
     memset(d, 0, sizeof *d);
     S.w.ok = G.opt_interp_impl != 0;
+    S.w.complete = 1;
     d->io_in_min = d->io_out_min = GENERIC_IO_LIMIT; d->io_in_max = d->io_out_max = -1;
     opcode_t *p = dspFindCoreBegin(core);
     d->format = format;
@@ -741,9 +788,24 @@ static int scan_generic(int format, opcode_t *core, avdsp_generic_desc *d)
     }
     free(smap);
     if (d->io_span == 0) d->io_span = 1;
-    if (d->io_span > WAVE_IO_LIMIT) S.w.ok = 0;
+    if (d->io_span > WAVE_IO_LIMIT) S.w.ok = S.w.complete = 0;
     if (S.w.ok) ws_finish(&S);
     d->wave_ok = S.w.ok;
+    core_deps local;
+    if (!deps) deps = &local;
+    ws_export(&S, deps);
+    /* for the device: what this core owns (written back after a launch; -1 = everything, the core runs alone) */
+    d->tpdf_calc = deps->tpdf_calc;
+    memcpy(d->early_io, deps->early_io, sizeof d->early_io);
+    memcpy(d->written_io, deps->written_io, sizeof d->written_io);
+    d->nown = -1;
+    if (deps->complete) {
+        static int32_t own[(DEPS_MAX_RANGES + 64) * 2];
+        int n = 0;
+        for (int i = 0; i < deps->nranges; i++) { own[2 * n] = deps->range[i][0]; own[2 * n + 1] = deps->range[i][1]; n++; }
+        for (int i = 0; i < deps->nwr; i++) { own[2 * n] = deps->wr_word[i]; own[2 * n + 1] = deps->wr_word[i] + S.aw; n++; }
+        d->nown = n; d->own = own;
+    }
     return 0;
 }
 
@@ -787,7 +849,9 @@ static core_plan *get_plan(int format, opcode_t *core)
         if (rc == 0) chains = 1;
         else { lowered_free(&L); if (rc != -8) return 0; }
     }
-    if (!chains && scan_generic(format, core, &gd)) return 0;
+    core_deps deps;
+    memset(&deps, 0, sizeof deps);                   /* chain cores: complete = 0, they run alone */
+    if (!chains && scan_generic(format, core, &gd, &deps)) return 0;
 
     if (select_device()) { lowered_free(&L); return 0; }
     if (!G.dev) {
@@ -803,6 +867,7 @@ static core_plan *get_plan(int format, opcode_t *core)
     core_plan *cp = &G.plans[G.nplans];
     cp->core = core; cp->format = format;
     cp->nchains = 0; cp->max_sections = 0; cp->max_taps = 0;
+    cp->deps = deps;
     if (chains) {
         avdsp_plan_desc d;
         memset(&d, 0, sizeof d);
@@ -855,7 +920,7 @@ int dspRuntimeCoreInfo(int format, opcode_t *core, int *nchains, int *max_sectio
     }
     if (rc == -8) {
         avdsp_generic_desc gd;
-        rc = scan_generic(format, core, &gd);
+        rc = scan_generic(format, core, &gd, 0);
     }
     if (rc) return rc;
     if (nchains) *nchains = nc;

@@ -859,6 +859,7 @@ struct Plan {
     int fir_gpc = 0;                  /* groups of 16 tap positions per LDS chunk */
     int io_in_min = 0, io_in_max = -1, io_out_min = 0, io_out_max = -1;
     bool wave_ok = false; unsigned carried_io[8] = {0, 0, 0, 0, 0, 0, 0, 0};      /* frame-parallel interpreter */
+    int *d_own = nullptr;                                /* owned mirror ranges (pairs), generic plans */
 };
 
 }  // namespace
@@ -895,7 +896,7 @@ void free_plan(Plan &p)
 {
     (void)hipFree(p.d_chains); (void)hipFree(p.d_sec_coef); (void)hipFree(p.d_sec_state);
     for (auto &g : p.bq) (void)hipFree(g.d_ids);
-    (void)hipFree(p.d_fir_ids); (void)hipFree(p.d_pass_ids); (void)hipFree(p.d_ring);
+    (void)hipFree(p.d_fir_ids); (void)hipFree(p.d_pass_ids); (void)hipFree(p.d_ring); (void)hipFree(p.d_own);
 }
 
 int fir_groups_per_chunk(int max_taps)
@@ -1168,6 +1169,24 @@ int avdsp_hip_prog_add_generic(avdsp_hip_prog *prog, const avdsp_generic_desc *d
         a.frame_lds = 0; a.stage_words = 0; a.batch_lds = 0;
         pl.ga_lds = (size_t)kGenericBatchLds * 4;
     }
+    /* what the core owns (written back after a launch); unknown = everything, and the core then runs alone */
+    a.nown = -1; a.own = nullptr; a.tpdf_owner = d->tpdf_calc != 0;
+    a.nrd_slot = a.nwr_slot = -1;
+    if (d->nown >= 0 && d->io_span <= 256) {
+        std::vector<int> own(d->own, d->own + 2 * (size_t)d->nown);
+        for (int i = 0; i < d->nown; i++)
+            if (own[2 * i] < 0 || own[2 * i + 1] < own[2 * i] || own[2 * i + 1] > prog->total_words)
+                return set_err("generic plan: owned range %d outside the mirror", i);
+        if (upload_vec(&pl.d_own, own)) return -1;
+        a.own = pl.d_own; a.nown = d->nown;
+        for (int k = 0; k < 8; k++) a.written_io[k] = d->written_io[k];
+        int nrd = 0, nwr = 0;
+        for (int sl = 0; sl < 256; sl++) {
+            if (d->early_io[sl >> 5] >> (sl & 31) & 1u) { if (nrd < 32) a.rd_slot[nrd] = (unsigned char)sl; nrd++; }
+            if (d->written_io[sl >> 5] >> (sl & 31) & 1u) { if (nwr < 32) a.wr_slot[nwr] = (unsigned char)sl; nwr++; }
+        }
+        if (nrd <= 32 && nwr <= 32) { a.nrd_slot = nrd; a.nwr_slot = nwr; }
+    }
     pl.wave_ok = d->wave_ok != 0 && d->nvm >= 0 && d->nvm <= 16;
     if (pl.wave_ok) {
         for (int k = 0; k < 8; k++) pl.carried_io[k] = d->carried_io[k];
@@ -1178,14 +1197,14 @@ int avdsp_hip_prog_add_generic(avdsp_hip_prog *prog, const avdsp_generic_desc *d
                        : d->format == 4 ? (const void *)interp_wave<4> : d->format == 5 ? (const void *)interp_wave<5>
                                                                                         : (const void *)interp_wave<6>;
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGenericLdsMax);
-        if (e != hipSuccess) return set_err("hipFuncSetAttribute(frame-parallel LDS): %s", hipGetErrorString(e));
+        if (e != hipSuccess) { (void)hipFree(pl.d_own); return set_err("hipFuncSetAttribute(frame-parallel LDS): %s", hipGetErrorString(e)); }
     }
     if (pl.ga_staged) {   /* per plan creation, like the FIR: nothing in the launch path may touch function attributes */
         const void *fn = d->format == 2 ? (const void *)interp_core<2, true> : d->format == 3 ? (const void *)interp_core<3, true>
                        : d->format == 4 ? (const void *)interp_core<4, true> : d->format == 5 ? (const void *)interp_core<5, true>
                                                                                               : (const void *)interp_core<6, true>;
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGenericLdsMax);
-        if (e != hipSuccess) return set_err("hipFuncSetAttribute(generic LDS): %s", hipGetErrorString(e));
+        if (e != hipSuccess) { (void)hipFree(pl.d_own); return set_err("hipFuncSetAttribute(generic LDS): %s", hipGetErrorString(e)); }
     }
     prog->plans.push_back(pl);
     return (int)prog->plans.size() - 1;
@@ -1215,6 +1234,10 @@ static bool wave_plan_fits(const avdsp_hip_prog *prog, const Plan &pl, const Blo
         }
     const size_t words = (size_t)span * interp::kLanePitch + prog->total_words + 2 + 128 + (size_t)a.nvm * 128 + a.seq_words;
     if (words * 4 > kGenericLdsMax) return false;
+    /* where the two windows share IO numbers the host loop hands the input through to the output rows for slots
+     * the core does not store: that needs the whole windows moved, not the core's slot lists */
+    if (io.in_stride > 0 && io.out_stride > 0 && io.in_base < io.out_base + io.out_stride && io.out_base < io.in_base + io.in_stride)
+        a.nrd_slot = a.nwr_slot = -1;
     a.wave_span = span;
     a.frame_lds = span * interp::kLanePitch;
     a.stage_words = prog->total_words; a.keep_words = (int)(sizeof(dspHeader_t) / 4);

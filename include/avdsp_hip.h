@@ -75,6 +75,13 @@ typedef struct avdsp_generic_desc {
     int32_t  nvm, vm_word[16];       /* mirror words written and read back inside one frame (STORE_MEM -> LOAD_MEM,
                                         LOAD_MUX / TPDF result -> LOAD_MEM_DATA): kept per lane                */
     int32_t  seq_words;              /* longest DSP_FIR impulse + 64 (0 = no FIR)                              */
+    /* What the core owns: an interpreter launch writes back only this, so that cores which do not meet may run
+     * side by side (avdsp_hip_run_level).  nown < 0: unknown, the launch writes everything back and runs alone. */
+    int32_t        nown;             /* pairs in own[]                                                          */
+    const int32_t *own;              /* mirror word ranges [lo, hi): opcode state, STORE_MEM / result words     */
+    uint32_t early_io[8];            /* frame slots < 256 the core reads before it has stored them in the frame  */
+    uint32_t written_io[8];          /* frame slots < 256 the core stores                                        */
+    int32_t  tpdf_calc;              /* the core holds the DSP_TPDF_CALC: it alone writes the dither globals     */
 } avdsp_generic_desc;
 
 /* A loaded program on the device: the mirror of the caller's buffer plus one plan per lowered core */
