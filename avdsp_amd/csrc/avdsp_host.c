@@ -75,6 +75,7 @@ static struct {
     int             nplans;
     int             opt_fir_impl, opt_biquad_impl, opt_device, opt_profile, opt_generic, opt_interp_impl;
     int             device_selected;
+    int             last_levels, last_cores;       /* of the latest dspRuntimeBlockAll: dspRuntimeGetOption("levels" / "cores") */
 } G = { .opt_fir_impl = 1, .opt_biquad_impl = 1, .opt_device = -1, .opt_interp_impl = 1 };
 
 static char g_err[512];
@@ -139,6 +140,8 @@ int dspRuntimeGetOption(const char *key)
     if (!strcmp(key, "profile"))     return G.opt_profile;
     if (!strcmp(key, "generic"))     return G.opt_generic;
     if (!strcmp(key, "interp_impl")) return G.opt_interp_impl;
+    if (!strcmp(key, "levels"))      return G.last_levels;
+    if (!strcmp(key, "cores"))       return G.last_cores;
     return -1;
 }
 
@@ -982,6 +985,79 @@ int dspRuntimeBlock_4(opcode_t *core, int *rundata, const int *in, int in_stride
 int dspRuntimeBlock_6(opcode_t *core, int *rundata, const float *in, int in_stride, int in_io_base,
                       float *out, int out_stride, int out_io_base, int nframes)
 { return block_host(6, core, rundata, in, in_stride, in_io_base, out, out_stride, out_io_base, nframes); }
+
+/* ---- all cores of the program over one block ----
+ * Same result as dspRuntimeBlock_N for core 1, 2, ... in turn (the host loop of linux/avdsp_plugin.c:95-142), in one
+ * call: samples cross PCIe once, and cores that do not meet run at the same time.  Two cores meet when one stores a
+ * frame slot, a memory word (STORE_MEM, LOAD_MUX / TPDF result), a state range or the dither globals that the other
+ * reads before writing it, or writes too; scan_generic collected that per core.  Levels: a core goes one level
+ * behind the latest earlier core it meets; the cores of a level are handed to the device together.            */
+static int cores_meet(const core_deps *a, const core_deps *b)
+{
+    if (!a->complete || !b->complete) return 1;
+    for (int k = 0; k < 8; k++)
+        if ((a->written_io[k] & (b->early_io[k] | b->written_io[k])) || (a->early_io[k] & b->written_io[k])) return 1;
+    for (int i = 0; i < a->nwr; i++) {
+        for (int j = 0; j < b->nrd; j++) { int d = a->wr_word[i] - b->rd_word[j]; if (d > -2 && d < 2) return 1; }
+        for (int j = 0; j < b->nwr; j++) { int d = a->wr_word[i] - b->wr_word[j]; if (d > -2 && d < 2) return 1; }
+        for (int j = 0; j < b->nranges; j++) if (a->wr_word[i] + 2 > b->range[j][0] && a->wr_word[i] < b->range[j][1]) return 1;
+    }
+    for (int i = 0; i < a->nrd; i++)
+        for (int j = 0; j < b->nwr; j++) { int d = a->rd_word[i] - b->wr_word[j]; if (d > -2 && d < 2) return 1; }
+    for (int i = 0; i < b->nwr; i++)
+        for (int j = 0; j < a->nranges; j++) if (b->wr_word[i] + 2 > a->range[j][0] && b->wr_word[i] < a->range[j][1]) return 1;
+    for (int i = 0; i < a->nranges; i++)
+        for (int j = 0; j < b->nranges; j++)
+            if (a->range[i][0] < b->range[j][1] && b->range[j][0] < a->range[i][1]) return 1;
+    if ((a->tpdf_calc && (b->tpdf_user || b->tpdf_calc)) || (a->tpdf_user && b->tpdf_calc)) return 1;
+    return 0;
+}
+
+static int block_all(int format, int *rundata, const void *in, int in_stride, int in_io_base,
+                     void *out, int out_stride, int out_io_base, int nframes, int on_device, void *stream)
+{
+    if (!dspHeaderPtr || !G.code) return fail(-1, "no program loaded");
+    if (check_rundata(rundata)) return -1;
+    if (nframes <= 0) return 0;
+    core_plan *cp[MAX_CORE_PLANS];
+    int level[MAX_CORE_PLANS], n = 0, nlevels = 0;
+    for (int k = 1; k <= MAX_CORE_PLANS; k++) {
+        opcode_t *c = dspFindCore(G.code, k);
+        if (!c || (k > 1 && c == G.code)) break;
+        cp[n] = get_plan(format, dspFindCoreBegin(c));
+        if (!cp[n]) return g_err_code;
+        n++;
+        if (c == G.code) break;                           /* a program without DSP_CORE is one core */
+    }
+    if (n == 0) return fail(-3, "no cores defined in the program");
+    for (int i = 0; i < n; i++) {
+        level[i] = 0;
+        for (int j = 0; j < i; j++)
+            if (level[j] + 1 > level[i] && cores_meet(&cp[j]->deps, &cp[i]->deps)) level[i] = level[j] + 1;
+        if (level[i] + 1 > nlevels) nlevels = level[i] + 1;
+    }
+    int plans[MAX_CORE_PLANS], size[MAX_CORE_PLANS], m = 0;
+    for (int l = 0; l < nlevels; l++) {
+        size[l] = 0;
+        for (int i = 0; i < n; i++) if (level[i] == l) { plans[m++] = cp[i]->plan_id; size[l]++; }
+    }
+    int rc = on_device
+        ? avdsp_hip_run_levels(G.dev, plans, size, nlevels, in, in_stride, in_io_base, out, out_stride, out_io_base,
+                               nframes, G.opt_fir_impl, G.opt_biquad_impl, stream)
+        : avdsp_hip_run_levels_host(G.dev, plans, size, nlevels, in, in_stride, in_io_base, out, out_stride, out_io_base,
+                                    nframes, G.opt_fir_impl, G.opt_biquad_impl);
+    if (rc) return fail(-10, "%s", avdsp_hip_last_error());
+    G.last_levels = nlevels; G.last_cores = n;
+    return 0;
+}
+
+int dspRuntimeBlockAll(int format, int *rundata, const void *in, int in_stride, int in_io_base,
+                       void *out, int out_stride, int out_io_base, int nframes)
+{ return block_all(format, rundata, in, in_stride, in_io_base, out, out_stride, out_io_base, nframes, 0, 0); }
+
+int dspRuntimeBlockAllDevice(int format, int *rundata, const void *d_in, int in_stride, int in_io_base,
+                             void *d_out, int out_stride, int out_io_base, int nframes, void *stream)
+{ return block_all(format, rundata, d_in, in_stride, in_io_base, d_out, out_stride, out_io_base, nframes, 1, stream); }
 
 /* linux/avdsp_plugin.c:95-142 with the sample-format switch of :109-121: packed PCM in, S32 out */
 int dspRuntimeBlockPcm(int format, opcode_t *core, int *rundata, int pcm, const void *src, int in_stride, int in_io_base,

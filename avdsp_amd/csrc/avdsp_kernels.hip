@@ -876,6 +876,10 @@ struct avdsp_hip_prog {
     struct Span { int kind; hipEvent_t a, b; };
     std::vector<Span> spans;            /* recorded, not yet read */
     std::vector<hipEvent_t> free_events;
+    /* cores of one level side by side (avdsp_hip_run_levels): side streams and their fork / join events */
+    std::vector<hipStream_t> side;
+    std::vector<hipEvent_t> join;
+    hipEvent_t fork = nullptr;
 };
 
 namespace {
@@ -1049,6 +1053,9 @@ void avdsp_hip_prog_destroy(avdsp_hip_prog *p)
     for (auto &pl : p->plans) free_plan(pl);
     for (auto &sp : p->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (auto e : p->free_events) (void)hipEventDestroy(e);
+    for (auto st : p->side) (void)hipStreamDestroy(st);
+    for (auto e : p->join) (void)hipEventDestroy(e);
+    if (p->fork) (void)hipEventDestroy(p->fork);
     (void)hipFree(p->d_buf); (void)hipFree(p->d_in); (void)hipFree(p->d_out); (void)hipFree(p->d_tpdf); (void)hipFree(p->d_frame);
     delete p;
 }
@@ -1234,10 +1241,6 @@ static bool wave_plan_fits(const avdsp_hip_prog *prog, const Plan &pl, const Blo
         }
     const size_t words = (size_t)span * interp::kLanePitch + prog->total_words + 2 + 128 + (size_t)a.nvm * 128 + a.seq_words;
     if (words * 4 > kGenericLdsMax) return false;
-    /* where the two windows share IO numbers the host loop hands the input through to the output rows for slots
-     * the core does not store: that needs the whole windows moved, not the core's slot lists */
-    if (io.in_stride > 0 && io.out_stride > 0 && io.in_base < io.out_base + io.out_stride && io.out_base < io.in_base + io.in_stride)
-        a.nrd_slot = a.nwr_slot = -1;
     a.wave_span = span;
     a.frame_lds = span * interp::kLanePitch;
     a.stage_words = prog->total_words; a.keep_words = (int)(sizeof(dspHeader_t) / 4);
@@ -1245,10 +1248,19 @@ static bool wave_plan_fits(const avdsp_hip_prog *prog, const Plan &pl, const Blo
     return true;
 }
 
+/* where the two windows share IO numbers the host loop hands the input through to the output rows for slots the
+ * core does not store: that (and unknown ownership) needs the whole windows moved, not the core's slots */
+static bool rows_whole(const Plan &pl, const BlockIO &io)
+{
+    const bool overlap = io.in_stride > 0 && io.out_stride > 0 && io.in_base < io.out_base + io.out_stride && io.out_base < io.in_base + io.in_stride;
+    return overlap || pl.ga.nown < 0 || pl.ga.nrd_slot < 0 || pl.ga.nwr_slot < 0;
+}
+
 static int launch_generic(avdsp_hip_prog *prog, Plan &pl, BlockIO io, hipStream_t stream)
 {
     GenericArgs a = pl.ga;
     a.io = io;
+    a.rows_whole = rows_whole(pl, io);
     const dim3 grid(1), block(64);
     if (wave_plan_fits(prog, pl, io, a)) {
         ProfileScope scope(prog, stream, AVDSP_KERNEL_GENERIC_WAVE);
@@ -1416,6 +1428,81 @@ int avdsp_hip_run_block_host(avdsp_hip_prog *prog, int plan, const void *h_in, i
     HIP_TRY(hipMemcpy(prog->d_out, h_out, out_words * 4, hipMemcpyHostToDevice));   /* unstored slots keep their content */
     if (avdsp_hip_run_block(prog, plan, prog->d_in, in_stride, in_io_base, prog->d_out, out_stride, out_io_base,
                             nframes, fir_impl, biquad_impl, nullptr)) return -1;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(h_out, prog->d_out, out_words * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+/* Several cores over the same block.  plans[] in program order, grouped into levels (level_size[]): the host
+ * has established that the cores of one level do not meet (no slot, memory word, state range or dither global
+ * written by one and touched by another), so they may run at the same time; levels run one after the other.
+ * Cores of a level go to side streams between a fork and a join on the caller's stream, provided every one of
+ * them delivers only its own slots for this call; otherwise the level runs in order on the caller's stream. */
+int avdsp_hip_run_levels(avdsp_hip_prog *prog, const int *plans, const int *level_size, int nlevels,
+                         const void *d_in, int in_stride, int in_io_base, void *d_out, int out_stride, int out_io_base,
+                         int nframes, int fir_impl, int biquad_impl, void *stream)
+{
+    hipStream_t main = (hipStream_t)stream;
+    int at = 0;
+    for (int l = 0; l < nlevels; l++) {
+        const int n = level_size[l];
+        bool together = n > 1;
+        BlockIO io{};
+        io.in_stride = in_stride; io.in_base = in_io_base; io.out_stride = out_stride; io.out_base = out_io_base;
+        for (int i = 0; i < n && together; i++) {
+            const int id = plans[at + i];
+            if (id < 0 || id >= (int)prog->plans.size()) return set_err("bad plan id %d", id);
+            const Plan &pl = prog->plans[id];
+            /* chain plans and interpreter cores working out of HBM share buffers; whole-window delivery overwrites */
+            if (!pl.generic || !pl.ga_staged || rows_whole(pl, io)) together = false;
+        }
+        if (!together) {
+            for (int i = 0; i < n; i++)
+                if (avdsp_hip_run_block(prog, plans[at + i], d_in, in_stride, in_io_base, d_out, out_stride, out_io_base,
+                                        nframes, fir_impl, biquad_impl, stream)) return -1;
+            at += n;
+            continue;
+        }
+        while ((int)prog->side.size() < n - 1) {
+            hipStream_t st; hipEvent_t ev;
+            HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            prog->side.push_back(st);
+            HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            prog->join.push_back(ev);
+        }
+        if (!prog->fork) HIP_TRY(hipEventCreateWithFlags(&prog->fork, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(prog->fork, main));
+        for (int i = 1; i < n; i++) {
+            HIP_TRY(hipStreamWaitEvent(prog->side[i - 1], prog->fork, 0));
+            if (avdsp_hip_run_block(prog, plans[at + i], d_in, in_stride, in_io_base, d_out, out_stride, out_io_base,
+                                    nframes, fir_impl, biquad_impl, prog->side[i - 1])) return -1;
+            HIP_TRY(hipEventRecord(prog->join[i - 1], prog->side[i - 1]));
+        }
+        if (avdsp_hip_run_block(prog, plans[at], d_in, in_stride, in_io_base, d_out, out_stride, out_io_base,
+                                nframes, fir_impl, biquad_impl, stream)) return -1;
+        for (int i = 1; i < n; i++) HIP_TRY(hipStreamWaitEvent(main, prog->join[i - 1], 0));
+        at += n;
+    }
+    return 0;
+}
+
+int avdsp_hip_run_levels_host(avdsp_hip_prog *prog, const int *plans, const int *level_size, int nlevels,
+                              const void *h_in, int in_stride, int in_io_base, void *h_out, int out_stride, int out_io_base,
+                              int nframes, int fir_impl, int biquad_impl)
+{
+    const size_t in_words = (size_t)nframes * in_stride, out_words = (size_t)nframes * out_stride;
+    if (prog->in_cap < in_words) {
+        (void)hipFree(prog->d_in); prog->d_in = nullptr; prog->in_cap = 0;
+        HIP_TRY(hipMalloc((void **)&prog->d_in, in_words * 4)); prog->in_cap = in_words;
+    }
+    if (prog->out_cap < out_words) {
+        (void)hipFree(prog->d_out); prog->d_out = nullptr; prog->out_cap = 0;
+        HIP_TRY(hipMalloc((void **)&prog->d_out, out_words * 4)); prog->out_cap = out_words;
+    }
+    HIP_TRY(hipMemcpy(prog->d_in, h_in, in_words * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(prog->d_out, h_out, out_words * 4, hipMemcpyHostToDevice));   /* unstored slots keep their content */
+    if (avdsp_hip_run_levels(prog, plans, level_size, nlevels, prog->d_in, in_stride, in_io_base, prog->d_out, out_stride,
+                             out_io_base, nframes, fir_impl, biquad_impl, nullptr)) return -1;
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(h_out, prog->d_out, out_words * 4, hipMemcpyDeviceToHost));
     return 0;

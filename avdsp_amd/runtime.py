@@ -27,13 +27,13 @@ EXPORTED = [
     "dspHeaderPtr", "dspBiquadFreqSkip", "dspMantissa", "dspOpcodeText", "dspQNM", "dspQM64", "dspQM32",
     # block extension (include/avdsp_runtime.h)
     "dspRuntimeBlock_2", "dspRuntimeBlock_3", "dspRuntimeBlock_4", "dspRuntimeBlock_5", "dspRuntimeBlock_6",
-    "dspRuntimeBlockDevice", "dspRuntimeBlockPcm", "dspRuntimeUnpackPcmDevice",
+    "dspRuntimeBlockDevice", "dspRuntimeBlockPcm", "dspRuntimeUnpackPcmDevice", "dspRuntimeBlockAll", "dspRuntimeBlockAllDevice",
     "dspRuntimeSyncState", "dspRuntimeUploadState", "dspRuntimeUploadParams", "dspRuntimeSetOption", "dspRuntimeGetOption",
     "dspRuntimeCoreInfo", "dspRuntimeKernelTime", "dspRuntimeLastError", "dspRuntimeRelease",
     # thin HIP ABI (include/avdsp_hip.h)
     "avdsp_hip_device_count", "avdsp_hip_set_device", "avdsp_hip_prog_create", "avdsp_hip_prog_destroy",
     "avdsp_hip_prog_add_plan", "avdsp_hip_prog_add_generic", "avdsp_hip_prog_clear_plans", "avdsp_hip_tpdf_reset", "avdsp_hip_upload_words", "avdsp_hip_download_words", "avdsp_hip_zero_words",
-    "avdsp_hip_run_block", "avdsp_hip_run_block_host", "avdsp_hip_unpack_pcm", "avdsp_hip_run_block_pcm_host", "avdsp_hip_profile_enable", "avdsp_hip_profile_read",
+    "avdsp_hip_run_block", "avdsp_hip_run_block_host", "avdsp_hip_run_levels", "avdsp_hip_run_levels_host", "avdsp_hip_unpack_pcm", "avdsp_hip_run_block_pcm_host", "avdsp_hip_profile_enable", "avdsp_hip_profile_read",
     "avdsp_hip_synchronize", "avdsp_hip_last_error",
 ]
 
@@ -93,6 +93,10 @@ def lib() -> C.CDLL:
             f = getattr(L, n); f.restype = i32; f.argtypes = [vp, vp, vp, i32, i32, vp, i32, i32, i32]
         L.dspRuntimeBlockDevice.restype = i32
         L.dspRuntimeBlockDevice.argtypes = [i32, vp, vp, vp, i32, i32, vp, i32, i32, i32, vp]
+        L.dspRuntimeBlockAll.restype = i32
+        L.dspRuntimeBlockAll.argtypes = [i32, vp, vp, i32, i32, vp, i32, i32, i32]
+        L.dspRuntimeBlockAllDevice.restype = i32
+        L.dspRuntimeBlockAllDevice.argtypes = [i32, vp, vp, i32, i32, vp, i32, i32, i32, vp]
         L.dspRuntimeBlockPcm.restype = i32
         L.dspRuntimeBlockPcm.argtypes = [i32, vp, vp, i32, vp, i32, i32, vp, i32, i32, i32]
         L.dspRuntimeUnpackPcmDevice.restype = i32
@@ -203,6 +207,24 @@ class Runtime:
                 self._check(f(core, self.rundata, x[b0:b1].ctypes.data, in_stride, in_io_base,
                               out[b0:b1].ctypes.data, out_stride, out_io_base, b1 - b0))
         return out
+
+    def run_block_all(self, x: np.ndarray, out_stride: int, in_io_base: int, out_io_base: int = 0,
+                      out: np.ndarray | None = None, block: int | None = None) -> np.ndarray:
+        """dspRuntimeBlockAll: every core of the program per block of `block` frames, in one call each; cores
+        that do not meet run at the same time.  Same result as run_block."""
+        x = np.ascontiguousarray(x, dtype=sample_dtype(self.fmt))
+        nframes, in_stride = x.shape
+        if out is None:
+            out = np.zeros((nframes, out_stride), dtype=sample_dtype(self.fmt))
+        block = block or nframes
+        for b0 in range(0, nframes, block):
+            b1 = min(b0 + block, nframes)
+            self._check(self.L.dspRuntimeBlockAll(self.fmt, self.rundata, x[b0:b1].ctypes.data, in_stride, in_io_base,
+                                                  out[b0:b1].ctypes.data, out_stride, out_io_base, b1 - b0))
+        return out
+
+    def get_option(self, key: str) -> int:
+        return self.L.dspRuntimeGetOption(key.encode())
 
     def run_block_pcm(self, pcm: int, raw: np.ndarray, nframes: int, in_stride: int, out_stride: int,
                       in_io_base: int, out_io_base: int = 0, block: int | None = None) -> np.ndarray:

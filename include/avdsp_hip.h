@@ -113,6 +113,16 @@ int avdsp_hip_run_block(avdsp_hip_prog *prog, int plan, const void *d_in, int in
                         void *d_out, int out_stride, int out_io_base, int nframes,
                         int fir_impl, int biquad_impl, void *stream);
 
+/* Several cores over one block: plans[] in program order, grouped into levels; the cores of a level do not meet
+ * (host's analysis) and run at the same time on side streams, the levels one after the other.  Same meaning as
+ * calling avdsp_hip_run_block for every plan in order.                                           */
+int avdsp_hip_run_levels(avdsp_hip_prog *prog, const int *plans, const int *level_size, int nlevels,
+                         const void *d_in, int in_stride, int in_io_base, void *d_out, int out_stride, int out_io_base,
+                         int nframes, int fir_impl, int biquad_impl, void *stream);
+int avdsp_hip_run_levels_host(avdsp_hip_prog *prog, const int *plans, const int *level_size, int nlevels,
+                              const void *h_in, int in_stride, int in_io_base, void *h_out, int out_stride, int out_io_base,
+                              int nframes, int fir_impl, int biquad_impl);
+
 /* host-buffer convenience: stages in/out through device scratch and synchronises               */
 int avdsp_hip_run_block_host(avdsp_hip_prog *prog, int plan, const void *h_in, int in_stride, int in_io_base,
                              void *h_out, int out_stride, int out_io_base, int nframes,

@@ -102,6 +102,18 @@ int dspRuntimeBlockDevice(int format, opcode_t *core, int *rundata,
                           const void *d_in, int in_stride, int in_io_base,
                           void *d_out, int out_stride, int out_io_base, int nframes, void *stream);
 
+/* All cores of the loaded program over one block: the result of dspRuntimeBlock_N for core 1, 2, ... in turn
+ * (the host loop of linux/avdsp_plugin.c:95-142 runs cores outermost too), in one call.  The samples cross PCIe
+ * once instead of once per core, and cores that do not meet -- no frame slot, memory word (STORE_MEM, LOAD_MUX /
+ * TPDF result), state range or dither global written by one and touched by the other -- run at the same time
+ * on the device; cores that do are kept in program order.  dspRuntimeGetOption("levels") / ("cores") tell how
+ * the latest call was arranged (levels < cores: something ran side by side).  format = DSP_FORMAT 2..6;
+ * in/out: int32 or float samples as in dspRuntimeBlock_N (host pointers) / device pointers + stream.       */
+int dspRuntimeBlockAll(int format, int *rundata, const void *in, int in_stride, int in_io_base,
+                       void *out, int out_stride, int out_io_base, int nframes);
+int dspRuntimeBlockAllDevice(int format, int *rundata, const void *d_in, int in_stride, int in_io_base,
+                             void *d_out, int out_stride, int out_io_base, int nframes, void *stream);
+
 /* The host's sample-format step (linux/avdsp_plugin.c:103-121): `src` holds packed little-endian PCM,
  * frame-interleaved [nframes][in_stride]; pcm = AVDSP_PCM_S32 | AVDSP_PCM_S24_3LE | AVDSP_PCM_S16
  * (include/avdsp_hip.h).  The unpacking to s.31 words happens on the device; output is S32 like the

@@ -236,3 +236,69 @@ def test_switching_kernels_mid_stream_keeps_the_state():
     finally:
         r.set_option("interp_impl", 1)
         r.release()
+
+
+def _all_vs_per_core(fmt, prog, x, out_stride, in_base, out_base, block, fs=48000, seed=11):
+    """dspRuntimeBlockAll against the per-core calls (and the oracle): outputs and the whole buffer"""
+    o = po.OracleProgram(fmt, prog, fs=fs, random=seed, dither=24)
+    frame = np.zeros(4096, dtype=np.uint32)
+    want = o.run_block(x, out_stride, in_base, out_base, block=block, frame=frame)
+    r = rt.Runtime(fmt, prog, fs=fs, random=seed, dither=24)
+    assert r.rc == o.rc and r.rc > 0
+    try:
+        got = r.run_block_all(x, out_stride, in_base, out_base, block=block)
+        levels, cores = r.get_option("levels"), r.get_option("cores")
+        bad = np.nonzero((got.view(np.uint32) != want.view(np.uint32)).any(axis=0))[0]
+        assert bad.size == 0, f"DSP_FORMAT {fmt} block {block}: output columns {list(bad)} differ ({cores} cores in {levels} levels)"
+        r.sync_state()
+        n = int(prog[1]) + int(prog[2])
+        words = np.nonzero(r.buf[12:n] != o.buf[12:n])[0] + 12
+        assert words.size == 0, f"DSP_FORMAT {fmt} block {block}: buffer words {list(words[:8])} differ ({cores} cores in {levels} levels)"
+        return levels, cores
+    finally:
+        r.release()
+
+
+def test_block_all_on_the_reference_programs():
+    """crossoverLV6: core 2 dithers with core 1's TPDF value -> two levels.  dacdiy1: core 1 feeds cores 2-4 through
+    STORE_MEM / LOAD_MEM and the dither value, those three do not meet -> two levels for four cores."""
+    import os
+    from tests.golden_recipes import GOLDEN_DIR
+    for name, expect in (("crossoverLV6.bin", (2, 2)), ("dacdiy1.bin", (2, 4))):
+        prog = np.fromfile(os.path.join(GOLDEN_DIR, name), dtype=np.uint32)
+        x = pb.lcg_input(700, 16, False, seed=5)
+        for block in (1, 100, 700):
+            assert _all_vs_per_core(2, prog, x, 32, 8, 0, block) == expect
+
+
+@pytest.mark.parametrize("seed", range(100, 130))
+def test_block_all_on_random_programs(seed):
+    """Random multi-core programs (memories, shared dither, histogram slots ...): whatever levels the host finds,
+    the result is the per-core one."""
+    from tests.fuzz_programs import IN_BASE, N_IN, N_OUT, random_program
+    for fmt in (2, 5, 6):
+        prog = random_program(seed, fmt)
+        fs, block = [48000, 48000, 96000][seed % 3], [7, 64, 400][seed % 3]
+        x = pb.lcg_input(400, N_IN, fmt in (5, 6), seed=seed)
+        _all_vs_per_core(fmt, prog, x, N_OUT, IN_BASE, 0, block, fs=fs, seed=seed)
+
+
+def test_block_all_runs_independent_cores_side_by_side():
+    """four cores that share nothing -> one level; outputs interleaved in the same rows"""
+    def build(L):
+        L.dsp_PARAM()
+        banks = []
+        for c in range(4):
+            b = L.dspBiquad_Sections(3)
+            for k in range(3):
+                L.dsp_Filter2ndOrder(FPEAK, 200.0 * (k + 1) + 50 * c, 1.1, 0.9)
+            banks.append(b)
+        for c in range(4):
+            L.dsp_CORE()
+            L.dsp_LOAD_GAIN_Fixed(IN + c, 0.5); L.dsp_DELAY_1(); L.dsp_BIQUADS(banks[c]); L.dsp_DCBLOCK(10); L.dsp_SAT0DB()
+            L.dsp_STORE(c); L.dsp_STORE(8 + c)
+    for fmt in (2, 6):
+        prog = encode(build, fmt)
+        x = pb.lcg_input(500, 8, fmt == 6, seed=2)
+        for block in (64, 500):
+            assert _all_vs_per_core(fmt, prog, x, 16, IN, 0, block) == (1, 4)

@@ -68,7 +68,48 @@ def interpreter():
             r.L.dspRuntimeRelease()
 
 
+def program_level():
+    """Whole programs on device-resident blocks, stream time (HIP events): the cores one after the other
+    (dspRuntimeBlockDevice per core) against dspRuntimeBlockAllDevice (cores that do not meet side by side)."""
+    gold = os.path.join(ROOT, "tests", "golden")
+    # windows that do not share IO numbers (with shared ones the whole rows are delivered and cores run in turn)
+    for name, fmt, in_stride, in_base, out_stride in (("crossoverLV6.bin", 2, 16, 8, 8), ("dacdiy1.bin", 2, 16, 8, 8),
+                                                      ("tour_float.bin", 6, 16, 32, 32)):
+        prog = np.fromfile(os.path.join(gold, name), dtype=np.uint32)
+        for frames in (256, 4096):
+            r = rt.Runtime(fmt, prog, fs=48000, random=1, dither=24)
+            x = torch.from_numpy(pb.lcg_input(frames, in_stride, fmt in (5, 6), seed=5)).cuda()
+            y = torch.zeros((frames, out_stride), dtype=x.dtype, device="cuda")
+            stream = torch.cuda.current_stream().cuda_stream
+            res = {}
+            for mode in ("per core", "all"):
+                def once():
+                    if mode == "all":
+                        r._check(r.L.dspRuntimeBlockAllDevice(fmt, r.rundata, x.data_ptr(), in_stride, in_base, y.data_ptr(),
+                                                              out_stride, 0, frames, stream))
+                    else:
+                        for k in range(len(r.cores)):
+                            r.run_block_device(x.data_ptr(), in_stride, in_base, y.data_ptr(), out_stride, 0, frames, stream, k)
+                for _ in range(3):
+                    once()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                reps = 20
+                e0.record()
+                for _ in range(reps):
+                    once()
+                e1.record()
+                torch.cuda.synchronize()
+                res[mode] = e0.elapsed_time(e1) * 1e3 / reps / frames
+            print(f"program {name:18s} fmt {fmt} block {frames:5d}: per core {res['per core']:6.3f} us/frame, "
+                  f"BlockAll {res['all']:6.3f} us/frame ({r.get_option('cores')} cores in {r.get_option('levels')} levels)", flush=True)
+            r.L.dspRuntimeRelease()
+
+
 if __name__ == "__main__":
+    if "program" in sys.argv[1:]:
+        program_level()
+        sys.exit(0)
     if "interp" not in sys.argv[1:]:
         unpack()
     interpreter()
