@@ -1,6 +1,6 @@
 """Development sweep: random programs on the general interpreter, frame-parallel kernel where the host
 allows it, against the oracle; reports how many block calls each kernel took.
-usage: python tests/gpu_wave_sweep.py SEED0 SEED1 [frames]"""
+usage: python tests/gpu_wave_sweep.py SEED0 SEED1 [frames] [all]     (all: through dspRuntimeBlockAll)"""
 import sys; sys.path.insert(0, '.')
 import numpy as np
 from avdsp_amd import progbuilder as pb, runtime as rt
@@ -8,6 +8,8 @@ from oracle import pyoracle as po
 from tests.fuzz_programs import IN_BASE, N_IN, N_OUT, random_program
 
 frames = int(sys.argv[3]) if len(sys.argv) > 3 else 300
+use_all = len(sys.argv) > 4 and sys.argv[4] == "all"
+levels_hist = {}
 bad = n = wave = scalar = 0
 for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     for fmt in (2, 3, 4, 5, 6):
@@ -19,8 +21,14 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
         if r.rc < 0:
             continue
         r.set_option("profile", 1)
-        want = o.run_block(x, N_OUT, IN_BASE, 0, scratch_len=48, block=block)
-        got = r.run_block(x, N_OUT, IN_BASE, 0, block=block)
+        if use_all:
+            block = max(block, 2)
+            want = o.run_block(x, N_OUT, IN_BASE, 0, block=block, frame=np.zeros(4096, dtype=np.uint32))
+            got = r.run_block_all(x, N_OUT, IN_BASE, 0, block=block)
+            key = (r.get_option("cores"), r.get_option("levels")); levels_hist[key] = levels_hist.get(key, 0) + 1
+        else:
+            want = o.run_block(x, N_OUT, IN_BASE, 0, scratch_len=48, block=block)
+            got = r.run_block(x, N_OUT, IN_BASE, 0, block=block)
         r.sync_state(); nn = int(prog[1]) + int(prog[2]); n += 1
         w = r.kernel_time(5)[1]; s = r.kernel_time(3)[1]
         wave += w; scalar += s
@@ -34,3 +42,5 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
         r.set_option("profile", 0)
         r.release()
 print('runs', n, 'bad', bad, 'frame-parallel launches', wave, 'scalar launches', scalar)
+if use_all:
+    print('(cores, levels) histogram:', sorted(levels_hist.items()))
