@@ -302,3 +302,55 @@ def test_block_all_runs_independent_cores_side_by_side():
         x = pb.lcg_input(500, 8, fmt == 6, seed=2)
         for block in (64, 500):
             assert _all_vs_per_core(fmt, prog, x, 16, IN, 0, block) == (1, 4)
+
+
+def test_block_all_mixes_chain_cores_and_interpreted_cores():
+    """a chain core (parallel kernels) next to interpreted cores: the chain core keeps its place in the order"""
+    def build(L):
+        L.dsp_PARAM()
+        b = L.dspBiquad_Sections(2)
+        for k in range(2):
+            L.dsp_Filter2ndOrder(FPEAK, 500.0 * (k + 1), 1.0, 0.9)
+        L.dsp_CORE()                                                             # chain core
+        L.dsp_LOAD_GAIN_Fixed(IN + 0, 0.5); L.dsp_BIQUADS(b); L.dsp_SAT0DB(); L.dsp_STORE(0)
+        L.dsp_CORE()                                                             # interpreted
+        L.dsp_LOAD_GAIN_Fixed(IN + 1, 0.5); L.dsp_DELAY_1(); L.dsp_STORE(1)
+        L.dsp_CORE()                                                             # interpreted, reads what the chain core stored
+        L.dsp_LOAD(0); L.dsp_GAIN_Fixed(0.5); L.dsp_DELAY_1(); L.dsp_STORE(2)
+    for fmt in (2, 6):
+        prog = encode(build, fmt)
+        x = pb.lcg_input(300, 8, fmt == 6, seed=6)
+        r = rt.Runtime(fmt, prog)
+        assert r.core_info(0)["chains"] == 1 and r.core_info(1)["chains"] == 0
+        r.release()
+        for block in (50, 300):
+            levels, cores = _all_vs_per_core(fmt, prog, x, 8, IN, 0, block, seed=0)
+            assert cores == 3 and levels >= 2
+
+
+def test_block_all_device_entry_point_on_a_side_stream():
+    torch = pytest.importorskip("torch")
+    import os
+    from tests.golden_recipes import GOLDEN_DIR
+    prog = np.fromfile(os.path.join(GOLDEN_DIR, "dacdiy1.bin"), dtype=np.uint32)
+    xh = pb.lcg_input(512, 16, False, seed=5)
+    o = po.OracleProgram(2, prog, fs=48000, random=3, dither=24)
+    want = o.run_block(xh, 8, 8, 0, block=256, frame=np.zeros(4096, dtype=np.uint32))
+    r = rt.Runtime(2, prog, fs=48000, random=3, dither=24)
+    try:
+        r.set_option("profile", 1)
+        side = torch.cuda.Stream()
+        x = torch.from_numpy(xh).cuda()
+        y = torch.zeros((512, 8), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            for b0 in (0, 256):
+                r._check(r.L.dspRuntimeBlockAllDevice(2, r.rundata, x[b0:].data_ptr(), 16, 8, y[b0:].data_ptr(), 8, 0, 256, side.cuda_stream))
+        side.synchronize()
+        assert (y.cpu().numpy() == want).all()
+        assert (r.sync_state() == o.state).all()
+        assert r.get_option("levels") == 2 and r.get_option("cores") == 4
+        assert r.kernel_time(KIND_WAVE)[1] == 8
+    finally:
+        r.set_option("profile", 0)
+        r.release()
