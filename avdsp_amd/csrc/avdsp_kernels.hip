@@ -872,7 +872,7 @@ struct avdsp_hip_prog {
     std::vector<Plan> plans;
     unsigned *d_in = nullptr, *d_out = nullptr; size_t in_cap = 0, out_cap = 0;   /* host-call staging */
     /* optional per-kernel timing with HIP events on the launch stream (avdsp_hip_profile_*) */
-    bool profile = false;
+    unsigned profile = 0;               /* bit k: time the launches of kind k (AVDSP_KERNEL_*) */
     struct Span { int kind; hipEvent_t a, b; };
     std::vector<Span> spans;            /* recorded, not yet read */
     std::vector<hipEvent_t> free_events;
@@ -932,7 +932,7 @@ struct ProfileScope {                   /* records an event pair around the laun
     avdsp_hip_prog *prog; hipStream_t stream; int kind; hipEvent_t a = nullptr;
     ProfileScope(avdsp_hip_prog *p, hipStream_t s, int k) : prog(p), stream(s), kind(k)
     {
-        if (prog->profile && (a = take_event(prog))) (void)hipEventRecord(a, stream);
+        if ((prog->profile >> kind & 1u) && (a = take_event(prog))) (void)hipEventRecord(a, stream);
     }
     ~ProfileScope()
     {
@@ -1557,7 +1557,7 @@ int avdsp_hip_run_block_pcm_host(avdsp_hip_prog *prog, int plan, int pcm, const 
 
 int avdsp_hip_profile_enable(avdsp_hip_prog *prog, int on)
 {
-    prog->profile = on != 0;
+    prog->profile = on == 1 ? ~0u : (unsigned)on >> 1;     /* 0 off, 1 every kind, otherwise 2 * (mask of kinds) */
     return 0;
 }
 

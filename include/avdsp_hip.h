@@ -140,7 +140,9 @@ int avdsp_hip_run_block_pcm_host(avdsp_hip_prog *prog, int plan, int pcm, const 
 
 /* Per-kernel timing: when enabled, every kernel launch of run_block is bracketed by a HIP event pair
  * recorded on the launch stream; profile_read waits for the recorded pairs of one kind, returns
- * the summed duration and the number of launches, and forgets them.                              */
+ * the summed duration and the number of launches, and forgets them.  on: 0 = off, 1 = every kind,
+ * 2 * mask = only the kinds whose bit is set in mask (an event pair costs a few microseconds of stream
+ * time: a benchmark times the kernel it reports and nothing else).                               */
 enum { AVDSP_KERNEL_BIQUAD = 0, AVDSP_KERNEL_FIR = 1, AVDSP_KERNEL_PASS = 2, AVDSP_KERNEL_GENERIC = 3, AVDSP_KERNEL_UNPACK = 4, AVDSP_KERNEL_GENERIC_WAVE = 5 };
 int avdsp_hip_profile_enable(avdsp_hip_prog *prog, int on);
 int avdsp_hip_profile_read(avdsp_hip_prog *prog, int kind, double *total_ms, int *launches);

@@ -139,7 +139,9 @@ int dspRuntimeUploadParams(void);
 int dspRuntimeSetOption(const char *key, int value);
 int dspRuntimeGetOption(const char *key);
 
-/* Kernel timing with HIP events on the launch stream: enable with dspRuntimeSetOption("profile", 1);
+/* Kernel timing with HIP events on the launch stream: enable with dspRuntimeSetOption("profile", 1), or
+ * ("profile", 2 * mask) to time only the kinds whose bit is set in mask (each event pair costs the stream a few
+ * microseconds);
  * kind 0 = biquad cascade, 1 = FIR, 2 = pass-through, 3 = general interpreter frame by frame,
  * 4 = PCM unpack, 5 = general interpreter frame-parallel.  Returns the summed duration (ms) and launch
  * count of the launches recorded since the previous read.                                        */
