@@ -50,6 +50,7 @@ typedef struct {
     int      nwr, wr_word[64];           /* mirror words written as per-frame variables (STORE_MEM, result words) */
     int      nrd, rd_word[64];           /* mirror words read before this core writes them in the frame */
     int      nranges, range[DEPS_MAX_RANGES][2];   /* opcode-private state, mirror words [lo, hi) */
+    int      nparams, param[DEPS_MAX_RANGES][2];   /* program words read as parameters, merged, [lo, hi) */
     int      tpdf_calc, tpdf_user;
 } core_deps;
 
@@ -442,6 +443,7 @@ typedef struct {
     int nwr, wr_word[64];
     int nearly, early_word[64];
     int nranges; struct { long long lo, hi; } range[512];
+    int nparams; int param[512][2];      /* program words read as parameters (gains, banks, tables, taps ...), [lo, hi) */
     int tpdf_calc_seen, tpdf_user_seen;
 } wscan;
 
@@ -499,6 +501,11 @@ static void ws_finish(gscan *s)
         if (w->early[io] && w->written[io]) s->d->carried_io[io >> 5] |= 1u << (io & 31);
     for (int i = 0; i < w->nearly && w->ok; i++)
         for (int k = 0; k < w->nwr; k++) if (w->wr_word[k] == w->early_word[i]) { w->ok = 0; break; }
+    /* a word this core stores with STORE_MEM and an opcode of it reads as a parameter (a gain computed on the fly):
+     * that opcode must see this frame's value, or last frame's, depending on the order -- frame by frame only */
+    for (int i = 0; i < w->nwr && w->ok; i++)
+        for (int k = 0; k < w->nparams; k++)
+            if (w->wr_word[i] < w->param[k][1] && w->wr_word[i] + s->aw > w->param[k][0]) { w->ok = 0; break; }
     /* values are aw words wide: two different keys closer than that would alias */
     for (int i = 0; i < w->nwr && w->ok; i++) {
         for (int k = 0; k < w->nwr; k++) { int dlt = w->wr_word[i] - w->wr_word[k]; if (dlt && dlt > -s->aw && dlt < s->aw) w->ok = 0; }
@@ -545,6 +552,16 @@ static void ws_export(const gscan *s, core_deps *dp)
         dp->range[n][0] = tmp[i][0]; dp->range[n][1] = tmp[i][1]; n++;
     }
     dp->nranges = n;
+    static int ptmp[512][2];
+    memcpy(ptmp, w->param, sizeof(int) * 2 * (size_t)w->nparams);
+    qsort(ptmp, (size_t)w->nparams, sizeof ptmp[0], cmp_range);
+    n = 0;
+    for (int i = 0; i < w->nparams; i++) {
+        if (n && ptmp[i][0] <= dp->param[n - 1][1]) { if (ptmp[i][1] > dp->param[n - 1][1]) dp->param[n - 1][1] = ptmp[i][1]; continue; }
+        if (n == DEPS_MAX_RANGES) { dp->complete = 0; break; }
+        dp->param[n][0] = ptmp[i][0]; dp->param[n][1] = ptmp[i][1]; n++;
+    }
+    dp->nparams = n;
 }
 
 static int gs_payload(const gscan *s, int need)
@@ -556,6 +573,16 @@ static int gs_prog(const gscan *s, int off, int n)          /* words [at+off, at
 {
     long long lo = (long long)s->at + off;
     if (n < 0 || lo < 0 || lo + n > s->prog_words) return fail(-8, "word %d: program offset %d (+%d) outside the program", s->at, off, n);
+    return 0;
+}
+static int gs_param(gscan *s, int off, int n)               /* gs_prog for words an opcode reads as parameters */
+{
+    if (gs_prog(s, off, n)) return g_err_code;
+    wscan *w = &s->w;
+    if (n > 0) {
+        if (w->nparams == 512) { w->ok = w->complete = 0; return 0; }
+        w->param[w->nparams][0] = s->at + off; w->param[w->nparams][1] = s->at + off + n; w->nparams++;
+    }
     return 0;
 }
 static int gs_data(const gscan *s, int off, long long n)    /* words [off, off+n) of the data area */
@@ -660,7 +687,7 @@ static int scan_generic(int format, opcode_t *core, avdsp_generic_desc *d, core_
             rc = gs_payload(&S, 1); break;
         case DSP_LOAD:  rc = gs_payload(&S, 1) || gs_io(&S, a[0], 0); if (!rc) ws_read_io(&S, a[0]); break;
         case DSP_STORE: rc = gs_payload(&S, 1) || gs_io(&S, a[0], 1); if (!rc) { ws_write_io(&S, a[0]); ws_tpdf_user(&S); } break;
-        case DSP_LOAD_GAIN: rc = gs_payload(&S, 2) || gs_io(&S, a[0], 0) || gs_prog(&S, a[1], 1); if (!rc) ws_read_io(&S, a[0]); break;
+        case DSP_LOAD_GAIN: rc = gs_payload(&S, 2) || gs_io(&S, a[0], 0) || gs_param(&S, a[1], 1); if (!rc) ws_read_io(&S, a[0]); break;
         case DSP_LOAD_STORE:
             for (unsigned k = 0; k + 2 <= skip - 1 && !rc; k += 2) {
                 rc = gs_io(&S, a[k], 0) || gs_io(&S, a[k + 1], 1);
@@ -671,7 +698,7 @@ static int scan_generic(int format, opcode_t *core, avdsp_generic_desc *d, core_
             ws_tpdf_user(&S);
             /* fall through */
         case DSP_GAIN: case DSP_SAT0DB_GAIN: case DSP_VALUE: case DSP_VALUE_INT:
-            rc = gs_payload(&S, 1) || gs_prog(&S, a[0], 1); break;
+            rc = gs_payload(&S, 1) || gs_param(&S, a[0], 1); break;
         case DSP_LOAD_MEM:
             rc = gs_payload(&S, 1) || gs_prog(&S, a[0], S.aw); if (!rc) ws_mem_read(&S, at + a[0], 0); break;
         case DSP_STORE_MEM:
@@ -711,30 +738,30 @@ static int scan_generic(int format, opcode_t *core, avdsp_generic_desc *d, core_
                 rc = gs_data(&S, a[1], 1 + n * (op == DSP_DELAY ? 1 : S.aw));
                 if (!rc) ws_state(&S, a[1], 1 + n * (op == DSP_DELAY ? 1 : S.aw));
             }
-            if (!rc && a[2]) rc = gs_prog(&S, a[2], 1);
+            if (!rc && a[2]) rc = gs_param(&S, a[2], 1);
             break;
         case DSP_BIQUADS: {
-            rc = gs_payload(&S, 2) || gs_prog(&S, a[1], 2);
+            rc = gs_payload(&S, 2) || gs_param(&S, a[1], 2);
             if (rc) break;
             const opcode_t *bank = p + a[1];
             const int num = (short)bank[0].i32;
             if (num < 1) { rc = fail(-8, "word %d: biquad bank with %d sections", at, num); break; }
-            rc = gs_prog(&S, a[1], G.biquad_offset + (num - 1) * dspBiquadFreqSkip + 5) || gs_data(&S, a[0], 6ll * num);
+            rc = gs_param(&S, a[1], G.biquad_offset + (num - 1) * dspBiquadFreqSkip + 5) || gs_data(&S, a[0], 6ll * num);
             if (!rc) ws_state(&S, a[0], 6ll * num);
             break; }
         case DSP_LOAD_MUX: {
-            rc = gs_payload(&S, 2) || gs_prog(&S, a[0], 1) || gs_data(&S, a[1], S.aw);
+            rc = gs_payload(&S, 2) || gs_param(&S, a[0], 1) || gs_data(&S, a[1], S.aw);
             if (rc) break;
             const opcode_t *t = p + a[0];
             const int n = (short)t[0].i32;
-            if (n > 0) rc = gs_prog(&S, a[0], 1 + 2 * n);
+            if (n > 0) rc = gs_param(&S, a[0], 1 + 2 * n);
             for (int k = 0; k < n && !rc; k++) { rc = gs_io(&S, t[1 + 2 * k].i32, 0); if (!rc) ws_read_io(&S, t[1 + 2 * k].i32); }
             if (!rc) ws_mem_write(&S, S.prog_words + a[1]);
             break; }
         case DSP_DATA_TABLE:
             rc = gs_payload(&S, 5);
             if (!rc && (a[2] < 1 || a[1] < 0 || a[1] > a[2])) rc = fail(-8, "word %d: data table size %d / step %d", at, a[2], a[1]);
-            if (!rc) rc = gs_data(&S, a[3], 1) || gs_prog(&S, a[4], a[2]);
+            if (!rc) rc = gs_data(&S, a[3], 1) || gs_param(&S, a[4], a[2]);
             if (!rc) ws_state(&S, a[3], 1);
             break;
         case DSP_FIR: {
@@ -742,7 +769,7 @@ static int scan_generic(int format, opcode_t *core, avdsp_generic_desc *d, core_
             if (rc) break;
             const int off = a[fi];
             if (!off) break;
-            rc = gs_prog(&S, off, 1);
+            rc = gs_param(&S, off, 1);
             if (rc) break;
             const int length = p[off].i32, delay = length >> 16;
             if (delay) { rc = gs_data(&S, a[nf], 1 + (long long)delay); if (!rc) ws_state(&S, a[nf], 1 + (long long)delay); }
@@ -750,7 +777,7 @@ static int scan_generic(int format, opcode_t *core, avdsp_generic_desc *d, core_
                 if (alu_int)
                     rc = fail(-8, "word %d: DSP_FIR in int64 mode is undefined behaviour in the reference "
                                   "(dsp_firSTD.h:8-35) and is not provided", at);
-                else rc = gs_prog(&S, off, 1 + length) || gs_data(&S, a[nf], length);
+                else rc = gs_param(&S, off, 1 + length) || gs_data(&S, a[nf], length);
                 if (!rc) { ws_state(&S, a[nf], length); if (length + 64 > d->seq_words) d->seq_words = length + 64; }
             }
             break; }
@@ -765,7 +792,7 @@ static int scan_generic(int format, opcode_t *core, avdsp_generic_desc *d, core_
         case DSP_DITHER:
             rc = gs_payload(&S, 1) || gs_data(&S, a[0], 3ll * S.aw); if (!rc) { ws_state(&S, a[0], 3ll * S.aw); ws_tpdf_user(&S); } break;
         case DSP_DITHER_NS2:
-            rc = gs_payload(&S, 2) || gs_data(&S, a[0], 3) || gs_prog(&S, a[1] + fi * 3, 3);
+            rc = gs_payload(&S, 2) || gs_data(&S, a[0], 3) || gs_param(&S, a[1] + fi * 3, 3);
             if (!rc) { ws_state(&S, a[0], 3); ws_tpdf_user(&S); }
             break;
         case DSP_DISTRIB:
@@ -1002,6 +1029,10 @@ static int cores_meet(const core_deps *a, const core_deps *b)
         for (int j = 0; j < b->nwr; j++) { int d = a->wr_word[i] - b->wr_word[j]; if (d > -2 && d < 2) return 1; }
         for (int j = 0; j < b->nranges; j++) if (a->wr_word[i] + 2 > b->range[j][0] && a->wr_word[i] < b->range[j][1]) return 1;
     }
+    for (int i = 0; i < a->nwr; i++)
+        for (int j = 0; j < b->nparams; j++) if (a->wr_word[i] + 2 > b->param[j][0] && a->wr_word[i] < b->param[j][1]) return 1;
+    for (int i = 0; i < b->nwr; i++)
+        for (int j = 0; j < a->nparams; j++) if (b->wr_word[i] + 2 > a->param[j][0] && b->wr_word[i] < a->param[j][1]) return 1;
     for (int i = 0; i < a->nrd; i++)
         for (int j = 0; j < b->nwr; j++) { int d = a->rd_word[i] - b->wr_word[j]; if (d > -2 && d < 2) return 1; }
     for (int i = 0; i < b->nwr; i++)
