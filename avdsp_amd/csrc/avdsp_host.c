@@ -1045,7 +1045,7 @@ static int cores_meet(const core_deps *a, const core_deps *b)
 }
 
 static int block_all(int format, int *rundata, const void *in, int in_stride, int in_io_base,
-                     void *out, int out_stride, int out_io_base, int nframes, int on_device, void *stream)
+                     void *out, int out_stride, int out_io_base, int nframes, int on_device, void *stream, int pcm)
 {
     if (!dspHeaderPtr || !G.code) return fail(-1, "no program loaded");
     if (check_rundata(rundata)) return -1;
@@ -1075,8 +1075,8 @@ static int block_all(int format, int *rundata, const void *in, int in_stride, in
     int rc = on_device
         ? avdsp_hip_run_levels(G.dev, plans, size, nlevels, in, in_stride, in_io_base, out, out_stride, out_io_base,
                                nframes, G.opt_fir_impl, G.opt_biquad_impl, stream)
-        : avdsp_hip_run_levels_host(G.dev, plans, size, nlevels, in, in_stride, in_io_base, out, out_stride, out_io_base,
-                                    nframes, G.opt_fir_impl, G.opt_biquad_impl);
+        : avdsp_hip_run_levels_pcm_host(G.dev, plans, size, nlevels, pcm, in, in_stride, in_io_base, out, out_stride, out_io_base,
+                                        nframes, G.opt_fir_impl, G.opt_biquad_impl);
     if (rc) return fail(-10, "%s", avdsp_hip_last_error());
     G.last_levels = nlevels; G.last_cores = n;
     return 0;
@@ -1084,11 +1084,20 @@ static int block_all(int format, int *rundata, const void *in, int in_stride, in
 
 int dspRuntimeBlockAll(int format, int *rundata, const void *in, int in_stride, int in_io_base,
                        void *out, int out_stride, int out_io_base, int nframes)
-{ return block_all(format, rundata, in, in_stride, in_io_base, out, out_stride, out_io_base, nframes, 0, 0); }
+{ return block_all(format, rundata, in, in_stride, in_io_base, out, out_stride, out_io_base, nframes, 0, 0, AVDSP_PCM_S32); }
 
 int dspRuntimeBlockAllDevice(int format, int *rundata, const void *d_in, int in_stride, int in_io_base,
                              void *d_out, int out_stride, int out_io_base, int nframes, void *stream)
-{ return block_all(format, rundata, d_in, in_stride, in_io_base, d_out, out_stride, out_io_base, nframes, 1, stream); }
+{ return block_all(format, rundata, d_in, in_stride, in_io_base, d_out, out_stride, out_io_base, nframes, 1, stream, AVDSP_PCM_S32); }
+
+/* linux/avdsp_plugin.c:95-142 whole: packed PCM in (:109-121), every core, S32 out */
+int dspRuntimeBlockAllPcm(int format, int *rundata, int pcm, const void *src, int in_stride, int in_io_base,
+                          int *dst, int out_stride, int out_io_base, int nframes)
+{
+    if (format != 2 && format != 3 && format != 4)
+        return fail(-1, "packed PCM feeds the int-sample formats 2, 3 and 4 (DSP_FORMAT %d has float samples)", format);
+    return block_all(format, rundata, src, in_stride, in_io_base, dst, out_stride, out_io_base, nframes, 0, 0, pcm);
+}
 
 /* linux/avdsp_plugin.c:95-142 with the sample-format switch of :109-121: packed PCM in, S32 out */
 int dspRuntimeBlockPcm(int format, opcode_t *core, int *rundata, int pcm, const void *src, int in_stride, int in_io_base,

@@ -1555,6 +1555,44 @@ int avdsp_hip_run_block_pcm_host(avdsp_hip_prog *prog, int plan, int pcm, const 
     return 0;
 }
 
+/* packed PCM in front of avdsp_hip_run_levels_host: the block is uploaded and unpacked once for all cores */
+int avdsp_hip_run_levels_pcm_host(avdsp_hip_prog *prog, const int *plans, const int *level_size, int nlevels, int pcm,
+                                  const void *h_src, int in_stride, int in_io_base, void *h_out, int out_stride, int out_io_base,
+                                  int nframes, int fir_impl, int biquad_impl)
+{
+    if (pcm == AVDSP_PCM_S32)
+        return avdsp_hip_run_levels_host(prog, plans, level_size, nlevels, h_src, in_stride, in_io_base, h_out, out_stride,
+                                         out_io_base, nframes, fir_impl, biquad_impl);
+    if (pcm != AVDSP_PCM_S24_3LE && pcm != AVDSP_PCM_S16) return set_err("unknown PCM kind %d", pcm);
+    int total = 0;
+    for (int l = 0; l < nlevels; l++) total += level_size[l];
+    for (int i = 0; i < total; i++) {
+        if (plans[i] < 0 || plans[i] >= (int)prog->plans.size()) return set_err("bad plan id %d", plans[i]);
+        if (prog->plans[plans[i]].format > 4) return set_err("packed PCM input feeds the int-sample formats 2, 3, 4 only");
+    }
+    if (nframes <= 0) return 0;
+    const size_t nsamples = (size_t)nframes * in_stride, out_words = (size_t)nframes * out_stride;
+    const size_t raw_bytes = nsamples * (pcm == AVDSP_PCM_S16 ? 2 : 3), raw_words = (raw_bytes + 3) / 4;
+    const size_t unpacked = (nsamples + 3) & ~(size_t)3;          /* staging: [unpacked samples | raw bytes] in d_in */
+    if (prog->in_cap < unpacked + raw_words) {
+        (void)hipFree(prog->d_in); prog->d_in = nullptr; prog->in_cap = 0;
+        HIP_TRY(hipMalloc((void **)&prog->d_in, (unpacked + raw_words) * 4)); prog->in_cap = unpacked + raw_words;
+    }
+    if (prog->out_cap < out_words) {
+        (void)hipFree(prog->d_out); prog->d_out = nullptr; prog->out_cap = 0;
+        HIP_TRY(hipMalloc((void **)&prog->d_out, out_words * 4)); prog->out_cap = out_words;
+    }
+    unsigned *d_raw = prog->d_in + unpacked;
+    HIP_TRY(hipMemcpy(d_raw, h_src, raw_bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(prog->d_out, h_out, out_words * 4, hipMemcpyHostToDevice));
+    if (avdsp_hip_unpack_pcm(prog, pcm, d_raw, prog->d_in, nsamples, nullptr)) return -1;
+    if (avdsp_hip_run_levels(prog, plans, level_size, nlevels, prog->d_in, in_stride, in_io_base, prog->d_out, out_stride,
+                             out_io_base, nframes, fir_impl, biquad_impl, nullptr)) return -1;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(h_out, prog->d_out, out_words * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int avdsp_hip_profile_enable(avdsp_hip_prog *prog, int on)
 {
     prog->profile = on == 1 ? ~0u : (unsigned)on >> 1;     /* 0 off, 1 every kind, otherwise 2 * (mask of kinds) */

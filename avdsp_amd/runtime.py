@@ -27,13 +27,13 @@ EXPORTED = [
     "dspHeaderPtr", "dspBiquadFreqSkip", "dspMantissa", "dspOpcodeText", "dspQNM", "dspQM64", "dspQM32",
     # block extension (include/avdsp_runtime.h)
     "dspRuntimeBlock_2", "dspRuntimeBlock_3", "dspRuntimeBlock_4", "dspRuntimeBlock_5", "dspRuntimeBlock_6",
-    "dspRuntimeBlockDevice", "dspRuntimeBlockPcm", "dspRuntimeUnpackPcmDevice", "dspRuntimeBlockAll", "dspRuntimeBlockAllDevice",
+    "dspRuntimeBlockDevice", "dspRuntimeBlockPcm", "dspRuntimeUnpackPcmDevice", "dspRuntimeBlockAll", "dspRuntimeBlockAllDevice", "dspRuntimeBlockAllPcm",
     "dspRuntimeSyncState", "dspRuntimeUploadState", "dspRuntimeUploadParams", "dspRuntimeSetOption", "dspRuntimeGetOption",
     "dspRuntimeCoreInfo", "dspRuntimeKernelTime", "dspRuntimeLastError", "dspRuntimeRelease",
     # thin HIP ABI (include/avdsp_hip.h)
     "avdsp_hip_device_count", "avdsp_hip_set_device", "avdsp_hip_prog_create", "avdsp_hip_prog_destroy",
     "avdsp_hip_prog_add_plan", "avdsp_hip_prog_add_generic", "avdsp_hip_prog_clear_plans", "avdsp_hip_tpdf_reset", "avdsp_hip_upload_words", "avdsp_hip_download_words", "avdsp_hip_zero_words",
-    "avdsp_hip_run_block", "avdsp_hip_run_block_host", "avdsp_hip_run_levels", "avdsp_hip_run_levels_host", "avdsp_hip_unpack_pcm", "avdsp_hip_run_block_pcm_host", "avdsp_hip_profile_enable", "avdsp_hip_profile_read",
+    "avdsp_hip_run_block", "avdsp_hip_run_block_host", "avdsp_hip_run_levels", "avdsp_hip_run_levels_host", "avdsp_hip_run_levels_pcm_host", "avdsp_hip_unpack_pcm", "avdsp_hip_run_block_pcm_host", "avdsp_hip_profile_enable", "avdsp_hip_profile_read",
     "avdsp_hip_synchronize", "avdsp_hip_last_error",
 ]
 
@@ -97,6 +97,8 @@ def lib() -> C.CDLL:
         L.dspRuntimeBlockAll.argtypes = [i32, vp, vp, i32, i32, vp, i32, i32, i32]
         L.dspRuntimeBlockAllDevice.restype = i32
         L.dspRuntimeBlockAllDevice.argtypes = [i32, vp, vp, i32, i32, vp, i32, i32, i32, vp]
+        L.dspRuntimeBlockAllPcm.restype = i32
+        L.dspRuntimeBlockAllPcm.argtypes = [i32, vp, i32, vp, i32, i32, vp, i32, i32, i32]
         L.dspRuntimeBlockPcm.restype = i32
         L.dspRuntimeBlockPcm.argtypes = [i32, vp, vp, i32, vp, i32, i32, vp, i32, i32, i32]
         L.dspRuntimeUnpackPcmDevice.restype = i32
@@ -221,6 +223,21 @@ class Runtime:
             b1 = min(b0 + block, nframes)
             self._check(self.L.dspRuntimeBlockAll(self.fmt, self.rundata, x[b0:b1].ctypes.data, in_stride, in_io_base,
                                                   out[b0:b1].ctypes.data, out_stride, out_io_base, b1 - b0))
+        return out
+
+    def run_block_all_pcm(self, pcm: int, raw: np.ndarray, nframes: int, in_stride: int, out_stride: int,
+                          in_io_base: int, out_io_base: int = 0, block: int | None = None) -> np.ndarray:
+        """dspRuntimeBlockAllPcm: packed PCM bytes in, every core, S32 out."""
+        raw = np.ascontiguousarray(raw, dtype=np.uint8)
+        width = {PCM_S32: 4, PCM_S24_3LE: 3, PCM_S16: 2}[pcm]
+        assert raw.size == nframes * in_stride * width
+        out = np.zeros((nframes, out_stride), dtype=np.int32)
+        block = block or nframes
+        for b0 in range(0, nframes, block):
+            b1 = min(b0 + block, nframes)
+            src = raw[b0 * in_stride * width:b1 * in_stride * width]
+            self._check(self.L.dspRuntimeBlockAllPcm(self.fmt, self.rundata, pcm, src.ctypes.data, in_stride, in_io_base,
+                                                     out[b0:b1].ctypes.data, out_stride, out_io_base, b1 - b0))
         return out
 
     def get_option(self, key: str) -> int:

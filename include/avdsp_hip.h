@@ -123,6 +123,10 @@ int avdsp_hip_run_levels_host(avdsp_hip_prog *prog, const int *plans, const int 
                               const void *h_in, int in_stride, int in_io_base, void *h_out, int out_stride, int out_io_base,
                               int nframes, int fir_impl, int biquad_impl);
 
+int avdsp_hip_run_levels_pcm_host(avdsp_hip_prog *prog, const int *plans, const int *level_size, int nlevels, int pcm,
+                                  const void *h_src, int in_stride, int in_io_base, void *h_out, int out_stride, int out_io_base,
+                                  int nframes, int fir_impl, int biquad_impl);     /* packed PCM in (AVDSP_PCM_*), unpacked once */
+
 /* host-buffer convenience: stages in/out through device scratch and synchronises               */
 int avdsp_hip_run_block_host(avdsp_hip_prog *prog, int plan, const void *h_in, int in_stride, int in_io_base,
                              void *h_out, int out_stride, int out_io_base, int nframes,

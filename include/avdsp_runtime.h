@@ -113,6 +113,9 @@ int dspRuntimeBlockAll(int format, int *rundata, const void *in, int in_stride, 
                        void *out, int out_stride, int out_io_base, int nframes);
 int dspRuntimeBlockAllDevice(int format, int *rundata, const void *d_in, int in_stride, int in_io_base,
                              void *d_out, int out_stride, int out_io_base, int nframes, void *stream);
+/* the same with the plugin's packed PCM input (AVDSP_PCM_S16 / S24_3LE / S32, formats 2, 3, 4), unpacked once */
+int dspRuntimeBlockAllPcm(int format, int *rundata, int pcm, const void *src, int in_stride, int in_io_base,
+                          int *dst, int out_stride, int out_io_base, int nframes);
 
 /* The host's sample-format step (linux/avdsp_plugin.c:103-121): `src` holds packed little-endian PCM,
  * frame-interleaved [nframes][in_stride]; pcm = AVDSP_PCM_S32 | AVDSP_PCM_S24_3LE | AVDSP_PCM_S16

@@ -209,6 +209,26 @@ def test_packed_pcm_into_the_general_interpreter_and_refusal():
     assert e.value.code == -1 and "int-sample" in str(e.value)
 
 
+@pytest.mark.parametrize("pcm", [rt.PCM_S16, rt.PCM_S24_3LE, rt.PCM_S32])
+def test_packed_pcm_through_every_core_at_once(pcm):
+    """dspRuntimeBlockAllPcm = the plugin's whole transfer function: unpack once, every core, S32 out"""
+    prog = np.fromfile(os.path.join(os.path.dirname(__file__), "golden", "dacdiy1.bin"), dtype=np.uint32)
+    x = pb.lcg_input(300, 8, False, seed=4)
+    if pcm == rt.PCM_S32:
+        raw, xq = np.ascontiguousarray(x).view(np.uint8).reshape(-1), x
+    else:
+        raw = _pack(x, pcm)
+        xq = _unpack_like_the_plugin(raw, pcm).reshape(300, 8)
+    o = po.OracleProgram(2, prog, fs=48000, random=2, dither=24)
+    want = o.run_block(xq, 8, 8, 0, block=100, frame=np.zeros(4096, dtype=np.uint32))     # the plugin's IO layout: out 0..7, in 8..15
+    r = rt.Runtime(2, prog, fs=48000, random=2, dither=24)
+    got = r.run_block_all_pcm(pcm, raw, 300, 8, 8, 8, 0, block=100)
+    assert (got == want).all()
+    assert (r.sync_state() == o.state).all()
+    assert (r.get_option("levels"), r.get_option("cores")) == (2, 4)
+    r.release()
+
+
 def test_unpack_on_device_misaligned_source():
     torch = pytest.importorskip("torch")
     r = rt.Runtime(2, pb.synth_program(2, 2, 1))

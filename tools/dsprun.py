@@ -77,8 +77,8 @@ def main():
         raw, pcm = np.ascontiguousarray(x).view(np.uint8).reshape(-1), rt.PCM_S32
     if a.frames:
         frames = min(frames, a.frames)
-    out = r.run_block_pcm(pcm, raw[:frames * nin * {rt.PCM_S32: 4, rt.PCM_S24_3LE: 3, rt.PCM_S16: 2}[pcm]], frames, nin, nout,
-                          in_base, out_base, block=a.block)
+    out = r.run_block_all_pcm(pcm, raw[:frames * nin * {rt.PCM_S32: 4, rt.PCM_S24_3LE: 3, rt.PCM_S16: 2}[pcm]], frames, nin, nout,
+                              in_base, out_base, block=a.block)          # every core per block, cores that do not meet together
     if a.out.endswith(".wav"):
         with wave.open(a.out, "wb") as w:
             w.setnchannels(nout); w.setsampwidth(4); w.setframerate(a.fs)
