@@ -1100,7 +1100,12 @@ int avdsp_hip_prog_add_plan(avdsp_hip_prog *prog, const avdsp_plan_desc *d)
     }
     if (upload_vec(&pl.d_chains, chains) || upload_vec(&pl.d_sec_coef, coef) || upload_vec(&pl.d_sec_state, state)) { free_plan(pl); return -1; }
     for (auto &e : byN) {                                /* > 64 sections (P = 128): biquad_simple */
-        Plan::Group g{e.first > 64 ? 128 : pow2ceil(e.first), e.first, (int)e.second.size(), nullptr};
+        /* lanes per chain: the next power of two -- but a 16-lane row per chain while the chip has SIMDs to spare
+         * (<= 1024 waves): its step is shorter (one input batch per 16 steps, no mid-row section-0 lanes: cfg5's
+         * 8-section cascades 85 -> 62 us) and idle lanes cost nothing there */
+        int P = e.first > 64 ? 128 : pow2ceil(e.first);
+        if (P < 16 && (long long)e.second.size() * 16 <= 65536) P = 16;
+        Plan::Group g{P, e.first, (int)e.second.size(), nullptr};
         if (upload_vec(&g.d_ids, e.second)) { free_plan(pl); return -1; }
         pl.bq.push_back(g);
     }
