@@ -380,3 +380,22 @@ def test_block_all_orders_a_core_behind_the_one_that_computes_its_gain():
         x = pb.lcg_input(300, 8, False, seed=8)
         for block in (7, 300):
             assert _all_vs_per_core(fmt, prog, x, 8, IN, 0, block, seed=0) == (2, 3)
+
+
+@pytest.mark.parametrize("fmt", [3, 4, 5, 6])
+def test_long_fir_in_an_interpreted_core(fmt):
+    """a 3000-tap DSP_FIR next to a delay line (so the core is not a chain): the frame-parallel FIR reads a
+    3000 + 64 word sequence from LDS, every lane in the reference's tap order"""
+    taps = (np.random.default_rng(3).uniform(-1, 1, 3000) / 200).astype(np.float32)
+
+    def build(L):
+        L.dsp_PARAM()
+        imp = L.dspFir_Impulses()
+        L.dspFir_ImpulseData(taps.ctypes.data_as(C.POINTER(C.c_float)), 3000)
+        L.dsp_CORE()
+        L.dsp_LOAD_GAIN_Fixed(IN, 0.9); L.dsp_DELAY_1(); L.dsp_FIR(imp); L.dsp_SAT0DB(); L.dsp_STORE(0)
+    prog = encode(build, fmt)
+    x = pb.lcg_input(500, 8, fmt in (5, 6), seed=12)
+    for block in (64, 500):
+        run_both(fmt, prog, x, 8, IN, 0, block, expect_wave=True)
+    run_both(fmt, prog, x, 8, IN, 0, 500, expect_wave=False, impl=0)
