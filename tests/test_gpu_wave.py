@@ -399,3 +399,17 @@ def test_long_fir_in_an_interpreted_core(fmt):
     for block in (64, 500):
         run_both(fmt, prog, x, 8, IN, 0, block, expect_wave=True)
     run_both(fmt, prog, x, 8, IN, 0, 500, expect_wave=False, impl=0)
+
+
+def test_io_numbers_beyond_the_frame_parallel_limit():
+    """IO numbers >= 256: more frame than the per-lane layout holds -> frame by frame, the core runs alone"""
+    def build(L):
+        L.dsp_CORE()
+        L.dsp_LOAD_GAIN_Fixed(300, 0.5); L.dsp_DELAY_1(); L.dsp_STORE(2)
+        L.dsp_CORE()
+        L.dsp_LOAD_GAIN_Fixed(301, 0.25); L.dsp_DELAY_1(); L.dsp_STORE(3)
+    for fmt in (2, 6):
+        prog = encode(build, fmt, max_io=320)
+        x = pb.lcg_input(200, 8, fmt == 6, seed=4)
+        run_both(fmt, prog, x, 8, 298, 0, 200, expect_wave=False, span=320)
+        assert _all_vs_per_core(fmt, prog, x, 8, 298, 0, 100, seed=0) == (2, 2)
