@@ -232,7 +232,7 @@ def test_golden_general_interpreter(case):
 
 
 @pytest.mark.parametrize("interp_impl", [1, 0], ids=["frame_parallel", "frame_by_frame"])
-@pytest.mark.parametrize("seed", list(range(12, 72)) + [344, 373, 416, 462, 2260])     # the last five: NaN payloads through float / double adds
+@pytest.mark.parametrize("seed", list(range(12, 72)) + [344, 373, 416, 462, 2260, 6273])     # the last six: NaN payloads through float / double adds
 def test_random_programs_vs_oracle(seed, interp_impl):
     """More random programs than there are goldens: the interpreter against the oracle (itself held to the
     compiled reference on these generators, tests/golden/make_goldens.py and 800+ runs while developing),
