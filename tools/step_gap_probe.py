@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""What an event pair around every launch costs the stream: the north-star step (biquad + FIR kernel) with the
+library's per-kernel HIP events on and off, wall time per step over 30 steps.  Run on the GPU box:
+python tools/step_gap_probe.py   ->  profile 1: 0.62 ms/step, profile 0: 0.60 ms/step"""
 import sys, time; sys.path.insert(0,'.')
 import numpy as np, torch
 from avdsp_amd import progbuilder as pb, runtime as rt, sharding as sh
