@@ -57,12 +57,13 @@ typedef struct {
 typedef struct {
     opcode_t   *core;            /* key: the pointer the host passes (after dspFindCoreBegin) */
     int         format;
+    int         end_word;        /* 0: the whole core; else a strand group [core, end_word) of it */
     int         plan_id;         /* id inside the device program, < 0 = lowering failed */
     int         nchains, max_sections, max_taps;      /* nchains 0 = general interpreter */
     core_deps   deps;
 } core_plan;
 
-#define MAX_CORE_PLANS 64
+#define MAX_CORE_PLANS 512          /* cores, and the strand groups dspRuntimeBlockAll cuts them into */
 
 static struct {
     opcode_t       *code;
@@ -76,8 +77,10 @@ static struct {
     int             nplans;
     int             opt_fir_impl, opt_biquad_impl, opt_device, opt_profile, opt_generic, opt_interp_impl;
     int             device_selected;
-    int             last_levels, last_cores;       /* of the latest dspRuntimeBlockAll: dspRuntimeGetOption("levels" / "cores") */
-} G = { .opt_fir_impl = 1, .opt_biquad_impl = 1, .opt_device = -1, .opt_interp_impl = 1 };
+    int             last_levels, last_cores, last_pieces;  /* of the latest dspRuntimeBlockAll: dspRuntimeGetOption("levels" / "cores" / "pieces") */
+    int             opt_strand_split;
+    int             all_valid, all_format, all_n, all_nlevels, all_plans[MAX_CORE_PLANS], all_size[MAX_CORE_PLANS];
+} G = { .opt_fir_impl = 1, .opt_biquad_impl = 1, .opt_device = -1, .opt_interp_impl = 1, .opt_strand_split = 1 };
 
 static char g_err[512];
 static int  g_err_code;
@@ -99,6 +102,7 @@ static void drop_device(void)
     if (G.dev) avdsp_hip_prog_destroy(G.dev);
     G.dev = 0;
     G.nplans = 0;
+    G.all_valid = 0;
     G.dev_state_valid = 0;
 }
 
@@ -115,6 +119,7 @@ static int replan(void)
 {
     if (G.dev && avdsp_hip_prog_clear_plans(G.dev)) return fail(-10, "%s", avdsp_hip_last_error());
     G.nplans = 0;
+    G.all_valid = 0;
     return 0;
 }
 
@@ -125,6 +130,7 @@ int dspRuntimeSetOption(const char *key, int value)
     if (!strcmp(key, "device"))      { G.opt_device = value; G.device_selected = 0; return 0; }
     if (!strcmp(key, "generic"))     { G.opt_generic = value; return replan(); }
     if (!strcmp(key, "interp_impl")) { G.opt_interp_impl = value; return replan(); }
+    if (!strcmp(key, "strand_split")) { G.opt_strand_split = value; return replan(); }
     if (!strcmp(key, "profile")) {
         G.opt_profile = value;
         if (G.dev) avdsp_hip_profile_enable(G.dev, value);
@@ -143,6 +149,8 @@ int dspRuntimeGetOption(const char *key)
     if (!strcmp(key, "interp_impl")) return G.opt_interp_impl;
     if (!strcmp(key, "levels"))      return G.last_levels;
     if (!strcmp(key, "cores"))       return G.last_cores;
+    if (!strcmp(key, "pieces"))      return G.last_pieces;
+    if (!strcmp(key, "strand_split")) return G.opt_strand_split;
     return -1;
 }
 
@@ -638,7 +646,7 @@ static unsigned char *store_mem_map(void)
     return map;
 }
 
-static int scan_generic(int format, opcode_t *core, avdsp_generic_desc *d, core_deps *deps)
+static int scan_generic(int format, opcode_t *core, int end_word, avdsp_generic_desc *d, core_deps *deps)
 {
     if (format < 2 || format > 6) return fail(-1, "DSP_FORMAT %d is not one of 2..6", format);
     if ((format == DSP_FORMAT_INT64) != (dspHeaderPtr->format != 0))
@@ -655,9 +663,10 @@ static int scan_generic(int format, opcode_t *core, avdsp_generic_desc *d, core_
     S.w.ok = G.opt_interp_impl != 0;
     S.w.complete = 1;
     d->io_in_min = d->io_out_min = GENERIC_IO_LIMIT; d->io_in_max = d->io_out_max = -1;
-    opcode_t *p = dspFindCoreBegin(core);
+    opcode_t *p = end_word ? core : dspFindCoreBegin(core);      /* a strand group starts where it starts */
     d->format = format;
     d->core_word = (int)(p - G.code);
+    d->end_word = end_word;
     d->prog_words = S.prog_words;
     d->freq_index = fi; d->num_freq = nf;
     d->biquad_freq_skip = dspBiquadFreqSkip; d->biquad_freq_offset = G.biquad_offset;
@@ -669,7 +678,7 @@ static int scan_generic(int format, opcode_t *core, avdsp_generic_desc *d, core_
         const int *a = (const int *)p + 1;
         const int at = (int)(p - G.code);
         if (at < 0 || at >= S.prog_words) { free(smap); return fail(-8, "opcode stream runs past the program (word %d)", at); }
-        if (skip == 0 || op == DSP_CORE || op == DSP_END_OF_CODE) break;
+        if (skip == 0 || op == DSP_CORE || op == DSP_END_OF_CODE || at == end_word) break;
         if ((long long)at + skip > S.prog_words) { free(smap); return fail(-8, "word %d: opcode longer than the program", at); }
         S.at = at; S.skip = skip;
         int rc = 0;
@@ -855,13 +864,14 @@ static int select_device(void)
 }
 
 /* find or build the device plan of (core, format) */
-static core_plan *get_plan(int format, opcode_t *core)
+/* end_word != 0: the plan of a strand group [core, end_word) of an interpreted core (dspRuntimeBlockAll) */
+static core_plan *get_plan_range(int format, opcode_t *core, int end_word)
 {
     if (!dspHeaderPtr || !G.code) { fail(-1, "no program loaded"); return 0; }
     if (!G.have_rate) { fail(-1, "dspRuntimeReset(fs) has not selected a sample rate yet"); return 0; }
     if (format < 2 || format > 6) { fail(-1, "DSP_FORMAT %d is not one of 2..6", format); return 0; }
     for (int i = 0; i < G.nplans; i++)
-        if (G.plans[i].core == core && G.plans[i].format == format) {
+        if (G.plans[i].core == core && G.plans[i].format == format && G.plans[i].end_word == end_word) {
             if (G.plans[i].plan_id < 0) { fail(-8, "core was refused earlier"); return 0; }
             return &G.plans[i];
         }
@@ -874,14 +884,14 @@ static core_plan *get_plan(int format, opcode_t *core)
     avdsp_generic_desc gd;
     int chains = 0;
     memset(&L, 0, sizeof L);
-    if ((format == 2 || format == 4 || format == 6) && !G.opt_generic) {
+    if ((format == 2 || format == 4 || format == 6) && !G.opt_generic && !end_word) {
         int rc = lower_core(format, core, &L);
         if (rc == 0) chains = 1;
         else { lowered_free(&L); if (rc != -8) return 0; }
     }
     core_deps deps;
     memset(&deps, 0, sizeof deps);                   /* chain cores: complete = 0, they run alone */
-    if (!chains && scan_generic(format, core, &gd, &deps)) return 0;
+    if (!chains && scan_generic(format, core, end_word, &gd, &deps)) return 0;
 
     if (select_device()) { lowered_free(&L); return 0; }
     if (!G.dev) {
@@ -895,7 +905,7 @@ static core_plan *get_plan(int format, opcode_t *core)
         avdsp_hip_profile_enable(G.dev, G.opt_profile);
     }
     core_plan *cp = &G.plans[G.nplans];
-    cp->core = core; cp->format = format;
+    cp->core = core; cp->format = format; cp->end_word = end_word;
     cp->nchains = 0; cp->max_sections = 0; cp->max_taps = 0;
     cp->deps = deps;
     if (chains) {
@@ -918,6 +928,8 @@ static core_plan *get_plan(int format, opcode_t *core)
     G.nplans++;
     return cp;
 }
+
+static core_plan *get_plan(int format, opcode_t *core) { return get_plan_range(format, core, 0); }
 
 int dspRuntimeKernelTime(int kind, double *total_ms, int *launches)
 {
@@ -950,7 +962,7 @@ int dspRuntimeCoreInfo(int format, opcode_t *core, int *nchains, int *max_sectio
     }
     if (rc == -8) {
         avdsp_generic_desc gd;
-        rc = scan_generic(format, core, &gd, 0);
+        rc = scan_generic(format, core, 0, &gd, 0);
     }
     if (rc) return rc;
     if (nchains) *nchains = nc;
@@ -1044,41 +1056,168 @@ static int cores_meet(const core_deps *a, const core_deps *b)
     return 0;
 }
 
+/* ---- strand groups ----
+ * Inside a core the strands -- LOAD ... STORE runs -- mostly do not depend on each other either: a strand that
+ * begins by replacing X and never looks at the Y it inherits carries nothing over from the strand in front of it.
+ * Cut there, a core becomes several pieces that go through the same "do they meet" test as whole cores and may run
+ * at the same time (a wide program with one strand per channel turns into many workgroups instead of one wave).
+ * A cut is legal in front of LOAD / LOAD_GAIN / LOAD_MEM / LOAD_MUX / CLRXY when, from there on, nothing reads Y
+ * before Y has been set from this piece's own X; a core with a DSP_TPDF opcode (which switches the dither width
+ * for the rest of the frame) is left whole.  Returns the number of pieces, starts[] = their first opcode words. */
+#define MAX_GROUPS 64
+static int reads_y(int op)
+{
+    switch (op) {
+    case DSP_SWAPXY: case DSP_COPYYX: case DSP_ADDXY: case DSP_ADDYX: case DSP_SUBXY: case DSP_SUBYX: case DSP_MULXY:
+    case DSP_DIVXY: case DSP_DIVYX: case DSP_AVGXY: case DSP_AVGYX: case DSP_NEGY: case DSP_RMS:
+        return 1;
+    }
+    return 0;
+}
+static int sets_y_from_x(int op)
+{
+    switch (op) {
+    case DSP_LOAD: case DSP_LOAD_GAIN: case DSP_LOAD_MEM: case DSP_VALUE: case DSP_VALUE_INT: case DSP_DELAY_1:
+    case DSP_COPYXY: case DSP_CLRXY: case DSP_SINE:
+        return 1;
+    }
+    return 0;
+}
+static int split_core(opcode_t *core, int *starts)
+{
+    const int total = dspHeaderPtr->totalLength;
+    opcode_t *p0 = dspFindCoreBegin(core);
+    int at[4096], op[4096], n = 0;
+    for (opcode_t *p = p0;;) {
+        const int w = (int)(p - G.code);
+        if (w < 0 || w >= total) return 0;                     /* damaged: the scan will say so */
+        const int o = p->op.opcode; const unsigned skip = p->op.skip;
+        if (skip == 0 || o == DSP_CORE || o == DSP_END_OF_CODE) break;
+        if (o == DSP_TPDF) { n = -1; break; }
+        if (n == 4096) { n = -1; break; }
+        at[n] = w; op[n] = o; n++;
+        p += skip;
+    }
+    starts[0] = (int)(p0 - G.code);
+    if (n < 8) return 1;
+    /* legal cuts */
+    int cut[4096], ncut = 0;
+    for (int i = 1; i < n; i++) {
+        if (op[i] != DSP_LOAD && op[i] != DSP_LOAD_GAIN && op[i] != DSP_LOAD_MEM && op[i] != DSP_LOAD_MUX && op[i] != DSP_CLRXY) continue;
+        int legal = 1;
+        if (op[i] != DSP_CLRXY)
+            for (int k = i + 1; k < n; k++) {
+                if (reads_y(op[k])) { legal = 0; break; }
+                if (sets_y_from_x(op[k])) break;
+            }
+        if (legal) cut[ncut++] = i;
+    }
+    if (!ncut) return 1;
+    /* pieces of at least 4 opcodes, at most MAX_GROUPS of them, as even as the cuts allow */
+    int groups = n / 4;
+    if (groups > MAX_GROUPS) groups = MAX_GROUPS;
+    if (groups > ncut + 1) groups = ncut + 1;
+    int ng = 1, last = 0;
+    for (int g = 1; g < groups; g++) {
+        const int want = (int)((long long)n * g / groups);
+        int best = -1;
+        for (int c = 0; c < ncut; c++) if (cut[c] >= want && cut[c] > last) { best = cut[c]; break; }
+        if (best < 0 || n - best < 4 || best - last < 4) continue;
+        starts[ng++] = at[best];
+        last = best;
+    }
+    return ng;
+}
+
 static int block_all(int format, int *rundata, const void *in, int in_stride, int in_io_base,
                      void *out, int out_stride, int out_io_base, int nframes, int on_device, void *stream, int pcm)
 {
     if (!dspHeaderPtr || !G.code) return fail(-1, "no program loaded");
     if (check_rundata(rundata)) return -1;
     if (nframes <= 0) return 0;
-    core_plan *cp[MAX_CORE_PLANS];
-    int level[MAX_CORE_PLANS], n = 0, nlevels = 0;
-    for (int k = 1; k <= MAX_CORE_PLANS; k++) {
-        opcode_t *c = dspFindCore(G.code, k);
-        if (!c || (k > 1 && c == G.code)) break;
-        cp[n] = get_plan(format, dspFindCoreBegin(c));
-        if (!cp[n]) return g_err_code;
-        n++;
-        if (c == G.code) break;                           /* a program without DSP_CORE is one core */
+    /* the arrangement is worked out once per lowering (plans live until the next reset / option / parameter upload) */
+    if (!G.all_valid || G.all_format != format) {
+        static core_plan *cp[MAX_CORE_PLANS];
+        static int level[MAX_CORE_PLANS];
+        int n = 0, nlevels = 0, ncores = 0;
+        for (int k = 1; k <= MAX_CORE_PLANS; k++) {
+            opcode_t *c = dspFindCore(G.code, k);
+            if (!c || (k > 1 && c == G.code)) break;
+            opcode_t *begin = dspFindCoreBegin(c);
+            ncores++;
+            int starts[MAX_GROUPS + 1], ng = 1;
+            core_plan *whole = get_plan(format, begin);           /* also tells whether the core is a chain core */
+            if (!whole) return g_err_code;
+            if (G.opt_strand_split && whole->nchains == 0) ng = split_core(c, starts);
+            if (ng > 1) {
+                /* Inside a core everything happens frame by frame: a later strand sees what an earlier one stored in
+                 * the SAME frame (slots, memories, dither state).  Between launches it would see the last frame's.
+                 * So the pieces of one core must not meet at all; pieces that do are joined again (with whatever
+                 * lies between them), until the rest are strangers to each other. */
+                static core_deps pd[MAX_GROUPS];
+                avdsp_generic_desc gd;
+                starts[ng] = dspHeaderPtr->totalLength;
+                for (int g = 0; g < ng; g++)
+                    if (scan_generic(format, G.code + starts[g], starts[g + 1], &gd, &pd[g])) return g_err_code;
+                for (int again = 1; again && ng > 1;) {
+                    again = 0;
+                    for (int k = 1; k < ng && !again; k++)
+                        for (int j = 0; j < k; j++)
+                            if (cores_meet(&pd[j], &pd[k])) {
+                                /* join pieces j..k: drop the starts j+1..k, rescan the joined range */
+                                const int gone = k - j;
+                                for (int t = j + 1; t + gone <= ng; t++) starts[t] = starts[t + gone];
+                                for (int t = j + 1; t + gone < ng; t++) pd[t] = pd[t + gone];
+                                ng -= gone;
+                                if (scan_generic(format, G.code + starts[j], starts[j + 1], &gd, &pd[j])) return g_err_code;
+                                again = 1;
+                                break;
+                            }
+                }
+            }
+            if (ng <= 1) {
+                if (n == MAX_CORE_PLANS) return fail(-9, "too many cores");
+                cp[n++] = whole;
+            } else
+                for (int g = 0; g < ng; g++) {
+                    if (n == MAX_CORE_PLANS) return fail(-9, "too many cores");
+                    cp[n] = get_plan_range(format, G.code + starts[g], g + 1 < ng ? starts[g + 1] : dspHeaderPtr->totalLength);
+                    if (!cp[n]) return g_err_code;
+                    n++;
+                }
+            if (c == G.code) break;                           /* a program without DSP_CORE is one core */
+        }
+        if (n == 0) return fail(-3, "no cores defined in the program");
+        for (int i = 0; i < n; i++) {
+            level[i] = 0;
+            for (int j = 0; j < i; j++)
+                if (level[j] + 1 > level[i] && cores_meet(&cp[j]->deps, &cp[i]->deps)) level[i] = level[j] + 1;
+            if (level[i] + 1 > nlevels) nlevels = level[i] + 1;
+        }
+        if (getenv("AVDSP_DEBUG_LEVELS"))
+            for (int i = 0; i < n; i++) {
+                fprintf(stderr, "piece %d: words [%d,%d) level %d complete %d calc %d user %d nwr %d nrd %d nranges %d nparams %d meets:", i,
+                        (int)(cp[i]->core - G.code), cp[i]->end_word, level[i], cp[i]->deps.complete, cp[i]->deps.tpdf_calc,
+                        cp[i]->deps.tpdf_user, cp[i]->deps.nwr, cp[i]->deps.nrd, cp[i]->deps.nranges, cp[i]->deps.nparams);
+                for (int j = 0; j < i; j++) if (cores_meet(&cp[j]->deps, &cp[i]->deps)) fprintf(stderr, " %d", j);
+                fprintf(stderr, "\n");
+            }
+        int m = 0;
+        for (int l = 0; l < nlevels; l++) {
+            G.all_size[l] = 0;
+            for (int i = 0; i < n; i++) if (level[i] == l) { G.all_plans[m++] = cp[i]->plan_id; G.all_size[l]++; }
+        }
+        G.all_nlevels = nlevels; G.all_n = n; G.all_format = format; G.all_valid = 1;
+        G.last_levels = nlevels; G.last_cores = ncores; G.last_pieces = n;
     }
-    if (n == 0) return fail(-3, "no cores defined in the program");
-    for (int i = 0; i < n; i++) {
-        level[i] = 0;
-        for (int j = 0; j < i; j++)
-            if (level[j] + 1 > level[i] && cores_meet(&cp[j]->deps, &cp[i]->deps)) level[i] = level[j] + 1;
-        if (level[i] + 1 > nlevels) nlevels = level[i] + 1;
-    }
-    int plans[MAX_CORE_PLANS], size[MAX_CORE_PLANS], m = 0;
-    for (int l = 0; l < nlevels; l++) {
-        size[l] = 0;
-        for (int i = 0; i < n; i++) if (level[i] == l) { plans[m++] = cp[i]->plan_id; size[l]++; }
-    }
+    const int *plans = G.all_plans, *size = G.all_size;
+    const int nlevels = G.all_nlevels;
     int rc = on_device
         ? avdsp_hip_run_levels(G.dev, plans, size, nlevels, in, in_stride, in_io_base, out, out_stride, out_io_base,
                                nframes, G.opt_fir_impl, G.opt_biquad_impl, stream)
         : avdsp_hip_run_levels_pcm_host(G.dev, plans, size, nlevels, pcm, in, in_stride, in_io_base, out, out_stride, out_io_base,
                                         nframes, G.opt_fir_impl, G.opt_biquad_impl);
     if (rc) return fail(-10, "%s", avdsp_hip_last_error());
-    G.last_levels = nlevels; G.last_cores = n;
     return 0;
 }
 
@@ -1162,6 +1301,7 @@ int dspRuntimeUploadParams(void)
         avdsp_hip_upload_words(G.dev, (const int32_t *)G.code, first, dspHeaderPtr->totalLength - first))
         return fail(-10, "%s", avdsp_hip_last_error());
     G.nplans = 0;                                             /* cores are lowered again at their next block */
+    G.all_valid = 0;
     return 0;
 }
 

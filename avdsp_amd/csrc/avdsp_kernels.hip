@@ -877,6 +877,11 @@ struct avdsp_hip_prog {
     std::vector<Span> spans;            /* recorded, not yet read */
     std::vector<hipEvent_t> free_events;
     /* cores of one level side by side (avdsp_hip_run_levels): side streams and their fork / join events */
+    /* argument tables of grid launches (avdsp_hip_run_levels): a small ring of pinned host / device slot pairs, a slot
+     * is reused once the launch that read it has finished */
+    static constexpr int kTableSlots = 4;
+    GenericArgs *h_table = nullptr, *d_table = nullptr; int table_cap = 0, table_next = 0;
+    hipEvent_t table_done[kTableSlots] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<hipStream_t> side;
     std::vector<hipEvent_t> join;
     hipEvent_t fork = nullptr;
@@ -1053,6 +1058,8 @@ void avdsp_hip_prog_destroy(avdsp_hip_prog *p)
     for (auto &pl : p->plans) free_plan(pl);
     for (auto &sp : p->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (auto e : p->free_events) (void)hipEventDestroy(e);
+    (void)hipFree(p->d_table); (void)hipHostFree(p->h_table);
+    for (auto e : p->table_done) if (e) (void)hipEventDestroy(e);
     for (auto st : p->side) (void)hipStreamDestroy(st);
     for (auto e : p->join) (void)hipEventDestroy(e);
     if (p->fork) (void)hipEventDestroy(p->fork);
@@ -1144,7 +1151,8 @@ static const size_t kGenericLdsMax = 144 * 1024;     /* bytes */
 int avdsp_hip_prog_add_generic(avdsp_hip_prog *prog, const avdsp_generic_desc *d)
 {
     if (d->format < 2 || d->format > 6) return set_err("format %d is not one of 2..6", d->format);
-    if (d->core_word < 0 || d->core_word >= d->prog_words || d->prog_words > prog->total_words || d->io_span < 1)
+    if (d->core_word < 0 || d->core_word >= d->prog_words || d->prog_words > prog->total_words || d->io_span < 1 ||
+        (d->end_word && (d->end_word <= d->core_word || d->end_word > d->prog_words)))
         return set_err("generic plan: core word %d / program %d words / IO span %d do not fit the mirror (%d words)",
                        d->core_word, d->prog_words, d->io_span, prog->total_words);
     if (!prog->d_tpdf) return set_err("generic plan before avdsp_hip_tpdf_reset");
@@ -1153,7 +1161,7 @@ int avdsp_hip_prog_add_generic(avdsp_hip_prog *prog, const avdsp_generic_desc *d
     pl.io_in_min = d->io_in_min; pl.io_in_max = d->io_in_max; pl.io_out_min = d->io_out_min; pl.io_out_max = d->io_out_max;
     GenericArgs &a = pl.ga;
     a.buf = prog->d_buf; a.tpdf = prog->d_tpdf;
-    a.core_word = d->core_word; a.prog_words = d->prog_words;
+    a.core_word = d->core_word; a.prog_words = d->prog_words; a.end_word = d->end_word;
     a.freq_index = d->freq_index; a.num_freq = d->num_freq;
     a.biquad_skip = d->biquad_freq_skip; a.biquad_offset = d->biquad_freq_offset;
     a.delay_factor = d->delay_line_factor;
@@ -1209,6 +1217,11 @@ int avdsp_hip_prog_add_generic(avdsp_hip_prog *prog, const avdsp_generic_desc *d
                        : d->format == 4 ? (const void *)interp_wave<4> : d->format == 5 ? (const void *)interp_wave<5>
                                                                                         : (const void *)interp_wave<6>;
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGenericLdsMax);
+        if (e != hipSuccess) { (void)hipFree(pl.d_own); return set_err("hipFuncSetAttribute(frame-parallel LDS): %s", hipGetErrorString(e)); }
+        const void *gfn = d->format == 2 ? (const void *)interp_wave_grid<2> : d->format == 3 ? (const void *)interp_wave_grid<3>
+                        : d->format == 4 ? (const void *)interp_wave_grid<4> : d->format == 5 ? (const void *)interp_wave_grid<5>
+                                                                                          : (const void *)interp_wave_grid<6>;
+        e = hipFuncSetAttribute(gfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGenericLdsMax);
         if (e != hipSuccess) { (void)hipFree(pl.d_own); return set_err("hipFuncSetAttribute(frame-parallel LDS): %s", hipGetErrorString(e)); }
     }
     if (pl.ga_staged) {   /* per plan creation, like the FIR: nothing in the launch path may touch function attributes */
@@ -1468,7 +1481,62 @@ int avdsp_hip_run_levels(avdsp_hip_prog *prog, const int *plans, const int *leve
             at += n;
             continue;
         }
-        while ((int)prog->side.size() < n - 1) {
+        /* all of them frame-parallel for this call: one launch, one workgroup per piece */
+        if (nframes > 1 && nframes <= kFirChunk * 64) {
+            constexpr int K = avdsp_hip_prog::kTableSlots;
+            if (prog->table_cap < n) {
+                HIP_TRY(hipDeviceSynchronize());
+                (void)hipFree(prog->d_table); (void)hipHostFree(prog->h_table);
+                prog->d_table = nullptr; prog->h_table = nullptr; prog->table_cap = 0;
+                const int cap = std::max(n, 16);
+                HIP_TRY(hipMalloc((void **)&prog->d_table, (size_t)K * cap * sizeof(GenericArgs)));
+                HIP_TRY(hipHostMalloc((void **)&prog->h_table, (size_t)K * cap * sizeof(GenericArgs), hipHostMallocDefault));
+                prog->table_cap = cap;
+                for (auto &ev : prog->table_done) if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            }
+            const int slot = prog->table_next;
+            GenericArgs *table = prog->h_table + (size_t)slot * prog->table_cap;
+            GenericArgs *d_slot = prog->d_table + (size_t)slot * prog->table_cap;
+            HIP_TRY(hipEventSynchronize(prog->table_done[slot]));      /* (never recorded = done) */
+            size_t lds = 0;
+            bool grid_ok = true;
+            BlockIO gio = io;
+            gio.in = (const unsigned *)d_in; gio.out = (unsigned *)d_out; gio.nframes = nframes; gio.store_mask = -1;
+            for (int i = 0; i < n && grid_ok; i++) {
+                Plan &pl = prog->plans[plans[at + i]];
+                GenericArgs a = pl.ga;
+                a.io = gio;
+                a.rows_whole = 0;
+                if (in_stride < 0 || out_stride < 0 || in_io_base < 0 || out_io_base < 0 ||
+                    (in_stride && in_io_base + in_stride > pl.ga.scratch_len) || (out_stride && out_io_base + out_stride > pl.ga.scratch_len) ||
+                    pl.format != prog->plans[plans[at]].format || !wave_plan_fits(prog, pl, gio, a)) { grid_ok = false; break; }
+                lds = std::max(lds, ((size_t)a.batch_lds + 128 + (size_t)a.nvm * 128 + a.seq_words) * 4);
+                table[i] = a;
+            }
+            if (grid_ok) {
+                HIP_TRY(hipMemcpyAsync(d_slot, table, (size_t)n * sizeof(GenericArgs), hipMemcpyHostToDevice, main));
+                {
+                    ProfileScope scope(prog, main, AVDSP_KERNEL_GENERIC_WAVE);
+                    const dim3 grid(n), block(64);
+                    switch (prog->plans[plans[at]].format) {
+                    case 2:  hipLaunchKernelGGL((interp_wave_grid<2>), grid, block, lds, main, d_slot); break;
+                    case 3:  hipLaunchKernelGGL((interp_wave_grid<3>), grid, block, lds, main, d_slot); break;
+                    case 4:  hipLaunchKernelGGL((interp_wave_grid<4>), grid, block, lds, main, d_slot); break;
+                    case 5:  hipLaunchKernelGGL((interp_wave_grid<5>), grid, block, lds, main, d_slot); break;
+                    default: hipLaunchKernelGGL((interp_wave_grid<6>), grid, block, lds, main, d_slot); break;
+                    }
+                    HIP_TRY(hipGetLastError());
+                }
+                HIP_TRY(hipEventRecord(prog->table_done[slot], main));
+                prog->table_next = (slot + 1) % K;
+                at += n;
+                continue;
+            }
+        }
+        /* at most kSide + 1 launches in flight at a time: the cores of a level are independent of each other, so a
+         * large level simply goes in several rounds */
+        constexpr int kSide = 15;
+        while ((int)prog->side.size() < std::min(n - 1, kSide)) {
             hipStream_t st; hipEvent_t ev;
             HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
             prog->side.push_back(st);
@@ -1476,16 +1544,19 @@ int avdsp_hip_run_levels(avdsp_hip_prog *prog, const int *plans, const int *leve
             prog->join.push_back(ev);
         }
         if (!prog->fork) HIP_TRY(hipEventCreateWithFlags(&prog->fork, hipEventDisableTiming));
-        HIP_TRY(hipEventRecord(prog->fork, main));
-        for (int i = 1; i < n; i++) {
-            HIP_TRY(hipStreamWaitEvent(prog->side[i - 1], prog->fork, 0));
-            if (avdsp_hip_run_block(prog, plans[at + i], d_in, in_stride, in_io_base, d_out, out_stride, out_io_base,
-                                    nframes, fir_impl, biquad_impl, prog->side[i - 1])) return -1;
-            HIP_TRY(hipEventRecord(prog->join[i - 1], prog->side[i - 1]));
+        for (int c0 = 0; c0 < n; c0 += kSide + 1) {
+            const int m = std::min(kSide + 1, n - c0);
+            HIP_TRY(hipEventRecord(prog->fork, main));
+            for (int i = 1; i < m; i++) {
+                HIP_TRY(hipStreamWaitEvent(prog->side[i - 1], prog->fork, 0));
+                if (avdsp_hip_run_block(prog, plans[at + c0 + i], d_in, in_stride, in_io_base, d_out, out_stride, out_io_base,
+                                        nframes, fir_impl, biquad_impl, prog->side[i - 1])) return -1;
+                HIP_TRY(hipEventRecord(prog->join[i - 1], prog->side[i - 1]));
+            }
+            if (avdsp_hip_run_block(prog, plans[at + c0], d_in, in_stride, in_io_base, d_out, out_stride, out_io_base,
+                                    nframes, fir_impl, biquad_impl, stream)) return -1;
+            for (int i = 1; i < m; i++) HIP_TRY(hipStreamWaitEvent(main, prog->join[i - 1], 0));
         }
-        if (avdsp_hip_run_block(prog, plans[at], d_in, in_stride, in_io_base, d_out, out_stride, out_io_base,
-                                nframes, fir_impl, biquad_impl, stream)) return -1;
-        for (int i = 1; i < n; i++) HIP_TRY(hipStreamWaitEvent(main, prog->join[i - 1], 0));
         at += n;
     }
     return 0;

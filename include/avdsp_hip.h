@@ -59,6 +59,8 @@ typedef struct avdsp_plan_desc {
 typedef struct avdsp_generic_desc {
     int32_t  format;                 /* 2..6                                                     */
     int32_t  core_word;              /* word index of the first opcode executed                  */
+    int32_t  end_word;               /* execution stops in front of this opcode word (a core cut into groups of
+                                        strands that do not depend on each other); 0 = up to DSP_CORE / END    */
     int32_t  prog_words;             /* header totalLength: the data area starts at this word    */
     int32_t  freq_index, num_freq;   /* dsp_runtime.c:103-107                                    */
     int32_t  biquad_freq_skip;       /* 2 + 6*num_freq, :37                                      */
