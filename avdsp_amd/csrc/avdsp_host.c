@@ -78,7 +78,7 @@ static struct {
     int             opt_fir_impl, opt_biquad_impl, opt_device, opt_profile, opt_generic, opt_interp_impl;
     int             device_selected;
     int             last_levels, last_cores, last_pieces;  /* of the latest dspRuntimeBlockAll: dspRuntimeGetOption("levels" / "cores" / "pieces") */
-    int             opt_strand_split;
+    int             opt_strand_split, next_tpdf_role;
     int             all_valid, all_format, all_n, all_nlevels, all_plans[MAX_CORE_PLANS], all_size[MAX_CORE_PLANS];
 } G = { .opt_fir_impl = 1, .opt_biquad_impl = 1, .opt_device = -1, .opt_interp_impl = 1, .opt_strand_split = 1 };
 
@@ -892,6 +892,7 @@ static core_plan *get_plan_range(int format, opcode_t *core, int end_word)
     core_deps deps;
     memset(&deps, 0, sizeof deps);                   /* chain cores: complete = 0, they run alone */
     if (!chains && scan_generic(format, core, end_word, &gd, &deps)) return 0;
+    if (!chains) gd.tpdf_role = end_word ? G.next_tpdf_role : 0;
 
     if (select_device()) { lowered_free(&L); return 0; }
     if (!G.dev) {
@@ -1031,7 +1032,7 @@ int dspRuntimeBlock_6(opcode_t *core, int *rundata, const float *in, int in_stri
  * frame slot, a memory word (STORE_MEM, LOAD_MUX / TPDF result), a state range or the dither globals that the other
  * reads before writing it, or writes too; scan_generic collected that per core.  Levels: a core goes one level
  * behind the latest earlier core it meets; the cores of a level are handed to the device together.            */
-static int cores_meet(const core_deps *a, const core_deps *b)
+static int cores_meet_ex(const core_deps *a, const core_deps *b, int ignore_tpdf)
 {
     if (!a->complete || !b->complete) return 1;
     for (int k = 0; k < 8; k++)
@@ -1052,9 +1053,10 @@ static int cores_meet(const core_deps *a, const core_deps *b)
     for (int i = 0; i < a->nranges; i++)
         for (int j = 0; j < b->nranges; j++)
             if (a->range[i][0] < b->range[j][1] && b->range[j][0] < a->range[i][1]) return 1;
-    if ((a->tpdf_calc && (b->tpdf_user || b->tpdf_calc)) || (a->tpdf_user && b->tpdf_calc)) return 1;
+    if (!ignore_tpdf && ((a->tpdf_calc && (b->tpdf_user || b->tpdf_calc)) || (a->tpdf_user && b->tpdf_calc))) return 1;
     return 0;
 }
+static int cores_meet(const core_deps *a, const core_deps *b) { return cores_meet_ex(a, b, 0); }
 
 /* ---- strand groups ----
  * Inside a core the strands -- LOAD ... STORE runs -- mostly do not depend on each other either: a strand that
@@ -1146,6 +1148,7 @@ static int block_all(int format, int *rundata, const void *in, int in_stride, in
             opcode_t *begin = dspFindCoreBegin(c);
             ncores++;
             int starts[MAX_GROUPS + 1], ng = 1;
+            static core_deps pd[MAX_GROUPS];
             core_plan *whole = get_plan(format, begin);           /* also tells whether the core is a chain core */
             if (!whole) return g_err_code;
             if (G.opt_strand_split && whole->nchains == 0) ng = split_core(c, starts);
@@ -1154,7 +1157,6 @@ static int block_all(int format, int *rundata, const void *in, int in_stride, in
                  * the SAME frame (slots, memories, dither state).  Between launches it would see the last frame's.
                  * So the pieces of one core must not meet at all; pieces that do are joined again (with whatever
                  * lies between them), until the rest are strangers to each other. */
-                static core_deps pd[MAX_GROUPS];
                 avdsp_generic_desc gd;
                 starts[ng] = dspHeaderPtr->totalLength;
                 for (int g = 0; g < ng; g++)
@@ -1163,7 +1165,9 @@ static int block_all(int format, int *rundata, const void *in, int in_stride, in
                     again = 0;
                     for (int k = 1; k < ng && !again; k++)
                         for (int j = 0; j < k; j++)
-                            if (cores_meet(&pd[j], &pd[k])) {
+                            /* the dither value is the one thing a later piece may take from the core's FIRST piece:
+                             * the piece with the TPDF_CALC publishes it frame by frame (tpdf_role) */
+                            if (cores_meet_ex(&pd[j], &pd[k], j == 0 && pd[0].tpdf_calc && !pd[k].tpdf_calc)) {
                                 /* join pieces j..k: drop the starts j+1..k, rescan the joined range */
                                 const int gone = k - j;
                                 for (int t = j + 1; t + gone <= ng; t++) starts[t] = starts[t + gone];
@@ -1175,13 +1179,16 @@ static int block_all(int format, int *rundata, const void *in, int in_stride, in
                             }
                 }
             }
+            const int pd_calc_first = ng > 1 && pd[0].tpdf_calc;           /* the first piece holds the TPDF_CALC: it publishes */
             if (ng <= 1) {
                 if (n == MAX_CORE_PLANS) return fail(-9, "too many cores");
                 cp[n++] = whole;
             } else
                 for (int g = 0; g < ng; g++) {
                     if (n == MAX_CORE_PLANS) return fail(-9, "too many cores");
+                    G.next_tpdf_role = pd_calc_first ? (g == 0 ? 1 : 2) : 0;
                     cp[n] = get_plan_range(format, G.code + starts[g], g + 1 < ng ? starts[g + 1] : dspHeaderPtr->totalLength);
+                    G.next_tpdf_role = 0;
                     if (!cp[n]) return g_err_code;
                     n++;
                 }

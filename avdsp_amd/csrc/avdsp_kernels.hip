@@ -868,6 +868,7 @@ struct avdsp_hip_prog {
     int total_words = 0;
     int *d_buf = nullptr;
     TpdfGlobals *d_tpdf = nullptr;
+    int *d_tpdf_seq = nullptr; int tpdf_seq_frames = 0;   /* per-frame dither values inside a core cut into pieces */
     unsigned *d_frame = nullptr; int frame_words = 0;     /* samples[] frame of the general interpreter */
     std::vector<Plan> plans;
     unsigned *d_in = nullptr, *d_out = nullptr; size_t in_cap = 0, out_cap = 0;   /* host-call staging */
@@ -1064,6 +1065,7 @@ void avdsp_hip_prog_destroy(avdsp_hip_prog *p)
     for (auto e : p->join) (void)hipEventDestroy(e);
     if (p->fork) (void)hipEventDestroy(p->fork);
     (void)hipFree(p->d_buf); (void)hipFree(p->d_in); (void)hipFree(p->d_out); (void)hipFree(p->d_tpdf); (void)hipFree(p->d_frame);
+    (void)hipFree(p->d_tpdf_seq);
     delete p;
 }
 
@@ -1191,6 +1193,7 @@ int avdsp_hip_prog_add_generic(avdsp_hip_prog *prog, const avdsp_generic_desc *d
     }
     /* what the core owns (written back after a launch); unknown = everything, and the core then runs alone */
     a.nown = -1; a.own = nullptr; a.tpdf_owner = d->tpdf_calc != 0;
+    a.tpdf_role = d->tpdf_role; a.tpdf_seq = nullptr;
     a.nrd_slot = a.nwr_slot = -1;
     if (d->nown >= 0 && d->io_span <= 256) {
         std::vector<int> own(d->own, d->own + 2 * (size_t)d->nown);
@@ -1274,11 +1277,28 @@ static bool rows_whole(const Plan &pl, const BlockIO &io)
     return overlap || pl.ga.nown < 0 || pl.ga.nrd_slot < 0 || pl.ga.nwr_slot < 0;
 }
 
+/* pieces of a cut core exchange the per-frame dither values through one buffer per program */
+static int tpdf_seq_for(avdsp_hip_prog *prog, GenericArgs &a, int nframes)
+{
+    if (!a.tpdf_role) return 0;
+    if (prog->tpdf_seq_frames < nframes) {
+        HIP_TRY(hipDeviceSynchronize());
+        (void)hipFree(prog->d_tpdf_seq); prog->d_tpdf_seq = nullptr; prog->tpdf_seq_frames = 0;
+        const int cap = std::max(nframes, 4096);
+        HIP_TRY(hipMalloc((void **)&prog->d_tpdf_seq, (size_t)cap * 2 * sizeof(int)));
+        HIP_TRY(hipMemset(prog->d_tpdf_seq, 0, (size_t)cap * 2 * sizeof(int)));
+        prog->tpdf_seq_frames = cap;
+    }
+    a.tpdf_seq = prog->d_tpdf_seq;
+    return 0;
+}
+
 static int launch_generic(avdsp_hip_prog *prog, Plan &pl, BlockIO io, hipStream_t stream)
 {
     GenericArgs a = pl.ga;
     a.io = io;
     a.rows_whole = rows_whole(pl, io);
+    if (tpdf_seq_for(prog, a, io.nframes)) return -1;
     const dim3 grid(1), block(64);
     if (wave_plan_fits(prog, pl, io, a)) {
         ProfileScope scope(prog, stream, AVDSP_KERNEL_GENERIC_WAVE);
@@ -1507,6 +1527,7 @@ int avdsp_hip_run_levels(avdsp_hip_prog *prog, const int *plans, const int *leve
                 GenericArgs a = pl.ga;
                 a.io = gio;
                 a.rows_whole = 0;
+                if (tpdf_seq_for(prog, a, nframes)) return -1;
                 if (in_stride < 0 || out_stride < 0 || in_io_base < 0 || out_io_base < 0 ||
                     (in_stride && in_io_base + in_stride > pl.ga.scratch_len) || (out_stride && out_io_base + out_stride > pl.ga.scratch_len) ||
                     pl.format != prog->plans[plans[at]].format || !wave_plan_fits(prog, pl, gio, a)) { grid_ok = false; break; }

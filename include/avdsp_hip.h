@@ -84,6 +84,8 @@ typedef struct avdsp_generic_desc {
     uint32_t early_io[8];            /* frame slots < 256 the core reads before it has stored them in the frame  */
     uint32_t written_io[8];          /* frame slots < 256 the core stores                                        */
     int32_t  tpdf_calc;              /* the core holds the DSP_TPDF_CALC: it alone writes the dither globals     */
+    int32_t  tpdf_role;              /* pieces of a core cut into strand groups: 1 = the piece with the TPDF_CALC leaves
+                                        every frame's dither value for the later pieces (2) of that core; 0 otherwise    */
 } avdsp_generic_desc;
 
 /* A loaded program on the device: the mirror of the caller's buffer plus one plan per lowered core */

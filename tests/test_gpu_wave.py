@@ -413,3 +413,65 @@ def test_io_numbers_beyond_the_frame_parallel_limit():
         x = pb.lcg_input(200, 8, fmt == 6, seed=4)
         run_both(fmt, prog, x, 8, 298, 0, 200, expect_wave=False, span=320)
         assert _all_vs_per_core(fmt, prog, x, 8, 298, 0, 100, seed=0) == (2, 2)
+
+
+def test_wide_core_is_cut_into_strand_groups():
+    """100 channel strands in ONE core (gain, cascade, delay line each -- not a chain core): dspRuntimeBlockAll cuts
+    it into groups of strands that do not depend on each other and runs them as one grid; same result as the
+    core in one piece"""
+    nch = 100
+
+    def build(L):
+        L.dsp_PARAM()
+        banks = []
+        for c in range(nch):
+            b = L.dspBiquad_Sections(2)
+            for k in range(2):
+                L.dsp_Filter2ndOrder(FPEAK, 150.0 * (k + 1) + 7 * c, 1.0, 0.95)
+            banks.append(b)
+        L.dsp_CORE()
+        L.dsp_TPDF_CALC(0)
+        for c in range(nch):
+            L.dsp_LOAD_GAIN_Fixed(128 + c, 0.5); L.dsp_GAIN_Fixed(0.9); L.dsp_BIQUADS(banks[c])
+            L.dsp_DELAY_FixedMicroSec(100 + 10 * c); L.dsp_SAT0DB_TPDF(); L.dsp_STORE(c)
+    for fmt in (2, 6):
+        prog = encode(build, fmt, max_io=256)
+        x = pb.lcg_input(256, nch, fmt == 6, seed=21)
+        o = po.OracleProgram(fmt, prog, fs=48000, random=5, dither=24)
+        want = o.run_block(x, nch, 128, 0, block=128, frame=np.zeros(4096, dtype=np.uint32))
+        for split in (1, 0):
+            r = rt.Runtime(fmt, prog, fs=48000, random=5, dither=24)
+            r.set_option("strand_split", split)
+            try:
+                got = r.run_block_all(x, nch, 128, 0, block=128)
+                assert (got.view(np.uint32) == want.view(np.uint32)).all(), (fmt, split)
+                assert (r.sync_state() == o.state).all(), (fmt, split)
+                pieces, levels = r.get_option("pieces"), r.get_option("levels")
+                if split:
+                    assert pieces > 20 and levels == 2, (pieces, levels)       # TPDF_CALC's piece first, the rest together
+                else:
+                    assert pieces == 1 and levels == 1
+            finally:
+                r.set_option("strand_split", 1)
+                r.release()
+
+
+def test_strands_that_hand_values_over_stay_in_one_piece():
+    """a strand that loads a slot or a memory an earlier strand of the same core stored must see THIS frame's value:
+    such strands are never separated (the pieces of one core may not meet at all)"""
+    def build(L):
+        L.dsp_PARAM(); m = L.dspMem_Location()
+        L.dsp_CORE()
+        L.dsp_LOAD_GAIN_Fixed(IN + 0, 0.5); L.dsp_DELAY_1(); L.dsp_STORE(40); L.dsp_STORE(0)         # IO 40: outside both windows
+        L.dsp_LOAD_GAIN_Fixed(IN + 1, 0.5); L.dsp_DELAY_1(); L.dsp_STORE_MEM(m); L.dsp_STORE(1)
+        L.dsp_LOAD(40); L.dsp_GAIN_Fixed(0.5); L.dsp_DELAY_1(); L.dsp_STORE(2)                        # needs strand 1
+        L.dsp_LOAD_MEM(m); L.dsp_GAIN_Fixed(0.5); L.dsp_DELAY_1(); L.dsp_STORE(3)                     # needs strand 2
+        L.dsp_LOAD_GAIN_Fixed(IN + 2, 0.5); L.dsp_DELAY_1(); L.dsp_DCBLOCK(10); L.dsp_STORE(4)        # needs nobody
+        L.dsp_LOAD_GAIN_Fixed(IN + 3, 0.5); L.dsp_COPYXY(); L.dsp_LOAD_GAIN_Fixed(IN + 4, 0.5)        # Y handed to the next load's strand
+        L.dsp_ADDXY(); L.dsp_SAT0DB(); L.dsp_STORE(5)
+    for fmt in (2, 6):
+        prog = encode(build, fmt)
+        x = pb.lcg_input(300, 8, fmt == 6, seed=13)
+        for block in (2, 64, 300):
+            levels, cores = _all_vs_per_core(fmt, prog, x, 8, IN, 0, block, seed=0)
+            assert cores == 1
