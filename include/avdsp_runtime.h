@@ -106,8 +106,9 @@ int dspRuntimeBlockDevice(int format, opcode_t *core, int *rundata,
  * (the host loop of linux/avdsp_plugin.c:95-142 runs cores outermost too), in one call.  The samples cross PCIe
  * once instead of once per core, and cores that do not meet -- no frame slot, memory word (STORE_MEM, LOAD_MUX /
  * TPDF result), state range or dither global written by one and touched by the other -- run at the same time
- * on the device; cores that do are kept in program order.  dspRuntimeGetOption("levels") / ("cores") tell how
- * the latest call was arranged (levels < cores: something ran side by side).  format = DSP_FORMAT 2..6;
+ * on the device; cores that do are kept in program order.  Interpreted cores are cut further, into groups of
+ * strands (LOAD ... STORE runs) that hand nothing to each other, which run side by side as well ("strand_split",
+ * default 1).  dspRuntimeGetOption("levels") / ("cores") / ("pieces") tell how the latest call was arranged.  format = DSP_FORMAT 2..6;
  * in/out: int32 or float samples as in dspRuntimeBlock_N (host pointers) / device pointers + stream.       */
 int dspRuntimeBlockAll(int format, int *rundata, const void *in, int in_stride, int in_io_base,
                        void *out, int out_stride, int out_io_base, int nframes);
@@ -137,7 +138,7 @@ int dspRuntimeUploadParams(void);
 
 /* Tunables: "fir_impl" 0 = plain tap loop, 1 = MFMA (default); "biquad_impl" 0 = lane per channel,
  * 1 = section-pipelined (default); "interp_impl" 0 = interpreter always frame by frame, 1 = frame-parallel
- * where the core allows it (default); "generic" 1 = every core through the interpreter;
+ * where the core allows it (default); "strand_split" 0 = dspRuntimeBlockAll keeps cores whole; "generic" 1 = every core through the interpreter;
  * "device" = HIP device ordinal (before the first block).                                        */
 int dspRuntimeSetOption(const char *key, int value);
 int dspRuntimeGetOption(const char *key);
