@@ -1152,6 +1152,7 @@ static int block_all(int format, int *rundata, const void *in, int in_stride, in
             core_plan *whole = get_plan(format, begin);           /* also tells whether the core is a chain core */
             if (!whole) return g_err_code;
             if (G.opt_strand_split && whole->nchains == 0) ng = split_core(c, starts);
+            if (ng > 1 && (G.nplans + ng + 8 > MAX_CORE_PLANS || n + ng + 8 > MAX_CORE_PLANS)) ng = 1;   /* plan table nearly full: whole */
             if (ng > 1) {
                 /* Inside a core everything happens frame by frame: a later strand sees what an earlier one stored in
                  * the SAME frame (slots, memories, dither state).  Between launches it would see the last frame's.
