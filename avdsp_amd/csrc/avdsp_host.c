@@ -1089,21 +1089,23 @@ static int split_core(opcode_t *core, int *starts)
 {
     const int total = dspHeaderPtr->totalLength;
     opcode_t *p0 = dspFindCoreBegin(core);
-    int at[4096], op[4096], n = 0;
+    enum { MAXOPS = 32768 };
+    static int at[MAXOPS], op[MAXOPS], cut[MAXOPS];
+    int n = 0;
     for (opcode_t *p = p0;;) {
         const int w = (int)(p - G.code);
         if (w < 0 || w >= total) return 0;                     /* damaged: the scan will say so */
         const int o = p->op.opcode; const unsigned skip = p->op.skip;
         if (skip == 0 || o == DSP_CORE || o == DSP_END_OF_CODE) break;
         if (o == DSP_TPDF) { n = -1; break; }
-        if (n == 4096) { n = -1; break; }
+        if (n == MAXOPS) { n = -1; break; }
         at[n] = w; op[n] = o; n++;
         p += skip;
     }
     starts[0] = (int)(p0 - G.code);
     if (n < 8) return 1;
     /* legal cuts */
-    int cut[4096], ncut = 0;
+    int ncut = 0;
     for (int i = 1; i < n; i++) {
         if (op[i] != DSP_LOAD && op[i] != DSP_LOAD_GAIN && op[i] != DSP_LOAD_MEM && op[i] != DSP_LOAD_MUX && op[i] != DSP_CLRXY) continue;
         int legal = 1;
