@@ -26,6 +26,7 @@ from avdsp_amd import encoder as enc
 import os
 
 NAN_HEAVY = bool(int(os.environ.get("AVDSP_FUZZ_NAN_HEAVY", "0")))
+WIDE = bool(int(os.environ.get("AVDSP_FUZZ_WIDE", "0")))            # development switch: many strands per core (strand groups)
 F44100, F48000, F96000, F192000 = 4, 5, 7, 9
 N_IN, IN_BASE, N_OUT = 8, 32, 24           # inputs IO 32..39, outputs IO 0..23
 
@@ -168,7 +169,7 @@ class _Builder:
             if r.random() < 0.3:
                 L.dsp_LOAD_STORE()
                 L.dspLoadStore_Data(IN_BASE + int(r.integers(0, N_IN)), 20 + int(r.integers(0, 4)))
-            for _ in range(int(r.integers(1, 5))):
+            for _ in range(int(r.integers(6, 20)) if WIDE else int(r.integers(1, 5))):
                 self.strand()
             if r.random() < 0.3:
                 L.dsp_LOAD(IN_BASE + int(r.integers(0, N_IN)))
