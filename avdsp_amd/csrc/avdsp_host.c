@@ -64,6 +64,8 @@ typedef struct {
 } core_plan;
 
 #define MAX_CORE_PLANS 512          /* cores, and the strand groups dspRuntimeBlockAll cuts them into */
+#define MAX_ARRANGEMENTS 17
+typedef struct { int valid, format, n, nlevels, ncores; opcode_t *only; int *plans, *size; } arrangement;
 
 static struct {
     opcode_t       *code;
@@ -79,7 +81,7 @@ static struct {
     int             device_selected;
     int             last_levels, last_cores, last_pieces;  /* of the latest dspRuntimeBlockAll: dspRuntimeGetOption("levels" / "cores" / "pieces") */
     int             opt_strand_split, next_tpdf_role;
-    int             all_valid, all_format, all_n, all_nlevels, all_plans[MAX_CORE_PLANS], all_size[MAX_CORE_PLANS];
+    arrangement     arr[MAX_ARRANGEMENTS]; int arr_next;   /* how the cores / pieces go to the device: [0] whole program, [1..] single cores */
 } G = { .opt_fir_impl = 1, .opt_biquad_impl = 1, .opt_device = -1, .opt_interp_impl = 1, .opt_strand_split = 1 };
 
 static char g_err[512];
@@ -102,7 +104,7 @@ static void drop_device(void)
     if (G.dev) avdsp_hip_prog_destroy(G.dev);
     G.dev = 0;
     G.nplans = 0;
-    G.all_valid = 0;
+    for (int i_ = 0; i_ < MAX_ARRANGEMENTS; i_++) G.arr[i_].valid = 0;
     G.dev_state_valid = 0;
 }
 
@@ -119,7 +121,7 @@ static int replan(void)
 {
     if (G.dev && avdsp_hip_prog_clear_plans(G.dev)) return fail(-10, "%s", avdsp_hip_last_error());
     G.nplans = 0;
-    G.all_valid = 0;
+    for (int i_ = 0; i_ < MAX_ARRANGEMENTS; i_++) G.arr[i_].valid = 0;
     return 0;
 }
 
@@ -979,6 +981,17 @@ static int check_rundata(const int *rundata)
     return 0;
 }
 
+static int block_all(int format, int *rundata, const void *in, int in_stride, int in_io_base,
+                     void *out, int out_stride, int out_io_base, int nframes, int on_device, void *stream, int pcm,
+                     opcode_t *only);
+/* an interpreted core goes to the device as its strand groups (block_all with that one core) */
+static int takes_pieces(const core_plan *cp, int nframes, int in_stride, int in_io_base, int out_stride, int out_io_base)
+{
+    /* windows that share IO numbers make every launch deliver whole rows, one after the other: the core in one piece then */
+    const int overlap = in_stride > 0 && out_stride > 0 && in_io_base < out_io_base + out_stride && out_io_base < in_io_base + in_stride;
+    return cp->nchains == 0 && G.opt_strand_split && nframes > 1 && !overlap;
+}
+
 int dspRuntimeBlockDevice(int format, opcode_t *core, int *rundata,
                           const void *d_in, int in_stride, int in_io_base,
                           void *d_out, int out_stride, int out_io_base, int nframes, void *stream)
@@ -987,6 +1000,8 @@ int dspRuntimeBlockDevice(int format, opcode_t *core, int *rundata,
     if (!cp) return g_err_code;
     if (check_rundata(rundata)) return -1;
     if (nframes <= 0) return 0;
+    if (takes_pieces(cp, nframes, in_stride, in_io_base, out_stride, out_io_base))
+        return block_all(format, rundata, d_in, in_stride, in_io_base, d_out, out_stride, out_io_base, nframes, 1, stream, AVDSP_PCM_S32, core);
     if (avdsp_hip_run_block(G.dev, cp->plan_id, d_in, in_stride, in_io_base, d_out, out_stride, out_io_base,
                             nframes, G.opt_fir_impl, G.opt_biquad_impl, stream))
         return fail(-10, "%s", avdsp_hip_last_error());
@@ -1000,6 +1015,8 @@ static int block_host(int format, opcode_t *core, int *rundata, const void *in, 
     if (!cp) return g_err_code;
     if (check_rundata(rundata)) return -1;
     if (nframes <= 0) return 0;
+    if (takes_pieces(cp, nframes, in_stride, in_io_base, out_stride, out_io_base))
+        return block_all(format, rundata, in, in_stride, in_io_base, out, out_stride, out_io_base, nframes, 0, 0, AVDSP_PCM_S32, core);
     if (avdsp_hip_run_block_host(G.dev, cp->plan_id, in, in_stride, in_io_base, out, out_stride, out_io_base,
                                  nframes, G.opt_fir_impl, G.opt_biquad_impl))
         return fail(-10, "%s", avdsp_hip_last_error());
@@ -1133,70 +1150,88 @@ static int split_core(opcode_t *core, int *starts)
     return ng;
 }
 
+/* one core -> its pieces (or itself), appended to cp[] */
+static int expand_core(int format, opcode_t *c, core_plan **cp, int *pn)
+{
+    int n = *pn;
+    opcode_t *begin = dspFindCoreBegin(c);
+    int starts[MAX_GROUPS + 1], ng = 1;
+    static core_deps pd[MAX_GROUPS];
+    core_plan *whole = get_plan(format, begin);           /* also tells whether the core is a chain core */
+    if (!whole) return g_err_code;
+    if (G.opt_strand_split && whole->nchains == 0) ng = split_core(c, starts);
+    if (ng > 1 && (G.nplans + ng + 8 > MAX_CORE_PLANS || n + ng + 8 > MAX_CORE_PLANS)) ng = 1;   /* plan table nearly full: whole */
+    if (ng > 1) {
+        /* Inside a core everything happens frame by frame: a later strand sees what an earlier one stored in
+         * the SAME frame (slots, memories, dither state).  Between launches it would see the last frame's.
+         * So the pieces of one core must not meet at all; pieces that do are joined again (with whatever
+         * lies between them), until the rest are strangers to each other. */
+        avdsp_generic_desc gd;
+        starts[ng] = dspHeaderPtr->totalLength;
+        for (int g = 0; g < ng; g++)
+            if (scan_generic(format, G.code + starts[g], starts[g + 1], &gd, &pd[g])) return g_err_code;
+        for (int again = 1; again && ng > 1;) {
+            again = 0;
+            for (int k = 1; k < ng && !again; k++)
+                for (int j = 0; j < k; j++)
+                    /* the dither value is the one thing a later piece may take from the core's FIRST piece:
+                     * the piece with the TPDF_CALC publishes it frame by frame (tpdf_role) */
+                    if (cores_meet_ex(&pd[j], &pd[k], j == 0 && pd[0].tpdf_calc && !pd[k].tpdf_calc)) {
+                        /* join pieces j..k: drop the starts j+1..k, rescan the joined range */
+                        const int gone = k - j;
+                        for (int t = j + 1; t + gone <= ng; t++) starts[t] = starts[t + gone];
+                        for (int t = j + 1; t + gone < ng; t++) pd[t] = pd[t + gone];
+                        ng -= gone;
+                        if (scan_generic(format, G.code + starts[j], starts[j + 1], &gd, &pd[j])) return g_err_code;
+                        again = 1;
+                        break;
+                    }
+        }
+    }
+    const int pd_calc_first = ng > 1 && pd[0].tpdf_calc;           /* the first piece holds the TPDF_CALC: it publishes */
+    if (ng <= 1) {
+        if (n == MAX_CORE_PLANS) return fail(-9, "too many cores");
+        cp[n++] = whole;
+    } else
+        for (int g = 0; g < ng; g++) {
+            if (n == MAX_CORE_PLANS) return fail(-9, "too many cores");
+            G.next_tpdf_role = pd_calc_first ? (g == 0 ? 1 : 2) : 0;
+            cp[n] = get_plan_range(format, G.code + starts[g], g + 1 < ng ? starts[g + 1] : dspHeaderPtr->totalLength);
+            G.next_tpdf_role = 0;
+            if (!cp[n]) return g_err_code;
+            n++;
+        }
+    *pn = n;
+    return 0;
+}
+
+/* only == 0: every core of the program in program order; else that one core (its strand groups side by side) */
 static int block_all(int format, int *rundata, const void *in, int in_stride, int in_io_base,
-                     void *out, int out_stride, int out_io_base, int nframes, int on_device, void *stream, int pcm)
+                     void *out, int out_stride, int out_io_base, int nframes, int on_device, void *stream, int pcm,
+                     opcode_t *only)
 {
     if (!dspHeaderPtr || !G.code) return fail(-1, "no program loaded");
     if (check_rundata(rundata)) return -1;
     if (nframes <= 0) return 0;
     /* the arrangement is worked out once per lowering (plans live until the next reset / option / parameter upload) */
-    if (!G.all_valid || G.all_format != format) {
+    arrangement *A = 0;
+    for (int i = 0; i < MAX_ARRANGEMENTS; i++)
+        if (G.arr[i].valid && G.arr[i].format == format && G.arr[i].only == only) { A = &G.arr[i]; break; }
+    if (!A) {
         static core_plan *cp[MAX_CORE_PLANS];
         static int level[MAX_CORE_PLANS];
         int n = 0, nlevels = 0, ncores = 0;
-        for (int k = 1; k <= MAX_CORE_PLANS; k++) {
-            opcode_t *c = dspFindCore(G.code, k);
-            if (!c || (k > 1 && c == G.code)) break;
-            opcode_t *begin = dspFindCoreBegin(c);
-            ncores++;
-            int starts[MAX_GROUPS + 1], ng = 1;
-            static core_deps pd[MAX_GROUPS];
-            core_plan *whole = get_plan(format, begin);           /* also tells whether the core is a chain core */
-            if (!whole) return g_err_code;
-            if (G.opt_strand_split && whole->nchains == 0) ng = split_core(c, starts);
-            if (ng > 1 && (G.nplans + ng + 8 > MAX_CORE_PLANS || n + ng + 8 > MAX_CORE_PLANS)) ng = 1;   /* plan table nearly full: whole */
-            if (ng > 1) {
-                /* Inside a core everything happens frame by frame: a later strand sees what an earlier one stored in
-                 * the SAME frame (slots, memories, dither state).  Between launches it would see the last frame's.
-                 * So the pieces of one core must not meet at all; pieces that do are joined again (with whatever
-                 * lies between them), until the rest are strangers to each other. */
-                avdsp_generic_desc gd;
-                starts[ng] = dspHeaderPtr->totalLength;
-                for (int g = 0; g < ng; g++)
-                    if (scan_generic(format, G.code + starts[g], starts[g + 1], &gd, &pd[g])) return g_err_code;
-                for (int again = 1; again && ng > 1;) {
-                    again = 0;
-                    for (int k = 1; k < ng && !again; k++)
-                        for (int j = 0; j < k; j++)
-                            /* the dither value is the one thing a later piece may take from the core's FIRST piece:
-                             * the piece with the TPDF_CALC publishes it frame by frame (tpdf_role) */
-                            if (cores_meet_ex(&pd[j], &pd[k], j == 0 && pd[0].tpdf_calc && !pd[k].tpdf_calc)) {
-                                /* join pieces j..k: drop the starts j+1..k, rescan the joined range */
-                                const int gone = k - j;
-                                for (int t = j + 1; t + gone <= ng; t++) starts[t] = starts[t + gone];
-                                for (int t = j + 1; t + gone < ng; t++) pd[t] = pd[t + gone];
-                                ng -= gone;
-                                if (scan_generic(format, G.code + starts[j], starts[j + 1], &gd, &pd[j])) return g_err_code;
-                                again = 1;
-                                break;
-                            }
-                }
+        if (only) {
+            ncores = 1;
+            if (expand_core(format, only, cp, &n)) return g_err_code;
+        } else
+            for (int k = 1; k <= MAX_CORE_PLANS; k++) {
+                opcode_t *c = dspFindCore(G.code, k);
+                if (!c || (k > 1 && c == G.code)) break;
+                ncores++;
+                if (expand_core(format, c, cp, &n)) return g_err_code;
+                if (c == G.code) break;                           /* a program without DSP_CORE is one core */
             }
-            const int pd_calc_first = ng > 1 && pd[0].tpdf_calc;           /* the first piece holds the TPDF_CALC: it publishes */
-            if (ng <= 1) {
-                if (n == MAX_CORE_PLANS) return fail(-9, "too many cores");
-                cp[n++] = whole;
-            } else
-                for (int g = 0; g < ng; g++) {
-                    if (n == MAX_CORE_PLANS) return fail(-9, "too many cores");
-                    G.next_tpdf_role = pd_calc_first ? (g == 0 ? 1 : 2) : 0;
-                    cp[n] = get_plan_range(format, G.code + starts[g], g + 1 < ng ? starts[g + 1] : dspHeaderPtr->totalLength);
-                    G.next_tpdf_role = 0;
-                    if (!cp[n]) return g_err_code;
-                    n++;
-                }
-            if (c == G.code) break;                           /* a program without DSP_CORE is one core */
-        }
         if (n == 0) return fail(-3, "no cores defined in the program");
         for (int i = 0; i < n; i++) {
             level[i] = 0;
@@ -1212,16 +1247,25 @@ static int block_all(int format, int *rundata, const void *in, int in_stride, in
                 for (int j = 0; j < i; j++) if (cores_meet(&cp[j]->deps, &cp[i]->deps)) fprintf(stderr, " %d", j);
                 fprintf(stderr, "\n");
             }
+        /* slot 0 holds the whole-program arrangement, the others the per-core ones (round robin) */
+        int slot = 0;
+        if (only) { slot = 1 + G.arr_next; G.arr_next = (G.arr_next + 1) % (MAX_ARRANGEMENTS - 1); }
+        A = &G.arr[slot];
+        if (n > (only ? MAX_GROUPS : MAX_CORE_PLANS)) return fail(-9, "too many pieces");
+        free(A->plans);
+        A->plans = (int *)malloc(sizeof(int) * 2 * (size_t)(unsigned)n);
+        if (!A->plans) { A->valid = 0; return fail(-9, "out of memory"); }
+        A->size = A->plans + n;
         int m = 0;
         for (int l = 0; l < nlevels; l++) {
-            G.all_size[l] = 0;
-            for (int i = 0; i < n; i++) if (level[i] == l) { G.all_plans[m++] = cp[i]->plan_id; G.all_size[l]++; }
+            A->size[l] = 0;
+            for (int i = 0; i < n; i++) if (level[i] == l) { A->plans[m++] = cp[i]->plan_id; A->size[l]++; }
         }
-        G.all_nlevels = nlevels; G.all_n = n; G.all_format = format; G.all_valid = 1;
-        G.last_levels = nlevels; G.last_cores = ncores; G.last_pieces = n;
+        A->nlevels = nlevels; A->n = n; A->ncores = ncores; A->format = format; A->only = only; A->valid = 1;
     }
-    const int *plans = G.all_plans, *size = G.all_size;
-    const int nlevels = G.all_nlevels;
+    G.last_levels = A->nlevels; G.last_cores = A->ncores; G.last_pieces = A->n;
+    const int *plans = A->plans, *size = A->size;
+    const int nlevels = A->nlevels;
     int rc = on_device
         ? avdsp_hip_run_levels(G.dev, plans, size, nlevels, in, in_stride, in_io_base, out, out_stride, out_io_base,
                                nframes, G.opt_fir_impl, G.opt_biquad_impl, stream)
@@ -1233,11 +1277,11 @@ static int block_all(int format, int *rundata, const void *in, int in_stride, in
 
 int dspRuntimeBlockAll(int format, int *rundata, const void *in, int in_stride, int in_io_base,
                        void *out, int out_stride, int out_io_base, int nframes)
-{ return block_all(format, rundata, in, in_stride, in_io_base, out, out_stride, out_io_base, nframes, 0, 0, AVDSP_PCM_S32); }
+{ return block_all(format, rundata, in, in_stride, in_io_base, out, out_stride, out_io_base, nframes, 0, 0, AVDSP_PCM_S32, 0); }
 
 int dspRuntimeBlockAllDevice(int format, int *rundata, const void *d_in, int in_stride, int in_io_base,
                              void *d_out, int out_stride, int out_io_base, int nframes, void *stream)
-{ return block_all(format, rundata, d_in, in_stride, in_io_base, d_out, out_stride, out_io_base, nframes, 1, stream, AVDSP_PCM_S32); }
+{ return block_all(format, rundata, d_in, in_stride, in_io_base, d_out, out_stride, out_io_base, nframes, 1, stream, AVDSP_PCM_S32, 0); }
 
 /* linux/avdsp_plugin.c:95-142 whole: packed PCM in (:109-121), every core, S32 out */
 int dspRuntimeBlockAllPcm(int format, int *rundata, int pcm, const void *src, int in_stride, int in_io_base,
@@ -1245,7 +1289,7 @@ int dspRuntimeBlockAllPcm(int format, int *rundata, int pcm, const void *src, in
 {
     if (format != 2 && format != 3 && format != 4)
         return fail(-1, "packed PCM feeds the int-sample formats 2, 3 and 4 (DSP_FORMAT %d has float samples)", format);
-    return block_all(format, rundata, src, in_stride, in_io_base, dst, out_stride, out_io_base, nframes, 0, 0, pcm);
+    return block_all(format, rundata, src, in_stride, in_io_base, dst, out_stride, out_io_base, nframes, 0, 0, pcm, 0);
 }
 
 /* linux/avdsp_plugin.c:95-142 with the sample-format switch of :109-121: packed PCM in, S32 out */
@@ -1258,6 +1302,8 @@ int dspRuntimeBlockPcm(int format, opcode_t *core, int *rundata, int pcm, const 
     if (!cp) return g_err_code;
     if (check_rundata(rundata)) return -1;
     if (nframes <= 0) return 0;
+    if (takes_pieces(cp, nframes, in_stride, in_io_base, out_stride, out_io_base))
+        return block_all(format, rundata, src, in_stride, in_io_base, dst, out_stride, out_io_base, nframes, 0, 0, pcm, core);
     if (avdsp_hip_run_block_pcm_host(G.dev, cp->plan_id, pcm, src, in_stride, in_io_base, dst, out_stride, out_io_base,
                                      nframes, G.opt_fir_impl, G.opt_biquad_impl))
         return fail(-10, "%s", avdsp_hip_last_error());
@@ -1311,7 +1357,7 @@ int dspRuntimeUploadParams(void)
         avdsp_hip_upload_words(G.dev, (const int32_t *)G.code, first, dspHeaderPtr->totalLength - first))
         return fail(-10, "%s", avdsp_hip_last_error());
     G.nplans = 0;                                             /* cores are lowered again at their next block */
-    G.all_valid = 0;
+    for (int i_ = 0; i_ < MAX_ARRANGEMENTS; i_++) G.arr[i_].valid = 0;
     return 0;
 }
 
