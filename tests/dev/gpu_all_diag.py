@@ -1,5 +1,5 @@
 """Development probe: dspRuntimeBlockAllDevice on a side stream / with profiling; prints its stages.
-usage: python tools/dev/gpu_all_diag.py PROFILE(0|1) SIDE(0|1)"""
+usage: python tests/dev/gpu_all_diag.py PROFILE(0|1) SIDE(0|1)"""
 import os, sys
 sys.path.insert(0, '.')
 import numpy as np, torch

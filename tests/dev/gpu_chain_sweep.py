@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One-off sweep (GPU box): larger random chain shapes (up to 40 channels, 70 sections, 1500 taps, blocks up to
-2500 frames, two blocks per run) through the parallel kernels against the oracle.  python tools/dev/gpu_chain_sweep.py LO HI"""
+2500 frames, two blocks per run) through the parallel kernels against the oracle.  python tests/dev/gpu_chain_sweep.py LO HI"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

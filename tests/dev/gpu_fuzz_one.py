@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Development probe (GPU box): python tools/dev/gpu_fuzz_one.py SEED FMT -- where does the interpreter differ from the oracle?"""
+"""Development probe (GPU box): python tests/dev/gpu_fuzz_one.py SEED FMT -- where does the interpreter differ from the oracle?"""
 import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

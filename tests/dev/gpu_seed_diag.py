@@ -1,5 +1,5 @@
 """Development probe: one random program (seed, fmt) through the interpreter variants against the oracle.
-usage: python tools/dev/gpu_seed_diag.py SEED FMT [block]"""
+usage: python tests/dev/gpu_seed_diag.py SEED FMT [block]"""
 import sys; sys.path.insert(0, '.')
 import numpy as np
 from avdsp_amd import progbuilder as pb, runtime as rt

@@ -1,6 +1,6 @@
 """Development sweep: random programs on the general interpreter, frame-parallel kernel where the host
 allows it, against the oracle; reports how many block calls each kernel took.
-usage: python tools/dev/gpu_wave_sweep.py SEED0 SEED1 [frames] [all]     (all: through dspRuntimeBlockAll)"""
+usage: python tests/dev/gpu_wave_sweep.py SEED0 SEED1 [frames] [all]     (all: through dspRuntimeBlockAll)"""
 import sys; sys.path.insert(0, '.')
 import numpy as np
 from avdsp_amd import progbuilder as pb, runtime as rt
