@@ -9,12 +9,14 @@ from tests.fuzz_programs import IN_BASE, N_IN, N_OUT, random_program
 
 frames = int(sys.argv[3]) if len(sys.argv) > 3 else 300
 use_all = len(sys.argv) > 4 and sys.argv[4] == "all"
+import os
+BLOCKS = [int(b) for b in os.environ.get("AVDSP_SWEEP_BLOCKS", "1,64,0").split(",")]      # 0 = all frames in one block
 levels_hist = {}
 bad = n = wave = scalar = 0
 for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     for fmt in (2, 3, 4, 5, 6):
         prog = random_program(seed, fmt)
-        fs, block = [48000, 48000, 96000][seed % 3], [1, 64, frames][seed % 3]
+        fs, block = [48000, 48000, 96000][seed % 3], BLOCKS[seed % 3] or frames
         x = pb.lcg_input(frames, N_IN, fmt in (5, 6), seed=seed)
         o = po.OracleProgram(fmt, prog, fs=fs, random=seed, dither=24)
         r = rt.Runtime(fmt, prog, fs=fs, random=seed, dither=24)
