@@ -1139,7 +1139,15 @@ static int split_core(opcode_t *core, int *starts)
     if (groups > MAX_GROUPS) groups = MAX_GROUPS;
     if (groups > ncut + 1) groups = ncut + 1;
     int ng = 1, last = 0;
-    for (int g = 1; g < groups; g++) {
+    /* the piece with the TPDF_CALC is a level of its own in front of every piece that dithers: keep it as short as the
+     * cuts allow (the first legal cut behind the TPDF_CALC), whatever its size */
+    for (int i = 0; i < n; i++)
+        if (op[i] == DSP_TPDF_CALC) {
+            for (int c = 0; c < ncut; c++)
+                if (cut[c] > i) { if (n - cut[c] >= 4) { starts[ng++] = at[cut[c]]; last = cut[c]; } break; }
+            break;
+        }
+    for (int g = 1; g < groups && ng < MAX_GROUPS; g++) {
         const int want = (int)((long long)n * g / groups);
         int best = -1;
         for (int c = 0; c < ncut; c++) if (cut[c] >= want && cut[c] > last) { best = cut[c]; break; }
