@@ -475,3 +475,17 @@ def test_strands_that_hand_values_over_stay_in_one_piece():
         for block in (2, 64, 300):
             levels, cores = _all_vs_per_core(fmt, prog, x, 8, IN, 0, block, seed=0)
             assert cores == 1
+
+
+@pytest.mark.parametrize("seed,switch", [(s, "WIDE") for s in list(range(1030, 1042)) + [37, 211]] +
+                                        [(s, "NAN_HEAVY") for s in (10021, 7003, 7011, 12005)])
+def test_block_all_on_wide_and_nan_heavy_random_programs(seed, switch, monkeypatch):
+    """the generator's development switches: many strands per core (strand groups, joins) and DITHER-poisoned
+    strands (NaN operand order: seeds 1037 and 10021 found AVGYX and DCBLOCK)"""
+    import tests.fuzz_programs as fz
+    monkeypatch.setattr(fz, switch, True)
+    for fmt in (2, 3, 6):
+        prog = fz.random_program(seed, fmt)
+        fs, block = [48000, 48000, 96000][seed % 3], [5, 64, 150][seed % 3]
+        x = pb.lcg_input(150, fz.N_IN, fmt in (5, 6), seed=seed)
+        _all_vs_per_core(fmt, prog, x, fz.N_OUT, fz.IN_BASE, 0, block, fs=fs, seed=seed)
