@@ -60,6 +60,9 @@ typedef struct {
     int         end_word;        /* 0: the whole core; else a strand group [core, end_word) of it */
     int         plan_id;         /* id inside the device program, < 0 = lowering failed */
     int         nchains, max_sections, max_taps;      /* nchains 0 = general interpreter */
+    int         total_chains, first_chain;            /* chain cores: the core has total_chains, this process runs
+                                                         [first_chain, first_chain + nchains) of them (dspRuntimeSetShard) */
+    int         empty;                                /* chain core whose shard holds no chain: block calls do nothing */
     core_deps   deps;
 } core_plan;
 
@@ -81,8 +84,9 @@ static struct {
     int             device_selected;
     int             last_levels, last_cores, last_pieces;  /* of the latest dspRuntimeBlockAll: dspRuntimeGetOption("levels" / "cores" / "pieces") */
     int             opt_strand_split, next_tpdf_role;
+    int             shard_rank, shard_world;               /* dspRuntimeSetShard: this process's slice of every chain core */
     arrangement     arr[MAX_ARRANGEMENTS]; int arr_next;   /* how the cores / pieces go to the device: [0] whole program, [1..] single cores */
-} G = { .opt_fir_impl = 1, .opt_biquad_impl = 1, .opt_device = -1, .opt_interp_impl = 1, .opt_strand_split = 1 };
+} G = { .opt_fir_impl = 1, .opt_biquad_impl = 1, .opt_device = -1, .opt_interp_impl = 1, .opt_strand_split = 1, .shard_world = 1 };
 
 static char g_err[512];
 static int  g_err_code;
@@ -153,7 +157,28 @@ int dspRuntimeGetOption(const char *key)
     if (!strcmp(key, "cores"))       return G.last_cores;
     if (!strcmp(key, "pieces"))      return G.last_pieces;
     if (!strcmp(key, "strand_split")) return G.opt_strand_split;
+    if (!strcmp(key, "shard_rank"))  return G.shard_rank;
+    if (!strcmp(key, "shard_world")) return G.shard_world;
     return -1;
+}
+
+/* ---- channel sharding ----
+ * The chains of a core are independent (lower_core proves it per core), so N processes -- one per GPU -- may each
+ * run a contiguous range of them with no exchange at all.  Contiguous and balanced: the first (total % world)
+ * ranks take one chain more, i.e. avdsp_amd/sharding.py shard_range().                                        */
+static void shard_range(int total, int world, int rank, int *lo, int *hi)
+{
+    const int q = total / world, r = total % world;
+    *lo = rank * q + (rank < r ? rank : r);
+    *hi = *lo + q + (rank < r ? 1 : 0);
+}
+
+int dspRuntimeSetShard(int rank, int world)
+{
+    if (world < 1 || rank < 0 || rank >= world) return fail(-1, "shard %d of %d: need 0 <= rank < world", rank, world);
+    if (rank == G.shard_rank && world == G.shard_world) return 0;
+    G.shard_rank = rank; G.shard_world = world;
+    return replan();                     /* the FIR histories go back into the mirror; cores are lowered again */
 }
 
 /* ---- dsp_runtime.c:42-59 ---- */
@@ -872,13 +897,24 @@ static core_plan *get_plan_range(int format, opcode_t *core, int end_word)
     if (!dspHeaderPtr || !G.code) { fail(-1, "no program loaded"); return 0; }
     if (!G.have_rate) { fail(-1, "dspRuntimeReset(fs) has not selected a sample rate yet"); return 0; }
     if (format < 2 || format > 6) { fail(-1, "DSP_FORMAT %d is not one of 2..6", format); return 0; }
+    if (core < G.code || core >= G.code + dspHeaderPtr->totalLength) { fail(-1, "core pointer outside the loaded program"); return 0; }
+    /* one key per core: a host may pass the DSP_CORE word or the first executable word behind it */
+    if (!end_word) core = dspFindCoreBegin(core);
     for (int i = 0; i < G.nplans; i++)
         if (G.plans[i].core == core && G.plans[i].format == format && G.plans[i].end_word == end_word) {
-            if (G.plans[i].plan_id < 0) { fail(-8, "core was refused earlier"); return 0; }
+            if (G.plans[i].plan_id < 0 && !G.plans[i].empty) { fail(-8, "core was refused earlier"); return 0; }
             return &G.plans[i];
         }
+    /* A chain plan owns the FIR histories of its core (device rings, written back into the mirror only when plans
+     * are dropped).  The same core under a second DSP_FORMAT would get rings of its own that never see the
+     * first's samples: go through the mirror instead -- drop every plan, lower again under the new format. */
+    for (int i = 0; i < G.nplans; i++)
+        if (G.plans[i].core == core && G.plans[i].format != format && !G.plans[i].end_word && !end_word &&
+            (G.plans[i].max_taps || G.plans[i].nchains)) {
+            if (replan()) return 0;
+            break;
+        }
     if (G.nplans == MAX_CORE_PLANS) { fail(-9, "too many cores"); return 0; }
-    if (core < G.code || core >= G.code + dspHeaderPtr->totalLength) { fail(-1, "core pointer outside the loaded program"); return 0; }
 
     /* chains first (formats with parallel kernels); anything else the chain lowering calls "not
      * lowerable" (-8) is offered to the general interpreter; other failures are final */
@@ -910,17 +946,31 @@ static core_plan *get_plan_range(int format, opcode_t *core, int end_word)
     core_plan *cp = &G.plans[G.nplans];
     cp->core = core; cp->format = format; cp->end_word = end_word;
     cp->nchains = 0; cp->max_sections = 0; cp->max_taps = 0;
+    cp->total_chains = 0; cp->first_chain = 0; cp->empty = 0;
     cp->deps = deps;
     if (chains) {
+        /* this process's contiguous slice of the core's chains (dspRuntimeSetShard; the whole core when unsharded):
+         * the plan, its FIR rings and the IO windows a block call must cover shrink to the slice */
+        int lo, hi;
+        shard_range(L.nchains, G.shard_world, G.shard_rank, &lo, &hi);
+        cp->total_chains = L.nchains; cp->first_chain = lo; cp->nchains = hi - lo;
+        if (hi == lo) {                                     /* more ranks than chains: nothing to do here */
+            cp->empty = 1; cp->plan_id = -1;
+            lowered_free(&L);
+            G.nplans++;
+            return cp;
+        }
+        const int sec0 = L.chains[lo].sec_base;
+        const int sec1 = hi < L.nchains ? L.chains[hi].sec_base : L.nsec;
+        for (int i = lo; i < hi; i++) L.chains[i].sec_base -= sec0;
         avdsp_plan_desc d;
         memset(&d, 0, sizeof d);
         d.format = format;
-        d.nchains = L.nchains; d.chains = L.chains;
-        d.nsections = L.nsec; d.sec_coef_word = L.coef_word; d.sec_state_word = L.state_word;
+        d.nchains = hi - lo; d.chains = L.chains + lo;
+        d.nsections = sec1 - sec0; d.sec_coef_word = L.coef_word + sec0; d.sec_state_word = L.state_word + sec0;
         d.store_mask = G.store_mask;
         cp->plan_id = avdsp_hip_prog_add_plan(G.dev, &d);
-        cp->nchains = L.nchains;
-        for (int i = 0; i < L.nchains; i++) {
+        for (int i = lo; i < hi; i++) {
             if (L.chains[i].nsec > cp->max_sections) cp->max_sections = L.chains[i].nsec;
             if (L.chains[i].fir_taps > cp->max_taps) cp->max_taps = L.chains[i].fir_taps;
         }
@@ -974,6 +1024,46 @@ int dspRuntimeCoreInfo(int format, opcode_t *core, int *nchains, int *max_sectio
     return 0;
 }
 
+/* Host-only: which chains of the core this process runs under the current dspRuntimeSetShard, and the IO numbers
+ * they load and store -- what the block call's windows must cover, so a host can cut its column slice of a
+ * [frames][channels] block for ANY loaded program.  total == 0: not a chain core (it runs whole on every rank). */
+int dspRuntimeShardInfo(int format, opcode_t *core, int *total_chains, int *first_chain, int *nchains,
+                        int *in_io_min, int *in_io_max, int *out_io_min, int *out_io_max)
+{
+    if (!dspHeaderPtr || !G.code) return fail(-1, "no program loaded");
+    if (!G.have_rate) return fail(-1, "dspRuntimeReset(fs) has not selected a sample rate yet");
+    if (format < 2 || format > 6) return fail(-1, "DSP_FORMAT %d is not one of 2..6", format);
+    if (core < G.code || core >= G.code + dspHeaderPtr->totalLength) return fail(-1, "core pointer outside the loaded program");
+    int tot = 0, lo = 0, hi = 0, imin = 0, imax = -1, omin = 0, omax = -1;
+    if ((format == 2 || format == 4 || format == 6) && !G.opt_generic) {
+        lowered L;
+        int rc = lower_core(format, core, &L);
+        if (rc == 0) {
+            tot = L.nchains;
+            shard_range(tot, G.shard_world, G.shard_rank, &lo, &hi);
+            for (int i = lo; i < hi; i++) {
+                const avdsp_chain *c = &L.chains[i];
+                if (imax < imin || c->in_io < imin) imin = c->in_io;
+                if (imax < imin || c->in_io > imax) imax = c->in_io;
+                for (int k = 0; k < c->n_out; k++) {
+                    if (omax < omin || c->out_io[k] < omin) omin = c->out_io[k];
+                    if (omax < omin || c->out_io[k] > omax) omax = c->out_io[k];
+                }
+            }
+        }
+        lowered_free(&L);
+        if (rc && rc != -8) return rc;
+    }
+    if (total_chains) *total_chains = tot;
+    if (first_chain) *first_chain = lo;
+    if (nchains) *nchains = hi - lo;
+    if (in_io_min) *in_io_min = imin;
+    if (in_io_max) *in_io_max = imax;
+    if (out_io_min) *out_io_min = omin;
+    if (out_io_max) *out_io_max = omax;
+    return 0;
+}
+
 static int check_rundata(const int *rundata)
 {
     if (rundata != (const int *)G.code + dspHeaderPtr->totalLength)
@@ -989,7 +1079,7 @@ static int takes_pieces(const core_plan *cp, int nframes, int in_stride, int in_
 {
     /* windows that share IO numbers make every launch deliver whole rows, one after the other: the core in one piece then */
     const int overlap = in_stride > 0 && out_stride > 0 && in_io_base < out_io_base + out_stride && out_io_base < in_io_base + in_stride;
-    return cp->nchains == 0 && G.opt_strand_split && nframes > 1 && !overlap;
+    return cp->total_chains == 0 && G.opt_strand_split && nframes > 1 && !overlap;
 }
 
 int dspRuntimeBlockDevice(int format, opcode_t *core, int *rundata,
@@ -999,7 +1089,7 @@ int dspRuntimeBlockDevice(int format, opcode_t *core, int *rundata,
     core_plan *cp = get_plan(format, core);
     if (!cp) return g_err_code;
     if (check_rundata(rundata)) return -1;
-    if (nframes <= 0) return 0;
+    if (nframes <= 0 || cp->empty) return 0;
     if (takes_pieces(cp, nframes, in_stride, in_io_base, out_stride, out_io_base))
         return block_all(format, rundata, d_in, in_stride, in_io_base, d_out, out_stride, out_io_base, nframes, 1, stream, AVDSP_PCM_S32, core);
     if (avdsp_hip_run_block(G.dev, cp->plan_id, d_in, in_stride, in_io_base, d_out, out_stride, out_io_base,
@@ -1014,7 +1104,7 @@ static int block_host(int format, opcode_t *core, int *rundata, const void *in, 
     core_plan *cp = get_plan(format, core);
     if (!cp) return g_err_code;
     if (check_rundata(rundata)) return -1;
-    if (nframes <= 0) return 0;
+    if (nframes <= 0 || cp->empty) return 0;
     if (takes_pieces(cp, nframes, in_stride, in_io_base, out_stride, out_io_base))
         return block_all(format, rundata, in, in_stride, in_io_base, out, out_stride, out_io_base, nframes, 0, 0, AVDSP_PCM_S32, core);
     if (avdsp_hip_run_block_host(G.dev, cp->plan_id, in, in_stride, in_io_base, out, out_stride, out_io_base,
@@ -1167,7 +1257,7 @@ static int expand_core(int format, opcode_t *c, core_plan **cp, int *pn)
     static core_deps pd[MAX_GROUPS];
     core_plan *whole = get_plan(format, begin);           /* also tells whether the core is a chain core */
     if (!whole) return g_err_code;
-    if (G.opt_strand_split && whole->nchains == 0) ng = split_core(c, starts);
+    if (G.opt_strand_split && whole->total_chains == 0) ng = split_core(c, starts);
     if (ng > 1 && (G.nplans + ng + 8 > MAX_CORE_PLANS || n + ng + 8 > MAX_CORE_PLANS)) ng = 1;   /* plan table nearly full: whole */
     if (ng > 1) {
         /* Inside a core everything happens frame by frame: a later strand sees what an earlier one stored in
@@ -1199,7 +1289,7 @@ static int expand_core(int format, opcode_t *c, core_plan **cp, int *pn)
     const int pd_calc_first = ng > 1 && pd[0].tpdf_calc;           /* the first piece holds the TPDF_CALC: it publishes */
     if (ng <= 1) {
         if (n == MAX_CORE_PLANS) return fail(-9, "too many cores");
-        cp[n++] = whole;
+        if (!whole->empty) cp[n++] = whole;                    /* a shard without chains of this core: nothing to run */
     } else
         for (int g = 0; g < ng; g++) {
             if (n == MAX_CORE_PLANS) return fail(-9, "too many cores");
@@ -1240,7 +1330,7 @@ static int block_all(int format, int *rundata, const void *in, int in_stride, in
                 if (expand_core(format, c, cp, &n)) return g_err_code;
                 if (c == G.code) break;                           /* a program without DSP_CORE is one core */
             }
-        if (n == 0) return fail(-3, "no cores defined in the program");
+        if (n == 0 && ncores == 0) return fail(-3, "no cores defined in the program");
         for (int i = 0; i < n; i++) {
             level[i] = 0;
             for (int j = 0; j < i; j++)
@@ -1261,7 +1351,7 @@ static int block_all(int format, int *rundata, const void *in, int in_stride, in
         A = &G.arr[slot];
         if (n > (only ? MAX_GROUPS : MAX_CORE_PLANS)) return fail(-9, "too many pieces");
         free(A->plans);
-        A->plans = (int *)malloc(sizeof(int) * 2 * (size_t)(unsigned)n);
+        A->plans = (int *)malloc(sizeof(int) * (2 * (size_t)(unsigned)n + 2));
         if (!A->plans) { A->valid = 0; return fail(-9, "out of memory"); }
         A->size = A->plans + n;
         int m = 0;
@@ -1272,6 +1362,7 @@ static int block_all(int format, int *rundata, const void *in, int in_stride, in
         A->nlevels = nlevels; A->n = n; A->ncores = ncores; A->format = format; A->only = only; A->valid = 1;
     }
     G.last_levels = A->nlevels; G.last_cores = A->ncores; G.last_pieces = A->n;
+    if (A->n == 0) return 0;                                     /* every core's shard is empty on this rank */
     const int *plans = A->plans, *size = A->size;
     const int nlevels = A->nlevels;
     int rc = on_device
@@ -1309,7 +1400,7 @@ int dspRuntimeBlockPcm(int format, opcode_t *core, int *rundata, int pcm, const 
     core_plan *cp = get_plan(format, core);
     if (!cp) return g_err_code;
     if (check_rundata(rundata)) return -1;
-    if (nframes <= 0) return 0;
+    if (nframes <= 0 || cp->empty) return 0;
     if (takes_pieces(cp, nframes, in_stride, in_io_base, out_stride, out_io_base))
         return block_all(format, rundata, src, in_stride, in_io_base, dst, out_stride, out_io_base, nframes, 0, 0, pcm, core);
     if (avdsp_hip_run_block_pcm_host(G.dev, cp->plan_id, pcm, src, in_stride, in_io_base, dst, out_stride, out_io_base,

@@ -30,6 +30,7 @@ EXPORTED = [
     "dspRuntimeBlockDevice", "dspRuntimeBlockPcm", "dspRuntimeUnpackPcmDevice", "dspRuntimeBlockAll", "dspRuntimeBlockAllDevice", "dspRuntimeBlockAllPcm",
     "dspRuntimeSyncState", "dspRuntimeUploadState", "dspRuntimeUploadParams", "dspRuntimeSetOption", "dspRuntimeGetOption",
     "dspRuntimeCoreInfo", "dspRuntimeKernelTime", "dspRuntimeLastError", "dspRuntimeRelease",
+    "dspRuntimeSetShard", "dspRuntimeShardInfo",
     # thin HIP ABI (include/avdsp_hip.h)
     "avdsp_hip_device_count", "avdsp_hip_set_device", "avdsp_hip_prog_create", "avdsp_hip_prog_destroy",
     "avdsp_hip_prog_add_plan", "avdsp_hip_prog_add_generic", "avdsp_hip_prog_clear_plans", "avdsp_hip_tpdf_reset", "avdsp_hip_upload_words", "avdsp_hip_download_words", "avdsp_hip_zero_words",
@@ -109,6 +110,9 @@ def lib() -> C.CDLL:
         L.dspRuntimeGetOption.restype = i32; L.dspRuntimeGetOption.argtypes = [C.c_char_p]
         L.dspRuntimeCoreInfo.restype = i32
         L.dspRuntimeCoreInfo.argtypes = [i32, vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+        L.dspRuntimeSetShard.restype = i32; L.dspRuntimeSetShard.argtypes = [i32, i32]
+        L.dspRuntimeShardInfo.restype = i32
+        L.dspRuntimeShardInfo.argtypes = [i32, vp] + [C.POINTER(i32)] * 7
         L.dspRuntimeKernelTime.restype = i32
         L.dspRuntimeKernelTime.argtypes = [i32, C.POINTER(C.c_double), C.POINTER(i32)]
         L.dspRuntimeLastError.restype = C.c_char_p
@@ -186,6 +190,17 @@ class Runtime:
         a, b, c = C.c_int(), C.c_int(), C.c_int()
         self._check(self.L.dspRuntimeCoreInfo(self.fmt, self.cores[core_index], C.byref(a), C.byref(b), C.byref(c)))
         return dict(chains=a.value, max_sections=b.value, max_taps=c.value)
+
+    def set_shard(self, rank: int, world: int):
+        """dspRuntimeSetShard: this process runs chains shard_range(total, world, rank) of every chain core."""
+        self._check(self.L.dspRuntimeSetShard(rank, world))
+
+    def shard_info(self, core_index: int = 0):
+        """dspRuntimeShardInfo: the chains this process runs and the IO numbers they load / store (host-only)."""
+        v = [C.c_int() for _ in range(7)]
+        self._check(self.L.dspRuntimeShardInfo(self.fmt, self.cores[core_index], *[C.byref(x) for x in v]))
+        keys = ("total_chains", "first_chain", "nchains", "in_io_min", "in_io_max", "out_io_min", "out_io_max")
+        return {k: x.value for k, x in zip(keys, v)}
 
     # -- execution -------------------------------------------------------------------------
     def run_frame(self, samples: np.ndarray, core_index: int = 0) -> int:

@@ -8,9 +8,12 @@ dspRuntimeBlockDevice(); inputs and outputs are resident in HBM before the timed
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload north|cfg2|cfg3|cfg4|cfg5]
 
 N > 1 is launched by the driver as  python -m torch.distributed.run --nproc-per-node N bench.py ...
-one rank per GPU.  Channels are independent, so ranks shard channels with NO data-path collective
-(weak scaling: every rank runs the workload's channel count with its own slice of the global
-channel numbering); torch.distributed (RCCL) is used for the barriers and the max-over-ranks time.
+one rank per GPU.  The experiment is the one BASELINE.json names: a FIXED program (north: 4096 channels;
+cfg5: 16384) at 1, 2, 4 and 8 GPUs = STRONG scaling.  Every rank loads the same unsharded program and
+calls dspRuntimeSetShard(rank, world): the library cuts the lowered chain list into contiguous balanced
+ranges, the rank feeds its column slice of the [B][C] block and gets its slice of the output.  Channels
+are independent, so there is NO data-path collective; torch.distributed (RCCL) is used for the barriers
+and the max-over-ranks time.
 
 Rank 0 prints ONE JSON line with, besides the contract fields:
   roofline     -- for the dominant kernel (the FIR on v_mfma_f64_16x16x4_f64 when the workload has
@@ -34,13 +37,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # name: (format, channels per GPU, biquad sections, FIR taps, frames per block)
+    # name: (format, channels IN TOTAL (all GPUs together), biquad sections, FIR taps, frames per block)
     "north": (6, 4096, 16, 4096, 1024),     # BASELINE.json north_star target
     "cfg2":  (6, 8, 8, 0, 256),
     "cfg3":  (6, 4096, 16, 0, 1024),
     "cfg3i": (2, 4096, 16, 0, 1024),        # same in int64 fixed point
     "cfg4":  (6, 256, 0, 4096, 1024),
-    "cfg5":  (6, 2048, 8, 2048, 1024),      # 16384 channels over 8 GPUs
+    "cfg5":  (6, 16384, 8, 2048, 1024),     # BASELINE config 5: 16384 channels, 2048 per GPU at 8 GPUs
+    "cfg5s": (6, 2048, 8, 2048, 1024),      # one 8-GPU shard's worth of cfg5 as a program of its own
+    "north8": (6, 512, 16, 4096, 1024),     # what one rank of the north-star program runs at 8 GPUs
 }
 
 # Peaks from /opt/skills/guides/MI355X_MICROARCH.md (HBM3E 8 TB/s) and the MI355X datasheet value
@@ -60,23 +65,39 @@ def pmc_traffic(workload, kernel):
         return None
 
 
-def cpu_baseline_reference(fmt, S, T, B, budget_s=12.0):
-    """The COMPILED REFERENCE (oracle/_ref, built in the build container from /root/reference with its
-    own -Ofast flags; binaries travel to the GPU box): one ref_driver process per host core, each with
-    one channel of the same chain (the reference keeps one program per process in globals)."""
+def host_cores():
+    """(cores this process may really use, os.cpu_count()): the affinity mask and the cgroup CPU quota both cap it;
+    the box hands a one-GPU job a share of the host, not the whole machine."""
+    n_all = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = n_all
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(-(-int(quota) // int(period)))))
+    except (OSError, ValueError):
+        pass
+    return n, n_all
+
+
+def _ref_run(fmt, S, T, B, nproc, budget_s):
+    """`nproc` ref_driver processes, each with ONE channel of the same chain (the reference keeps one program per
+    process in globals), steady state (FIR delay lines filled first: zero state is an early-out): (samples, seconds)"""
     import subprocess
     import tempfile
     from avdsp_amd import progbuilder as pb
     from oracle import pyoracle as po
-    cores = max(1, min(os.cpu_count() or 1, 64))
     drv = os.path.join(po.REF_DIR, "ref_driver")
     lib = os.path.join(po.REF_DIR, f"libavdspref_{fmt}.so")
-    warm = (T + B - 1) // B + 1                              # passes that fill the FIR delay line (zero state is an early-out)
+    warm = (T + B - 1) // B + 1
     with tempfile.TemporaryDirectory() as d:
         x = pb.lcg_input(B, 1, fmt in (5, 6))
         xin = os.path.join(d, "in.raw"); x.tofile(xin)
         progs = []
-        for i in range(cores):
+        for i in range(nproc):
             p = os.path.join(d, f"p{i}.bin")
             pb.synth_program(fmt, 1, S, T, channel_base=i).tofile(p)
             progs.append(p)
@@ -85,10 +106,9 @@ def cpu_baseline_reference(fmt, S, T, B, budget_s=12.0):
             ps = [subprocess.Popen([drv, lib, str(fmt), progs[i], "0", "48000", "0", "31", xin,
                                     os.path.join(d, f"o{i}.raw"), str(B), str(B), "1", "1", "1", "0", "4",
                                     "-", str(repeat + warm), str(warm)], stdout=subprocess.PIPE, text=True)
-                  for i in range(cores)]
+                  for i in range(nproc)]
             outs = [p.communicate()[0] for p in ps]
-            el = [float(o.split("elapsed=")[1].split()[0]) for o in outs]
-            return max(el)
+            return max(float(o.split("elapsed=")[1].split()[0]) for o in outs)
 
         blocks = 4
         for _ in range(4):                                   # grow the sample until it fills about the budget
@@ -96,66 +116,63 @@ def cpu_baseline_reference(fmt, S, T, B, budget_s=12.0):
             if dt >= 0.6 * budget_s:
                 break
             blocks = max(blocks + 1, min(int(blocks * budget_s / max(dt, 1e-3)), 1 << 22))
-    samples = cores * blocks * B
-    return dict(value=samples / dt / 1e6, unit="Msamples/s", cores=cores, kind="reference",
-                sample=f"{cores} processes x 1 ch x {blocks} blocks of {B} frames of the same chain ({S} biquads + "
-                       f"{T}-tap FIR, DSP_FORMAT {fmt}) through the compiled reference runtime (oracle/_ref, gcc -Ofast), "
-                       f"steady state, {dt:.1f} s")
+    return nproc * blocks * B, dt, blocks
 
 
-def cpu_baseline(fmt, S, T, B, budget_s=12.0):
-    """Reference binaries when they travelled with the snapshot, else the oracle (CPU restatement):
-    one private program per thread, channels partitioned across threads."""
+def _port_run(fmt, S, T, B, nthreads, budget_s):
+    """the oracle (CPU restatement), one private program per thread (the C library releases the GIL)"""
     from avdsp_amd import progbuilder as pb
     from oracle import pyoracle as po
-    if po.have_ref() and os.path.exists(os.path.join(po.REF_DIR, f"libavdspref_{fmt}.so")):
-        try:
-            return cpu_baseline_reference(fmt, S, T, B, budget_s)
-        except Exception as e:                               # fall through to the port, say why
-            print(f"cpu_baseline: reference run failed ({e}); timing the oracle instead", file=sys.stderr)
     po.build()
-    cores = max(1, min(os.cpu_count() or 1, 64))
-    # size the sample from a short calibration so the whole leg stays near budget_s
-    ch_per_thread = 1
-    prog = pb.synth_program(fmt, ch_per_thread, S, T)
-    x = pb.lcg_input(B, ch_per_thread, fmt in (5, 6))
-    o = po.OracleProgram(fmt, prog)
-    warm_blocks = (T + B - 1) // B + 1                      # fill the FIR delay line: zero state takes an early-out
-    cal_frames = max(16, min(B, 128))
-    for _ in range(warm_blocks):
-        o.run_block(x, ch_per_thread, ch_per_thread)
+    x = pb.lcg_input(B, 1, fmt in (5, 6))
+    warm_blocks = (T + B - 1) // B + 1
+    progs = [po.OracleProgram(fmt, pb.synth_program(fmt, 1, S, T, channel_base=i)) for i in range(nthreads)]
+
+    def many(fn):
+        th = [threading.Thread(target=fn, args=(p,)) for p in progs]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        return time.perf_counter() - t0
+
+    many(lambda p: [p.run_block(x, 1, 1) for _ in range(warm_blocks)])
+    cal = max(16, min(B, 128))
     t0 = time.perf_counter()
-    o.run_block(x[:cal_frames], ch_per_thread, ch_per_thread)
-    per_sample = (time.perf_counter() - t0) / (cal_frames * ch_per_thread)
-    blocks = int(budget_s / max(per_sample * B * ch_per_thread, 1e-9))
-    blocks = max(1, min(blocks, 4096))
-    progs = [po.OracleProgram(fmt, pb.synth_program(fmt, ch_per_thread, S, T, channel_base=i)) for i in range(cores)]
+    progs[0].run_block(x[:cal], 1, 1)
+    per_sample = (time.perf_counter() - t0) / cal
+    blocks = max(1, min(int(budget_s / max(per_sample * B, 1e-9)), 4096))
+    dt = many(lambda p: [p.run_block(x, 1, 1) for _ in range(blocks)])
+    return nthreads * blocks * B, dt, blocks
 
-    def warm(p):
-        for _ in range(warm_blocks):
-            p.run_block(x, ch_per_thread, ch_per_thread)
 
-    th = [threading.Thread(target=warm, args=(p,)) for p in progs]
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
-
-    def work(p):
-        for _ in range(blocks):
-            p.run_block(x, ch_per_thread, ch_per_thread)
-
-    th = [threading.Thread(target=work, args=(p,)) for p in progs]
-    t0 = time.perf_counter()
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
-    dt = time.perf_counter() - t0
-    samples = cores * blocks * B * ch_per_thread
-    return dict(value=samples / dt / 1e6, unit="Msamples/s", cores=cores, kind="port",
-                sample=f"{cores} threads x {ch_per_thread} ch x {blocks} blocks of {B} frames of the same chain "
-                       f"({S} biquads + {T}-tap FIR, DSP_FORMAT {fmt}), oracle/liboracle.so, {dt:.1f} s")
+def cpu_baseline(fmt, S, T, B, budget_s=10.0):
+    """the CPU runtime on THIS box's host cores, (i) one thread, (ii) every core this job may use, one
+    channel of the same chain per core.  The compiled reference (oracle/_ref, kind "reference") when its binaries
+    travelled with the snapshot, else the oracle (kind "port")."""
+    from oracle import pyoracle as po
+    cores, n_all = host_cores()
+    kind, run = "port", _port_run
+    if po.have_ref() and os.path.exists(os.path.join(po.REF_DIR, f"libavdspref_{fmt}.so")):
+        kind, run = "reference", _ref_run
+    try:
+        s1, t1, b1 = run(fmt, S, T, B, 1, 0.35 * budget_s)
+        sn, tn, bn = run(fmt, S, T, B, cores, budget_s)
+    except Exception as e:                                   # fall through to the port, say why
+        if kind == "port":
+            raise
+        print(f"cpu_baseline: reference run failed ({e}); timing the oracle instead", file=sys.stderr)
+        kind = "port"
+        s1, t1, b1 = _port_run(fmt, S, T, B, 1, 0.35 * budget_s)
+        sn, tn, bn = _port_run(fmt, S, T, B, cores, budget_s)
+    what = ("the compiled reference runtime (oracle/_ref, gcc -Ofast), one process per core" if kind == "reference"
+            else "oracle/liboracle.so, one thread per core")
+    return dict(value=sn / tn / 1e6, unit="Msamples/s", cores=cores, kind=kind,
+                single_thread=s1 / t1 / 1e6, host_cpus=n_all,
+                sample=f"{cores} x 1 ch x {bn} blocks of {B} frames of the same chain ({S} biquads + {T}-tap FIR, "
+                       f"DSP_FORMAT {fmt}) through {what}, steady state, {tn:.1f} s; single_thread: 1 ch x {b1} blocks, {t1:.1f} s; "
+                       f"cores = what this job may use (affinity mask and cgroup quota) of the host's {n_all} CPUs")
 
 
 def main():
@@ -166,6 +183,9 @@ def main():
     ap.add_argument("--workload", default="north", choices=sorted(WORKLOADS))
     ap.add_argument("--fir-impl", type=int, default=1)
     ap.add_argument("--biquad-impl", type=int, default=1)
+    ap.add_argument("--overlap", type=int, default=-1, help="cascade of the next block under the FIR of this one: 0 off, 1 on, -1 library default")
+    ap.add_argument("--shard", default=None, help="RANK/WORLD: run that one shard of the program on this GPU alone (what one rank of a WORLD-GPU job does)")
+    ap.add_argument("--host-buffers", action="store_true", help="also time dspRuntimeBlock_N with HOST buffers (PCIe inclusive), reported beside value")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -173,7 +193,6 @@ def main():
     import torch.distributed as dist
     from avdsp_amd import progbuilder as pb
     from avdsp_amd import runtime as rt
-    from avdsp_amd import sharding as sh
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -199,23 +218,35 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
         else:
             dist.init_process_group(backend=backend)
-    # weak scaling: the job is C*world channels, this rank owns the contiguous slice [rank*C, (rank+1)*C)
-    prog, ch_lo, ch_hi = sh.shard_program(fmt, C * world, S, T, world, rank)
-    assert ch_hi - ch_lo == C
-    r = rt.Runtime(fmt, prog)
+    # STRONG scaling: the job is the fixed C-channel program; every rank loads it whole and runs its own chains
+    shard_rank, shard_world = rank, world
+    if args.shard:
+        shard_rank, shard_world = (int(v) for v in args.shard.split("/"))
+    r = rt.Runtime(fmt, pb.synth_program(fmt, C, S, T))
     if r.rc < 0:
         sys.exit(f"dspRuntimeInit failed: {r.rc} {r.last_error()}")
     r.set_option("device", device_index)
     r.set_option("fir_impl", args.fir_impl)
     r.set_option("biquad_impl", args.biquad_impl)
+    if args.overlap >= 0:
+        r.set_option("overlap", args.overlap)
     r.set_option("profile", 1)
+    r.set_shard(shard_rank, shard_world)
+    info = r.shard_info()
+    Cl = info["nchains"]                                    # this rank's channels
+    if Cl < 1:
+        sys.exit(f"rank {rank}: no chains in shard {shard_rank}/{shard_world}")
+    in_base, out_base = info["in_io_min"], info["out_io_min"]
+    assert info["in_io_max"] - in_base + 1 == Cl and info["out_io_max"] - out_base + 1 == Cl
 
-    x = torch.from_numpy(pb.lcg_input(B, C, fmt == 6, seed=12345 + rank)).cuda()
-    y = torch.zeros((B, C), dtype=x.dtype, device="cuda")
+    xfull = pb.lcg_input(B, C, fmt == 6, seed=12345)
+    xs = np.ascontiguousarray(xfull[:, in_base - C:in_base - C + Cl])      # the rank's column slice of the [B][C] block
+    x = torch.from_numpy(xs).cuda()
+    y = torch.zeros((B, Cl), dtype=x.dtype, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
-        r.run_block_device(x.data_ptr(), C, C, y.data_ptr(), C, 0, B, stream)
+        r.run_block_device(x.data_ptr(), Cl, in_base, y.data_ptr(), Cl, out_base, B, stream)
 
     for _ in range(args.warmup):
         step()
@@ -254,39 +285,67 @@ def main():
     if not np.isfinite(checksum) or checksum == 0.0:
         sys.exit("bench.py: output block is empty or not finite")
 
+    host_rate = None
+    if args.host_buffers and rank == 0:
+        # the reference-shaped boundary: dspRuntimeBlock_N with HOST pointers, PCIe crossings inside the timed region
+        r.set_option("profile", 0)
+        hy = np.zeros((B, Cl), dtype=xs.dtype)
+        for _ in range(3):
+            r.run_block(xs, Cl, in_base, out_base, out=hy)
+        n = max(5, args.steps // 2)
+        th = time.perf_counter()
+        for _ in range(n):
+            r.run_block(xs, Cl, in_base, out_base, out=hy)
+        host_rate = Cl * B * n / (time.perf_counter() - th) / 1e6
+
     if rank == 0:
-        total_samples = world * C * B * args.steps
-        value = total_samples / elapsed / 1e6
+        ranks_share = shard_world if args.shard else world
+        units = (Cl if args.shard else C) * B * args.steps   # samples all ranks processed (one shard alone: its own)
+        value = units / elapsed / 1e6
+        step_s = elapsed / args.steps
+        # SURVEY.md 8(d) algorithmic bytes of one step of THIS rank: samples in+out, biquad state r+w and coefficients,
+        # FIR history carry-in/out and taps
+        step_bytes = 8.0 * Cl * B + 68.0 * S * Cl + (8.0 * (T - 1) * Cl + 4.0 * T * Cl if T else 0.0)
         if T and fir_n:
             per_launch = fir_ms / fir_n * 1e-3
-            # 2*T flop per sample; the C*B samples of a step are spread over fir_n/steps launches
-            flops = 2.0 * T * B * C * args.steps / fir_n
+            # 2*T flop per sample; the Cl*B samples of a step are spread over fir_n/steps launches
+            flops = 2.0 * T * B * Cl * args.steps / fir_n
             ach = flops / per_launch / 1e12
             kname = "fir_mfma" if args.fir_impl else "fir_plain"
+            fir_bytes = (4.0 * Cl * B + 4.0 * (T - 1 + B) * Cl + 4.0 * T * Cl) * args.steps / fir_n   # out, window, taps
             roof = dict(bound="mfma", kernel=kname, achieved=ach,
-                        peak=PEAK_F64_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_F64_TFLOPS, traffic=pmc_traffic(args.workload, kname),
+                        peak=PEAK_F64_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_F64_TFLOPS,
+                        traffic=pmc_traffic(args.workload, kname), traffic_source="profiles/traffic.json (committed rocprofv3 --pmc passes of this command, not this run)",
+                        hbm_frac=fir_bytes / per_launch / 1e9 / PEAK_HBM_GBS,
                         launch_ms=per_launch * 1e3, launches=fir_n)
         elif bq_n:
             per_launch = bq_ms / bq_n * 1e-3
-            nbytes = 8.0 * C * B + 48.0 * S * C + 20.0 * S * C   # samples in+out, state r+w, coefficients
+            nbytes = 8.0 * Cl * B + 48.0 * S * Cl + 20.0 * S * Cl   # samples in+out, state r+w, coefficients
             ach = nbytes / per_launch / 1e9
             kname = "biquad_pipe" if args.biquad_impl else "biquad_simple"
             roof = dict(bound="hbm", kernel=kname, achieved=ach,
-                        peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS, traffic=pmc_traffic(args.workload, kname),
+                        peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS,
+                        traffic=pmc_traffic(args.workload, kname), traffic_source="profiles/traffic.json (committed rocprofv3 --pmc passes of this command, not this run)",
                         launch_ms=per_launch * 1e3, launches=bq_n)
         else:
             roof = None
+        shard_txt = (f"shard {shard_rank}/{shard_world} alone on one GPU ({Cl} ch)" if args.shard
+                     else f"{C} ch in total, {Cl} ch/GPU by dspRuntimeSetShard(rank, {world})")
         line = {
             "metric": "Msamples/s (all ch) biquad+FIR chain", "value": value, "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64" if fmt != 2 else "int64", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {C} ch/GPU x ({S} biquads + {T}-tap FIR), block {B} frames, "
-                                   f"DSP_FORMAT {fmt}, channels sharded {world}-way, no data-path collective",
-                       "channels_per_gpu": C, "sections": S, "taps": T, "block": B, "format": fmt},
+            "config": {"workload": f"{args.workload}: {C} ch x ({S} biquads + {T}-tap FIR), block {B} frames, "
+                                   f"DSP_FORMAT {fmt}; {shard_txt}, no data-path collective",
+                       "channels": C, "channels_per_gpu": Cl, "sections": S, "taps": T, "block": B, "format": fmt,
+                       "overlap": r.get_option("overlap")},
             "roofline": roof,
+            "hbm_frac_step": step_bytes / step_s / 1e9 / PEAK_HBM_GBS,
             "kernels_ms": {"biquad": bq_ms / max(bq_n, 1), "fir": fir_ms / max(fir_n, 1)},
         }
+        if host_rate is not None:
+            line["host_buffers_msamples_s"] = host_rate
         line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)
     r.release()

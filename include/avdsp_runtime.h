@@ -136,6 +136,25 @@ int dspRuntimeUploadState(const int *rundata);
  * words, as the reference allows between any two frames: carry the edits to the device.  State is kept. */
 int dspRuntimeUploadParams(void);
 
+/* ---------------- channel sharding across the GPUs of a node (not in the reference) ----------------
+ * The reference has one notion of several executors: DSP_CORE segments meant for parallel XMOS threads, which its
+ * Linux hosts run one after the other (linux/avdsp_plugin.c:95).  Here the unit is finer: the chains of a chain core
+ * are independent channels (the lowering proves it: no IO stored twice, none both loaded and stored), so
+ * `world` processes -- one per GPU -- each run a contiguous, balanced range of them and never exchange anything.
+ *
+ * dspRuntimeSetShard(rank, world): from now on every chain core of the loaded program is lowered to the chains
+ * [lo, hi) of rank `rank` only, lo = rank*q + min(rank, r), hi = lo + q + (rank < r), (q, r) = divmod(chains, world).
+ * It works on any loaded .bin (the cut is made after lowering, on the chain list), keeps the device state
+ * (FIR histories return to the mirror and are picked up again), and (0, 1) switches it off.  The block calls'
+ * windows then only need to cover the IO numbers of the rank's own chains: a host hands over its column slice
+ *     in  = x + in_io_min-th column,  in_io_base  = in_io_min,  in_stride  = whatever pitch the slice has
+ * and receives its slice of the output columns; dspRuntimeShardInfo() reports those IO ranges (host-only, nothing
+ * runs).  Cores that are not chain cores (interpreter) are not cut: every rank runs them whole (replicas).
+ * dspRuntimeSyncState() returns this rank's view: its own chains' state advanced, the other chains' untouched. */
+int dspRuntimeSetShard(int rank, int world);
+int dspRuntimeShardInfo(int format, opcode_t *core, int *total_chains, int *first_chain, int *nchains,
+                        int *in_io_min, int *in_io_max, int *out_io_min, int *out_io_max);
+
 /* Tunables: "fir_impl" 0 = plain tap loop, 1 = MFMA (default); "biquad_impl" 0 = lane per channel,
  * 1 = section-pipelined (default); "interp_impl" 0 = interpreter always frame by frame, 1 = frame-parallel
  * where the core allows it (default); "strand_split" 0 = dspRuntimeBlockAll keeps cores whole; "generic" 1 = every core through the interpreter;

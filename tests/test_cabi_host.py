@@ -120,6 +120,39 @@ def test_path_selection_and_refusals():
     assert len(bad) == 1 and bad[0][0] == -8 and "outside the program" in bad[0][1]
 
 
+def test_shard_cut_is_host_side_and_works_on_any_program():
+    """dspRuntimeSetShard / dspRuntimeShardInfo: contiguous balanced ranges of the lowered chain list, IO windows of the
+    rank's own chains, on a program with scattered IO numbers; interpreter cores are not cut; bad arguments are refused."""
+    L = rt.lib()
+    pw = pb.ProgramWriter(6)
+    pw.core()
+    ios = [(40, 3), (17, 9), (33, 0), (18, 30), (50, 7)]
+    for i, o in ios:
+        pw.load(i); pw.sat0db(); pw.store(o)
+    r = rt.Runtime(6, pw.end_of_code())
+    assert r.shard_info() == dict(total_chains=5, first_chain=0, nchains=5, in_io_min=17, in_io_max=50, out_io_min=0, out_io_max=30)
+    seen = []
+    for rank in range(3):
+        r.set_shard(rank, 3)
+        info = r.shard_info()
+        mine = ios[info["first_chain"]:info["first_chain"] + info["nchains"]]
+        seen += mine
+        assert info["in_io_min"] == min(i for i, _ in mine) and info["in_io_max"] == max(i for i, _ in mine)
+        assert info["out_io_min"] == min(o for _, o in mine) and info["out_io_max"] == max(o for _, o in mine)
+        assert r.get_option("shard_rank") == rank and r.get_option("shard_world") == 3
+    assert seen == ios
+    r.set_shard(6, 7)                                         # more ranks than chains: an empty slice, not an error
+    assert r.shard_info()["nchains"] == 0 and r.shard_info()["total_chains"] == 5
+    for bad in ((3, 3), (-1, 2), (0, 0)):
+        assert L.dspRuntimeSetShard(*bad) == -1
+    r.set_shard(0, 1)
+    prog = np.fromfile(os.path.join(GOLDEN_DIR, "crossoverLV6.bin"), dtype=np.uint32)
+    r = rt.Runtime(2, prog, fs=48000, dither=24)
+    r.set_shard(1, 2)
+    assert r.shard_info(0)["total_chains"] == 0               # not a chain core: runs whole on every rank
+    r.set_shard(0, 1)
+
+
 def test_no_cpu_fallback_without_a_gpu():
     if rt.lib().avdsp_hip_device_count() > 0:
         pytest.skip("a GPU is visible here")

@@ -1,9 +1,12 @@
-"""The N>1 path on CPU: world_size-2 (and 3) torch.distributed runs over gloo.  Each rank builds its
-channel shard of the program, processes its column slice of the same seeded input block, and the
-ranks agree -- through an all_gather and an all_reduce, the only collectives the design uses, both
-at the block boundary -- that the concatenated shards equal the unsharded result.  The per-rank
-compute here is the ORACLE (no GPU in this container); what is under test is the sharding logic,
-the slice bookkeeping and the collective calls bench.py relies on."""
+"""The N>1 path on CPU: world_size-2 (and 3) torch.distributed runs over gloo.  Each rank loads the UNSHARDED program
+into the C-ABI library, calls dspRuntimeSetShard(rank, world) and asks dspRuntimeShardInfo (host-only lowering, no
+GPU needed) which chains and IO windows are its own; it then processes that column slice of the same seeded input
+block, and the ranks agree -- through an all_gather and an all_reduce, the only collectives the design uses, both at
+the block boundary -- that the concatenated shards equal the unsharded result.  There is no GPU in this container,
+so the arithmetic of a rank's slice is done by the ORACLE on the equivalent shard program (the checker standing in
+for the kernels); what is under test is the library's cut, the slice bookkeeping and the collective calls bench.py
+relies on.  The same test with the HIP kernels doing the work is tests/test_gpu_headline.py
+(test_world_n_ranks_hip_path_over_gloo, -m gpu)."""
 import os
 import socket
 
@@ -28,9 +31,19 @@ def _worker(rank, world, port, fmt, C, S, T, B, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from oracle import pyoracle as po
+        from avdsp_amd import runtime as rt
+        # the library's cut of the unsharded program (what the GPU path runs) ...
+        r = rt.Runtime(fmt, pb.synth_program(fmt, C, S, T))
+        r.set_shard(rank, world)
+        info = r.shard_info()
+        r.release()
+        # ... must be the contiguous balanced range, with the IO windows of exactly those channels
         prog, lo, hi = sh.shard_program(fmt, C, S, T, world, rank)
+        assert info == dict(total_chains=C, first_chain=lo, nchains=hi - lo, in_io_min=C + lo, in_io_max=C + hi - 1,
+                            out_io_min=lo, out_io_max=hi - 1), info
         x = pb.lcg_input(B, C, fmt == 6, seed=31)
-        xs = sh.shard_block(x, world, rank)
+        xs = np.ascontiguousarray(x[:, info["in_io_min"] - C:info["in_io_max"] + 1 - C])
+        assert (xs == sh.shard_block(x, world, rank)).all()
         o = po.OracleProgram(fmt, prog)
         y = o.run_block(xs, hi - lo, hi - lo)
         # block-boundary collectives: gather the (ragged) slices, reduce the checksums
