@@ -64,6 +64,7 @@ int set_err(const char *fmt, ...)
 constexpr int kFirChunk   = 1024;     /* frames per launch: 4 MFMA tiles of 256 frames */
 constexpr int kTileFrames = 256;
 constexpr int kBlock      = 256;
+constexpr int kBigBlock   = 1024;
 
 /* ------------------------------------------------------------------------------------------
  * device helpers: arithmetic of the load / store stages
@@ -311,13 +312,17 @@ __device__ __forceinline__ Hand<FMT> hand_rotate(Hand<FMT> h)
     return h;
 }
 
-template <int FMT, int P>
-__global__ __launch_bounds__(kBlock) void biquad_pipe(const BiquadArgs a)
+/* BLK = threads per workgroup.  256 normally.  1024 for the launches that run UNDER the previous block's FIR
+ * (avdsp_hip_run_block, "overlap"): sixteen waves per workgroup, and the launch claims most of a CU's LDS without
+ * using it, so that a cascade workgroup has its CU to itself -- its v_fma_f64 chain shares the FP64 datapath with
+ * v_mfma_f64 and crawls behind a FIR wave on the same SIMD -- while the FIR keeps every other CU.              */
+template <int FMT, int P, int BLK = kBlock>
+__global__ __launch_bounds__(BLK) void biquad_pipe(const BiquadArgs a)
 {
     if constexpr (FMT != 2) flush_f32_subnormals_like_the_reference();
     using alu_t = typename Alu<FMT>::type;
     constexpr int NB = P < 16 ? P : 16;                 /* steps per IO batch */
-    constexpr int CPB = kBlock / P;                     /* chains per block */
+    constexpr int CPB = BLK / P;                        /* chains per block */
     constexpr int DEPTH = 3;                            /* input batches in flight */
     const int tid = threadIdx.x, rowpos = tid & 15;
     const int blk = xcd_remap(blockIdx.x, a.per_xcd);
@@ -860,6 +865,7 @@ struct Plan {
     int io_in_min = 0, io_in_max = -1, io_out_min = 0, io_out_max = -1;
     bool wave_ok = false; unsigned carried_io[8] = {0, 0, 0, 0, 0, 0, 0, 0};      /* frame-parallel interpreter */
     int *d_own = nullptr;                                /* owned mirror ranges (pairs), generic plans */
+    bool overlap_ok = false;                             /* every cascade of the plan feeds a FIR: its launches may run under the previous block's FIR */
 };
 
 }  // namespace
@@ -886,6 +892,12 @@ struct avdsp_hip_prog {
     std::vector<hipStream_t> side;
     std::vector<hipEvent_t> join;
     hipEvent_t fork = nullptr;
+    /* cascade of block k+1 under the FIR of block k ("overlap"): the cascades run on a stream of their own */
+    int overlap = 0, bq_block = kBigBlock, bq_lds = 140 * 1024;
+    hipStream_t s_bq = nullptr;
+    hipEvent_t ev_bq[2] = {nullptr, nullptr}, ev_fir[2] = {nullptr, nullptr};
+    bool ev_fir_set[2] = {false, false};
+    unsigned long long blk = 0;
 };
 
 namespace {
@@ -950,9 +962,23 @@ struct ProfileScope {                   /* records an event pair around the laun
     }
 };
 
+/* the 1024-thread form of the cascade and the LDS it claims (bytes) when it runs under a FIR; opted in per function
+ * at plan creation (nothing in the launch path may touch function attributes) */
+template <int FMT>
+const void *biquad_big_fn(int P)
+{
+    switch (P) {
+    case 8:  return (const void *)biquad_pipe<FMT, 8, kBigBlock>;
+    case 16: return (const void *)biquad_pipe<FMT, 16, kBigBlock>;
+    case 32: return (const void *)biquad_pipe<FMT, 32, kBigBlock>;
+    case 64: return (const void *)biquad_pipe<FMT, 64, kBigBlock>;
+    }
+    return nullptr;
+}
+
 template <int FMT>
 int launch_biquad(avdsp_hip_prog *prog, Plan &pl, const Plan::Group &g, const int *ids, int n, BlockIO io,
-                  int biquad_impl, hipStream_t stream)
+                  int biquad_impl, hipStream_t stream, bool under_fir = false)
 {
     ProfileScope scope(prog, stream, AVDSP_KERNEL_BIQUAD);
     BiquadArgs a{};
@@ -960,6 +986,18 @@ int launch_biquad(avdsp_hip_prog *prog, Plan &pl, const Plan::Group &g, const in
     a.group = ids; a.ngroup = n; a.nsec = g.nsec; a.ring = plan_ring(pl); a.io = io;
     if (biquad_impl == 0 || g.P > 64) {
         hipLaunchKernelGGL(biquad_simple<FMT>, dim3((n + 63) / 64), dim3(64), 0, stream, a);
+    } else if (under_fir && prog->bq_block == kBigBlock && biquad_big_fn<FMT>(g.P)) {
+        const int cpb = kBigBlock / g.P;
+        const int nblk = (n + cpb - 1) / cpb;
+        a.per_xcd = (nblk + 7) / 8;
+        const dim3 grid(a.per_xcd * 8), block(kBigBlock);
+        const size_t lds = (size_t)prog->bq_lds;
+        switch (g.P) {
+        case 8:  hipLaunchKernelGGL((biquad_pipe<FMT, 8, kBigBlock>),  grid, block, lds, stream, a); break;
+        case 16: hipLaunchKernelGGL((biquad_pipe<FMT, 16, kBigBlock>), grid, block, lds, stream, a); break;
+        case 32: hipLaunchKernelGGL((biquad_pipe<FMT, 32, kBigBlock>), grid, block, lds, stream, a); break;
+        default: hipLaunchKernelGGL((biquad_pipe<FMT, 64, kBigBlock>), grid, block, lds, stream, a); break;
+        }
     } else {
         const int cpb = kBlock / g.P;
         const int nblk = (n + cpb - 1) / cpb;
@@ -1001,16 +1039,54 @@ int launch_fir(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, BlockIO io
     }
 }
 
-/* The cascade and the FIR of a block run back to back on the caller's stream.  Running the cascades
- * of one slice of channels underneath the FIR of another slice (separate streams) was tried and is
- * 30 % SLOWER: the cascade's v_fma_f64 chain and v_mfma_f64 share the FP64 datapath, so a cascade step
- * behind a saturated matrix pipe waits a whole MFMA per FMA (152 us per quarter instead of 19 us).  */
+/* The cascade and the FIR of a block normally run back to back on the caller's stream.  Running the cascades of one
+ * slice of channels underneath the FIR of another slice in the ordinary launch geometry was tried and is 30 % SLOWER:
+ * the cascade's v_fma_f64 chain and v_mfma_f64 share the FP64 datapath, so a cascade step behind a saturated matrix
+ * pipe waits a whole MFMA per FMA (152 us per quarter instead of 19 us).
+ *
+ * "overlap" (opt-in, dspRuntimeSetOption): the cascade of block k+1 runs under the FIR of block k after all -- on a
+ * stream of its own, in 1024-thread workgroups that each claim a whole CU's LDS, so that cascade waves and FIR waves
+ * never share a SIMD: the cascade of a 512-channel shard keeps 8 CUs busy, the FIR the other 248.  The cascade is a
+ * latency-bound recurrence (its time hardly depends on the channel count), which is exactly what a strong-scaling
+ * rank with few channels cannot afford to run in front of its FIR.  Ordering:
+ *     cascade k   waits for FIR k-2 (the ring positions it appends are free once that FIR has read its window),
+ *                 NOT for the caller's stream -- the mode's contract is that the input block is complete in memory
+ *                 when the call is made;
+ *     FIR k       on the caller's stream, after cascade k: outputs are ordered on that stream as always.
+ * Only when every cascade feeds a FIR (a cascade that stores straight to the output block would write it from the
+ * side stream).                                                                                                */
+static int overlap_ready(avdsp_hip_prog *prog)
+{
+    if (prog->s_bq) return 0;
+    HIP_TRY(hipStreamCreateWithFlags(&prog->s_bq, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) {
+        HIP_TRY(hipEventCreateWithFlags(&prog->ev_bq[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&prog->ev_fir[i], hipEventDisableTiming));
+    }
+    return 0;
+}
+
 template <int FMT>
 int launch_all(avdsp_hip_prog *prog, Plan &pl, BlockIO io, int fir_impl, int biquad_impl, hipStream_t stream)
 {
-    for (auto &g : pl.bq)
-        if (launch_biquad<FMT>(prog, pl, g, g.d_ids, g.n, io, biquad_impl, stream)) return -1;
-    if (pl.n_fir && launch_fir<FMT>(prog, pl, pl.d_fir_ids, pl.n_fir, io, fir_impl, stream)) return -1;
+    const bool under = prog->overlap && pl.overlap_ok && biquad_impl && fir_impl;
+    if (under) {
+        if (overlap_ready(prog)) return -1;
+        const int slot = (int)(prog->blk & 1);
+        if (prog->ev_fir_set[slot]) HIP_TRY(hipStreamWaitEvent(prog->s_bq, prog->ev_fir[slot], 0));   /* FIR k-2 */
+        for (auto &g : pl.bq)
+            if (launch_biquad<FMT>(prog, pl, g, g.d_ids, g.n, io, biquad_impl, prog->s_bq, true)) return -1;
+        HIP_TRY(hipEventRecord(prog->ev_bq[slot], prog->s_bq));
+        HIP_TRY(hipStreamWaitEvent(stream, prog->ev_bq[slot], 0));
+        if (launch_fir<FMT>(prog, pl, pl.d_fir_ids, pl.n_fir, io, fir_impl, stream)) return -1;
+        HIP_TRY(hipEventRecord(prog->ev_fir[slot], stream));
+        prog->ev_fir_set[slot] = true;
+        prog->blk++;
+    } else {
+        for (auto &g : pl.bq)
+            if (launch_biquad<FMT>(prog, pl, g, g.d_ids, g.n, io, biquad_impl, stream)) return -1;
+        if (pl.n_fir && launch_fir<FMT>(prog, pl, pl.d_fir_ids, pl.n_fir, io, fir_impl, stream)) return -1;
+    }
     if (pl.n_pass) {
         ProfileScope scope(prog, stream, AVDSP_KERNEL_PASS);
         PassArgs a{pl.d_chains, pl.d_pass_ids, pl.n_pass, io};
@@ -1064,6 +1140,8 @@ void avdsp_hip_prog_destroy(avdsp_hip_prog *p)
     for (auto st : p->side) (void)hipStreamDestroy(st);
     for (auto e : p->join) (void)hipEventDestroy(e);
     if (p->fork) (void)hipEventDestroy(p->fork);
+    if (p->s_bq) (void)hipStreamDestroy(p->s_bq);
+    for (int i = 0; i < 2; i++) { if (p->ev_bq[i]) (void)hipEventDestroy(p->ev_bq[i]); if (p->ev_fir[i]) (void)hipEventDestroy(p->ev_fir[i]); }
     (void)hipFree(p->d_buf); (void)hipFree(p->d_in); (void)hipFree(p->d_out); (void)hipFree(p->d_tpdf); (void)hipFree(p->d_frame);
     (void)hipFree(p->d_tpdf_seq);
     delete p;
@@ -1132,7 +1210,8 @@ int avdsp_hip_prog_add_plan(avdsp_hip_prog *prog, const avdsp_plan_desc *d)
                 if (e != hipSuccess) { free_plan(pl); return set_err("hipFuncSetAttribute(LDS %d): %s", lds, hipGetErrorString(e)); }
             }
         }
-        pl.ring_R = pow2ceil(pl.max_taps + kFirChunk + 16 * pl.fir_gpc + 16 * (kNG + 4) + 64);
+        /* + one more launch of frames: under "overlap" the cascade appends block k+1 while the FIR still reads block k's window */
+        pl.ring_R = pow2ceil(pl.max_taps + 2 * kFirChunk + 16 * pl.fir_gpc + 16 * (kNG + 4) + 64);
         static_assert(kFirChunk == kFirPad, "one FIR launch covers exactly the frames the window image is laid out for");
         hipError_t e = hipMalloc((void **)&pl.d_ring, (size_t)d->nchains * pl.ring_R * sizeof(float));
         if (e != hipSuccess) { free_plan(pl); return set_err("hipMalloc(FIR rings, %d x %d): %s", d->nchains, pl.ring_R, hipGetErrorString(e)); }
@@ -1141,6 +1220,16 @@ int avdsp_hip_prog_add_plan(avdsp_hip_prog *prog, const avdsp_plan_desc *d)
         hipLaunchKernelGGL(state_to_ring, dim3(pl.n_fir), dim3(kBlock), 0, nullptr, ca);   /* history the caller's buffer holds */
         if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) { free_plan(pl); return set_err("state_to_ring failed"); }
     }
+    pl.overlap_ok = pl.n_fir > 0 && !pl.bq.empty();
+    for (int i = 0; i < d->nchains && pl.overlap_ok; i++)
+        if (chains[i].nsec && !chains[i].fir_taps) pl.overlap_ok = false;
+    if (pl.overlap_ok)
+        for (auto &g : pl.bq) {
+            const void *fn = d->format == 4 ? biquad_big_fn<4>(g.P) : biquad_big_fn<6>(g.P);
+            if (!fn) continue;
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) { free_plan(pl); return set_err("hipFuncSetAttribute(cascade LDS claim): %s", hipGetErrorString(e)); }
+        }
     prog->plans.push_back(pl);
     return (int)prog->plans.size() - 1;
 }
@@ -1688,6 +1777,19 @@ int avdsp_hip_run_levels_pcm_host(avdsp_hip_prog *prog, const int *plans, const 
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(h_out, prog->d_out, out_words * 4, hipMemcpyDeviceToHost));
     return 0;
+}
+
+int avdsp_hip_prog_set_option(avdsp_hip_prog *prog, int key, int value)
+{
+    HIP_TRY(hipDeviceSynchronize());                    /* nothing in flight when the launch arrangement changes */
+    switch (key) {
+    case AVDSP_OPT_OVERLAP:  prog->overlap = value != 0; prog->ev_fir_set[0] = prog->ev_fir_set[1] = false; return 0;
+    case AVDSP_OPT_BQ_BLOCK: if (value != kBlock && value != kBigBlock) return set_err("cascade workgroups have %d or %d threads", kBlock, kBigBlock);
+                             prog->bq_block = value; return 0;
+    case AVDSP_OPT_BQ_LDS:   if (value < 0 || value > 160 * 1024) return set_err("LDS claim %d outside [0, 160 KiB]", value);
+                             prog->bq_lds = value; return 0;
+    }
+    return set_err("unknown device option %d", key);
 }
 
 int avdsp_hip_profile_enable(avdsp_hip_prog *prog, int on)

@@ -34,7 +34,7 @@ EXPORTED = [
     # thin HIP ABI (include/avdsp_hip.h)
     "avdsp_hip_device_count", "avdsp_hip_set_device", "avdsp_hip_prog_create", "avdsp_hip_prog_destroy",
     "avdsp_hip_prog_add_plan", "avdsp_hip_prog_add_generic", "avdsp_hip_prog_clear_plans", "avdsp_hip_tpdf_reset", "avdsp_hip_upload_words", "avdsp_hip_download_words", "avdsp_hip_zero_words",
-    "avdsp_hip_run_block", "avdsp_hip_run_block_host", "avdsp_hip_run_levels", "avdsp_hip_run_levels_host", "avdsp_hip_run_levels_pcm_host", "avdsp_hip_unpack_pcm", "avdsp_hip_run_block_pcm_host", "avdsp_hip_profile_enable", "avdsp_hip_profile_read",
+    "avdsp_hip_run_block", "avdsp_hip_run_block_host", "avdsp_hip_run_levels", "avdsp_hip_run_levels_host", "avdsp_hip_run_levels_pcm_host", "avdsp_hip_unpack_pcm", "avdsp_hip_run_block_pcm_host", "avdsp_hip_profile_enable", "avdsp_hip_profile_read", "avdsp_hip_prog_set_option",
     "avdsp_hip_synchronize", "avdsp_hip_last_error",
 ]
 

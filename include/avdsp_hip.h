@@ -155,6 +155,13 @@ enum { AVDSP_KERNEL_BIQUAD = 0, AVDSP_KERNEL_FIR = 1, AVDSP_KERNEL_PASS = 2, AVD
 int avdsp_hip_profile_enable(avdsp_hip_prog *prog, int on);
 int avdsp_hip_profile_read(avdsp_hip_prog *prog, int kind, double *total_ms, int *launches);
 
+/* Launch arrangement of the chain kernels.  AVDSP_OPT_OVERLAP 1: the cascade of block k+1 may run under the FIR of
+ * block k (side stream, whole-CU workgroups; see launch_all in avdsp_kernels.hip) -- the caller then guarantees that
+ * a block's input is complete in memory when the call is made.  AVDSP_OPT_BQ_BLOCK 256 | 1024 and AVDSP_OPT_BQ_LDS
+ * (bytes of LDS a cascade workgroup claims so that it has its CU to itself) shape those launches.               */
+enum { AVDSP_OPT_OVERLAP = 0, AVDSP_OPT_BQ_BLOCK = 1, AVDSP_OPT_BQ_LDS = 2 };
+int avdsp_hip_prog_set_option(avdsp_hip_prog *prog, int key, int value);
+
 int avdsp_hip_synchronize(void *stream);
 const char *avdsp_hip_last_error(void);
 

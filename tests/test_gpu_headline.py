@@ -288,3 +288,32 @@ def test_world_n_ranks_hip_path_over_gloo(world, fmt, C, S, T):
         assert p.exitcode == 0
     same, cks_ok, range_ok = q.get(timeout=5)
     assert same and cks_ok and range_ok
+
+
+@pytest.mark.parametrize("fmt,C,S,T", [(6, 600, 16, 700), (6, 130, 8, 4096), (4, 70, 24, 300), (6, 40, 40, 100)])
+def test_overlap_mode_is_bit_identical(fmt, C, S, T):
+    """dspRuntimeSetOption("overlap", 1): the cascade of block k+1 runs under the FIR of block k (side stream, 1024-thread
+    workgroups that claim a CU each).  Six blocks are enqueued back to back without any host synchronisation, each with
+    buffers of its own; the result must be the oracle's, bit for bit, outputs and state -- and the same with the option off."""
+    import torch
+    B, nb = 1024, 6
+    prog = pb.synth_program(fmt, C, S, T)
+    x = pb.lcg_input(B * nb, C, fmt == 6, seed=5)
+    o = po.OracleProgram(fmt, prog)
+    want = o.run_block(x, C, C, block=B)
+    for overlap in (1, 0):
+        r = rt.Runtime(fmt, prog)
+        r.set_option("overlap", overlap)
+        assert r.get_option("overlap") == overlap
+        xd = [torch.from_numpy(x[k * B:(k + 1) * B].copy()).cuda() for k in range(nb)]
+        yd = [torch.zeros((B, C), dtype=xd[0].dtype, device="cuda") for _ in range(nb)]
+        torch.cuda.synchronize()                             # the mode's contract: inputs complete when the call is made
+        st = torch.cuda.current_stream().cuda_stream
+        for k in range(nb):
+            r.run_block_device(xd[k].data_ptr(), C, C, yd[k].data_ptr(), C, 0, B, st)
+        torch.cuda.synchronize()
+        got = np.concatenate([y.cpu().numpy() for y in yd])
+        assert (words(got) == words(want)).all(), f"overlap={overlap}"
+        assert (r.sync_state() == o.state).all()
+        r.set_option("overlap", 0)
+        r.release()
