@@ -87,7 +87,7 @@ static struct {
     int             shard_rank, shard_world;               /* dspRuntimeSetShard: this process's slice of every chain core */
     int             opt_overlap, opt_bq_block, opt_bq_lds; /* launch arrangement of the chain kernels (avdsp_hip_prog_set_option) */
     arrangement     arr[MAX_ARRANGEMENTS]; int arr_next;   /* how the cores / pieces go to the device: [0] whole program, [1..] single cores */
-} G = { .opt_fir_impl = 1, .opt_biquad_impl = 1, .opt_device = -1, .opt_interp_impl = 1, .opt_strand_split = 1, .shard_world = 1, .opt_bq_block = 1024, .opt_bq_lds = 140 * 1024 };
+} G = { .opt_fir_impl = 1, .opt_biquad_impl = 1, .opt_device = -1, .opt_interp_impl = 1, .opt_strand_split = 1, .shard_world = 1, .opt_bq_block = 512, .opt_bq_lds = 140 * 1024 };
 
 static char g_err[512];
 static int  g_err_code;

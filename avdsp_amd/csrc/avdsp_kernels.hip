@@ -64,7 +64,6 @@ int set_err(const char *fmt, ...)
 constexpr int kFirChunk   = 1024;     /* frames per launch: 4 MFMA tiles of 256 frames */
 constexpr int kTileFrames = 256;
 constexpr int kBlock      = 256;
-constexpr int kBigBlock   = 1024;
 
 /* ------------------------------------------------------------------------------------------
  * device helpers: arithmetic of the load / store stages
@@ -323,7 +322,8 @@ __global__ __launch_bounds__(BLK) void biquad_pipe(const BiquadArgs a)
     using alu_t = typename Alu<FMT>::type;
     constexpr int NB = P < 16 ? P : 16;                 /* steps per IO batch */
     constexpr int CPB = BLK / P;                        /* chains per block */
-    constexpr int DEPTH = 3;                            /* input batches in flight */
+    constexpr int DEPTH = 3;                            /* input batches in flight (the batch loop is unrolled by it) */
+    static_assert(DEPTH == 3, "kNext below is written out for three slots");
     const int tid = threadIdx.x, rowpos = tid & 15;
     const int blk = xcd_remap(blockIdx.x, a.per_xcd);
     const int slot = blk * CPB + tid / P;
@@ -353,6 +353,7 @@ __global__ __launch_bounds__(BLK) void biquad_pipe(const BiquadArgs a)
     const int ocid = owner ? a.group[oslot] : 0;
     const avdsp_chain oc = a.chains[ocid];
     const int ostep = NB - 1 - d;                       /* step of the batch whose result this lane stores */
+    [[maybe_unused]] const unsigned long long lastmask = __ballot(last);   /* lanes whose results leave the cascade */
 
     /* coefficients and the 6 state words of this (chain, section) stay in registers */
     int sw = 0;
@@ -380,13 +381,14 @@ __global__ __launch_bounds__(BLK) void biquad_pipe(const BiquadArgs a)
         }
     }
 
-    /* input batches: lane s < NB of a channel fetches frame (batch*NB + s), clamped into the block */
+    /* input batches: lane s < NB of a channel fetches frame (batch*NB + s), clamped into the block.  Every lane loads
+     * (the others a word of their channel nobody looks at): a load under a branch would hide from the compiler how many
+     * memory operations follow it, and it would then wait for ALL of them before each batch (s_waitcnt vmcnt(0)). */
     const unsigned *inp = a.io.in + (c.in_io - a.io.in_base);
-    const bool loader = have_chain && s < NB;
     auto fetch = [&](int batch) -> unsigned {
-        int n = batch * NB + s;
+        int n = batch * NB + (s & (NB - 1));
         n = n < B ? n : B - 1;
-        return loader ? inp[(size_t)n * a.io.in_stride] : 0u;
+        return inp[(size_t)n * a.io.in_stride];
     };
     unsigned rawq[DEPTH];
 #pragma unroll
@@ -394,53 +396,61 @@ __global__ __launch_bounds__(BLK) void biquad_pipe(const BiquadArgs a)
 
     Hand<FMT> hy;                                       /* this lane's latest result, offered to lane+1 */
     hy.y = y1;
+    Hand<FMT> xcur;                                     /* operand of this step, fetched during the previous one */
+    xcur.y = 0;
     unsigned ob_lo = 0, ob_hi = 0;                      /* rotating output batch (accumulator bits) */
 
-    auto step = [&](Hand<FMT> &ib, int t, auto masked) {
-        /* operand from the previous section, or the next input sample for section 0 */
-        Hand<FMT> xin;
-        xin.y = from_prev_lane<P>(ib.y, hy.y);
+    /* Step u does two things that do not depend on each other.  FETCH: take the operand of the NEXT step -- the
+     * previous section's latest result through DPP (it is the result of step u-1, i.e. of compute index u-2), or the
+     * next input sample for section 0.  COMPUTE index u-1 with the operand fetched one step ago.  So section s works
+     * on frame n = (u-1) - 2s: the hand-off skews the pipeline by TWO steps per section, not one, and its
+     * DPP move and widening conversion lie a whole step ahead of their use instead of at the head of the dependent
+     * chain -- the loop-carried chain of a step is then the five accumulations alone (it was those five plus
+     * cvt, DPP, cvt: 132 cycles per step with one wave per SIMD).  Costs nsec-1 more steps of fill per block.   */
+    auto step = [&](Hand<FMT> &ib, int u, auto masked) {
+        const Hand<FMT> ibr = hand_rotate<FMT, kRowRor15>(ib);
+        Hand<FMT> xnext;
+        xnext.y = from_prev_lane<P>(ib.y, hy.y);
         if constexpr (P != 16) {                        /* section-0 lanes that do not sit at a row start */
-            if (first) xin = ib;
+            if (first) xnext = ib;
         }
-        ib = hand_rotate<FMT, kRowRor15>(ib);
+        ib = ibr;
         ob_lo = dpp_mov<kRowRor1>(ob_lo, ob_lo);
         if constexpr (FMT == 4) ob_hi = dpp_mov<kRowRor1>(ob_hi, ob_hi);
         bool act = true;
-        if constexpr (decltype(masked)::value) { const int n = t - s; act = lane_on && n >= 0 && n < B; }
+        if constexpr (decltype(masked)::value) { const int n = u - 1 - 2 * s; act = lane_on && n >= 0 && n < B; }
         if (act) {
             if constexpr (FMT == 2) {
                 /* dsp_biquadSTD.h:37-74: five 32x32 MACs onto the previous full-precision output,
                  * saturate on the high word, keep acc, y = acc >> 28                              */
-                unsigned long long u = (unsigned long long)acc;
-                u += (unsigned long long)((long long)(int)xin.y * ci[0]);
-                u += (unsigned long long)((long long)(int)x1 * ci[1]);
-                u += (unsigned long long)((long long)(int)x2 * ci[2]);
-                u += (unsigned long long)((long long)(int)y1 * ci[3]);
-                u += (unsigned long long)((long long)(int)y2 * ci[4]);
-                acc = (long long)u;
+                unsigned long long v = (unsigned long long)acc;
+                v += (unsigned long long)((long long)(int)xcur.y * ci[0]);
+                v += (unsigned long long)((long long)(int)x1 * ci[1]);
+                v += (unsigned long long)((long long)(int)x2 * ci[2]);
+                v += (unsigned long long)((long long)(int)y1 * ci[3]);
+                v += (unsigned long long)((long long)(int)y2 * ci[4]);
+                acc = (long long)v;
                 const int hi = (int)(acc >> 32);
                 if (hi >= (1 << 27)) acc = (1ll << 59) - 1;
                 else if (hi <= 1 - (1 << 27)) acc = -(1ll << 59);
-                x2 = x1; x1 = xin.y; y2 = y1;
+                x2 = x1; x1 = xcur.y; y2 = y1;
                 y1 = (unsigned)(int)(acc >> 28);
                 hy.y = y1;
             } else {
                 /* dsp_biquadSTD.h:87-117: exact float x float products, five sequential f64 adds */
-                const double dxin = (double)__uint_as_float(xin.y);     /* flushed by the MODE like mulop's exponent-0 rule */
+                const double dxin = (double)__uint_as_float(xcur.y);    /* flushed by the MODE like mulop's exponent-0 rule */
                 acc = __builtin_fma(dxin, cd[0], acc);
                 acc = __builtin_fma(dx1, cd[1], acc);
                 acc = __builtin_fma(dx2, cd[2], acc);
                 acc = __builtin_fma(dy1, cd[3], acc);
                 acc = __builtin_fma(dy2, cd[4], acc);
                 /* (float)acc flushed like the reference's cvtsd2ss under FTZ; its product operand is then simply
-                 * the widened value (+-0.0 adds nothing, like mulop's +0.0).  NOT mirrored here: an Inf / NaN
+                 * the widened value (+-0.0 adds nothing, like mulop's +0.0).  NOT mirrored in this loop: an Inf / NaN
                  * travelling down the cascade.  The reference's bit-field product reads exponent 255 as
                  * 1.m x 2^128 (mulop); honouring that for every section input and output costs this kernel
-                 * 7 % (measured) for samples no audio stream contains.  biquad_impl 0, the FIR and the
-                 * general interpreter do mirror it.                                                       */
+                 * 7 % (measured) for samples no audio stream contains.  Such a block is caught instead: see `odd`. */
                 const float yn = narrow_f32(acc);
-                x2 = x1; x1 = xin.y; y2 = y1; y1 = __float_as_uint(yn);
+                x2 = x1; x1 = xcur.y; y2 = y1; y1 = __float_as_uint(yn);
                 dx2 = dx1; dx1 = dxin; dy2 = dy1; dy1 = (double)yn;
                 hy.y = y1;
             }
@@ -456,42 +466,88 @@ __global__ __launch_bounds__(BLK) void biquad_pipe(const BiquadArgs a)
                 else ob_lo = c.sat ? y1 : (unsigned)(unsigned long long)acc;
             }
         }
+        xcur = xnext;
     };
 
-    const int steps = B + nsec - 1;
+    const int steps = B + 2 * nsec - 1;                 /* u = 0 .. B + 2 (nsec - 1) */
     const int nbatches = (steps + NB - 1) / NB;
-    auto next_batch = [&](int b) -> Hand<FMT> {         /* batch b's samples, converted once; refill the queue */
-        Hand<FMT> h = hand_from_sample<FMT>(rawq[0], c);
+    /* The batch loop is unrolled DEPTH times so that every queue slot is a register of its own: a queue that shifts
+     * (rawq[k] = rawq[k+1]) moves registers that loads are still in flight to, which costs a wait for the YOUNGEST
+     * load at every batch -- the prefetch distance was one batch, not three, and a third of the kernel's time was
+     * s_waitcnt (profiles/r01_cfg3: SQ_WAIT_ANY 33 %). */
+    Hand<FMT> ib = hand_from_sample<FMT>(rawq[0], c);
+    rawq[0] = fetch(DEPTH);
+    for (int b0 = 0; b0 < nbatches; b0 += DEPTH) {      /* (up to DEPTH - 1 batches past the end: every step masked, nothing stored) */
 #pragma unroll
-        for (int k = 0; k + 1 < DEPTH; k++) rawq[k] = rawq[k + 1];
-        rawq[DEPTH - 1] = fetch(b + DEPTH);
-        return h;
-    };
-    Hand<FMT> ib = next_batch(0);
-    for (int b = 0; b < nbatches; b++) {
-        const int tb = b * NB;
-        if (tb >= nsec - 1 && tb + NB <= B) {           /* every lane busy for the whole batch */
+        for (int j = 0; j < DEPTH; j++) {
+            const int b = b0 + j;
+            const int tb = b * NB;
+            if (tb >= 2 * nsec - 1 && tb + NB <= B + 1) {   /* every lane busy for the whole batch */
+                if constexpr (FMT == 6 && P == 16) {
+                    /* The same thirteen instructions per step, in an order the compiler does not find: it issues the
+                     * five dependent v_fma_f64 back to back (each waits ~4 cycles for its predecessor) and the eight
+                     * independent instructions after them.  Here one of those sits behind every FMA, and the first FMA of
+                     * the NEXT step (acc + x*b0: its operand was fetched a step ago) is issued under this step's
+                     * (float)acc, so the conversions are off the chain as well.  accN = acc + x*b0 enters and leaves.  */
+                    double accN = __builtin_fma((double)__uint_as_float(xcur.y), cd[0], acc);
+                    double dxc = (double)__uint_as_float(xcur.y);
+                    unsigned xb = xcur.y, ibv = ib.y;
 #pragma unroll
-            for (int i = 0; i < NB; i++) step(ib, tb + i, std::false_type{});
-        } else {
+                    for (int i = 0; i < NB; i++) {
+                        double accQ, dyn, dxn;
+                        unsigned yb, ibr;
+                        asm volatile(
+                            "v_fma_f64 %[an], %[dx1], %[c1], %[an]\n\t"
+                            "v_mov_b32_dpp %[ibr], %[ib] row_ror:15 row_mask:0xf bank_mask:0xf\n\t"
+                            "v_fma_f64 %[an], %[dx2], %[c2], %[an]\n\t"
+                            "v_mov_b32_dpp %[ib], %[hy] row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                            "v_fma_f64 %[an], %[dy1], %[c3], %[an]\n\t"
+                            "v_mov_b32_dpp %[ob], %[ob] row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+                            "v_fma_f64 %[an], %[dy2], %[c4], %[an]\n\t"
+                            "v_cvt_f64_f32 %[dxn], %[ib]\n\t"
+                            "v_cvt_f32_f64 %[yb], %[an]\n\t"
+                            "v_fma_f64 %[aq], %[dxn], %[c0], %[an]\n\t"
+                            "v_cndmask_b32 %[ob], %[ob], %[yb], %[lm]\n\t"
+                            "v_cvt_f64_f32 %[dyn], %[yb]\n\t"
+                            : [an] "+v"(accN), [ib] "+v"(ibv), [ob] "+v"(ob_lo), [aq] "=&v"(accQ), [yb] "=&v"(yb), [dyn] "=&v"(dyn),
+                              [dxn] "=&v"(dxn), [ibr] "=&v"(ibr)
+                            : [dx1] "v"(dx1), [dx2] "v"(dx2), [dy1] "v"(dy1), [dy2] "v"(dy2), [c0] "v"(cd[0]), [c1] "v"(cd[1]),
+                              [c2] "v"(cd[2]), [c3] "v"(cd[3]), [c4] "v"(cd[4]), [hy] "v"(hy.y), [lm] "s"(lastmask));
+                        acc = accN;                      /* the finished accumulator of this step */
+                        x2 = x1; x1 = xb; y2 = y1; y1 = yb;
+                        dx2 = dx1; dx1 = dxc; dy2 = dy1; dy1 = dyn;
+                        hy.y = yb;
+                        xb = ibv; dxc = dxn;             /* operand of the next step: fetched and widened above */
+                        ibv = ibr;
+                        accN = accQ;
+                    }
+                    xcur.y = xb;
+                    ib.y = ibv;
+                } else {
 #pragma unroll
-            for (int i = 0; i < NB; i++) step(ib, tb + i, std::true_type{});
-        }
-        /* The next batch's loads were issued three batches ago: waiting for them here, BEFORE this
-         * batch's stores are issued, never waits on a fresh memory operation.                     */
-        ib = next_batch(b + 1);
-        /* flush the output batch: this lane holds the result of step tb + ostep of chain `ocid` */
-        const int n = tb + ostep - (nsec - 1);
-        if (owner && n >= 0 && n < B) {
-            if constexpr (FMT == 4) {
-                const double X = __longlong_as_double((long long)(((unsigned long long)ob_hi << 32) | ob_lo));
-                if (oc.fir_taps) *ring_at(a.ring, ocid, n) = __uint_as_float(narrow_stage<FMT>(X));
-                else emit_out(a.io, oc, n, store_stage<FMT>(X, oc.sat, a.io.store_mask));
-            } else if constexpr (FMT == 6) {
-                if (oc.fir_taps) *ring_at(a.ring, ocid, n) = __uint_as_float(ob_lo);
-                else emit_out(a.io, oc, n, oc.sat ? __float_as_uint(saturate_f32_0db(__uint_as_float(ob_lo))) : ob_lo);
-            } else
-                emit_out(a.io, oc, n, ob_lo & (unsigned)a.io.store_mask);
+                    for (int i = 0; i < NB; i++) step(ib, tb + i, std::false_type{});
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NB; i++) step(ib, tb + i, std::true_type{});
+            }
+            /* batch b+1's samples were requested DEPTH batches ago; its slot is then refilled for batch b+1+DEPTH */
+            constexpr int kNext[3] = {1 % DEPTH, 2 % DEPTH, 0};
+            ib = hand_from_sample<FMT>(rawq[kNext[j]], c);
+            rawq[kNext[j]] = fetch(b + 1 + DEPTH);
+            /* flush the output batch: this lane holds the result of step tb + ostep of chain `ocid` */
+            const int n = tb + ostep - 1 - 2 * (nsec - 1);
+            if (owner && n >= 0 && n < B) {
+                if constexpr (FMT == 4) {
+                    const double X = __longlong_as_double((long long)(((unsigned long long)ob_hi << 32) | ob_lo));
+                    if (oc.fir_taps) *ring_at(a.ring, ocid, n) = __uint_as_float(narrow_stage<FMT>(X));
+                    else emit_out(a.io, oc, n, store_stage<FMT>(X, oc.sat, a.io.store_mask));
+                } else if constexpr (FMT == 6) {
+                    if (oc.fir_taps) *ring_at(a.ring, ocid, n) = __uint_as_float(ob_lo);
+                    else emit_out(a.io, oc, n, oc.sat ? __float_as_uint(saturate_f32_0db(__uint_as_float(ob_lo))) : ob_lo);
+                } else
+                    emit_out(a.io, oc, n, ob_lo & (unsigned)a.io.store_mask);
+            }
         }
     }
 
@@ -893,7 +949,7 @@ struct avdsp_hip_prog {
     std::vector<hipEvent_t> join;
     hipEvent_t fork = nullptr;
     /* cascade of block k+1 under the FIR of block k ("overlap"): the cascades run on a stream of their own */
-    int overlap = 0, bq_block = kBigBlock, bq_lds = 140 * 1024;
+    int overlap = 0, bq_block = 512, bq_lds = 140 * 1024;
     hipStream_t s_bq = nullptr;
     hipEvent_t ev_bq[2] = {nullptr, nullptr}, ev_fir[2] = {nullptr, nullptr};
     bool ev_fir_set[2] = {false, false};
@@ -964,16 +1020,22 @@ struct ProfileScope {                   /* records an event pair around the laun
 
 /* the 1024-thread form of the cascade and the LDS it claims (bytes) when it runs under a FIR; opted in per function
  * at plan creation (nothing in the launch path may touch function attributes) */
-template <int FMT>
-const void *biquad_big_fn(int P)
+/* the cascade in workgroups of 256, 512 or 1024 threads */
+template <int FMT, int BLK>
+const void *biquad_fn(int P)
 {
     switch (P) {
-    case 8:  return (const void *)biquad_pipe<FMT, 8, kBigBlock>;
-    case 16: return (const void *)biquad_pipe<FMT, 16, kBigBlock>;
-    case 32: return (const void *)biquad_pipe<FMT, 32, kBigBlock>;
-    case 64: return (const void *)biquad_pipe<FMT, 64, kBigBlock>;
+    case 8:  return (const void *)biquad_pipe<FMT, 8, BLK>;
+    case 16: return (const void *)biquad_pipe<FMT, 16, BLK>;
+    case 32: return (const void *)biquad_pipe<FMT, 32, BLK>;
+    case 64: return (const void *)biquad_pipe<FMT, 64, BLK>;
     }
     return nullptr;
+}
+template <int FMT>
+const void *biquad_big_fn(int P, int blk)
+{
+    return blk == 1024 ? biquad_fn<FMT, 1024>(P) : blk == 512 ? biquad_fn<FMT, 512>(P) : biquad_fn<FMT, kBlock>(P);
 }
 
 template <int FMT>
@@ -986,18 +1048,15 @@ int launch_biquad(avdsp_hip_prog *prog, Plan &pl, const Plan::Group &g, const in
     a.group = ids; a.ngroup = n; a.nsec = g.nsec; a.ring = plan_ring(pl); a.io = io;
     if (biquad_impl == 0 || g.P > 64) {
         hipLaunchKernelGGL(biquad_simple<FMT>, dim3((n + 63) / 64), dim3(64), 0, stream, a);
-    } else if (under_fir && prog->bq_block == kBigBlock && biquad_big_fn<FMT>(g.P)) {
-        const int cpb = kBigBlock / g.P;
+    } else if (under_fir && biquad_big_fn<FMT>(g.P, prog->bq_block)) {
+        /* under the previous block's FIR: workgroups of bq_block threads that claim bq_lds bytes of LDS (unused), so
+         * that no FIR workgroup shares their CU */
+        const int blk = prog->bq_block;
+        const int cpb = blk / g.P;
         const int nblk = (n + cpb - 1) / cpb;
         a.per_xcd = (nblk + 7) / 8;
-        const dim3 grid(a.per_xcd * 8), block(kBigBlock);
-        const size_t lds = (size_t)prog->bq_lds;
-        switch (g.P) {
-        case 8:  hipLaunchKernelGGL((biquad_pipe<FMT, 8, kBigBlock>),  grid, block, lds, stream, a); break;
-        case 16: hipLaunchKernelGGL((biquad_pipe<FMT, 16, kBigBlock>), grid, block, lds, stream, a); break;
-        case 32: hipLaunchKernelGGL((biquad_pipe<FMT, 32, kBigBlock>), grid, block, lds, stream, a); break;
-        default: hipLaunchKernelGGL((biquad_pipe<FMT, 64, kBigBlock>), grid, block, lds, stream, a); break;
-        }
+        void *kargs[] = {(void *)&a};
+        HIP_TRY(hipLaunchKernel(biquad_big_fn<FMT>(g.P, blk), dim3(a.per_xcd * 8), dim3(blk), kargs, (size_t)prog->bq_lds, stream));
     } else {
         const int cpb = kBlock / g.P;
         const int nblk = (n + cpb - 1) / cpb;
@@ -1225,10 +1284,12 @@ int avdsp_hip_prog_add_plan(avdsp_hip_prog *prog, const avdsp_plan_desc *d)
         if (chains[i].nsec && !chains[i].fir_taps) pl.overlap_ok = false;
     if (pl.overlap_ok)
         for (auto &g : pl.bq) {
-            const void *fn = d->format == 4 ? biquad_big_fn<4>(g.P) : biquad_big_fn<6>(g.P);
-            if (!fn) continue;
-            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) { free_plan(pl); return set_err("hipFuncSetAttribute(cascade LDS claim): %s", hipGetErrorString(e)); }
+            for (int blk : {256, 512, 1024}) {
+                const void *fn = d->format == 4 ? biquad_big_fn<4>(g.P, blk) : biquad_big_fn<6>(g.P, blk);
+                if (!fn) continue;
+                hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) { free_plan(pl); return set_err("hipFuncSetAttribute(cascade LDS claim): %s", hipGetErrorString(e)); }
+            }
         }
     prog->plans.push_back(pl);
     return (int)prog->plans.size() - 1;
@@ -1784,7 +1845,7 @@ int avdsp_hip_prog_set_option(avdsp_hip_prog *prog, int key, int value)
     HIP_TRY(hipDeviceSynchronize());                    /* nothing in flight when the launch arrangement changes */
     switch (key) {
     case AVDSP_OPT_OVERLAP:  prog->overlap = value != 0; prog->ev_fir_set[0] = prog->ev_fir_set[1] = false; return 0;
-    case AVDSP_OPT_BQ_BLOCK: if (value != kBlock && value != kBigBlock) return set_err("cascade workgroups have %d or %d threads", kBlock, kBigBlock);
+    case AVDSP_OPT_BQ_BLOCK: if (value != 256 && value != 512 && value != 1024) return set_err("cascade workgroups have 256, 512 or 1024 threads");
                              prog->bq_block = value; return 0;
     case AVDSP_OPT_BQ_LDS:   if (value < 0 || value > 160 * 1024) return set_err("LDS claim %d outside [0, 160 KiB]", value);
                              prog->bq_lds = value; return 0;

@@ -184,6 +184,8 @@ def main():
     ap.add_argument("--fir-impl", type=int, default=1)
     ap.add_argument("--biquad-impl", type=int, default=1)
     ap.add_argument("--overlap", type=int, default=-1, help="cascade of the next block under the FIR of this one: 0 off, 1 on, -1 library default")
+    ap.add_argument("--bq-block", type=int, default=-1, help="threads per cascade workgroup under overlap (256 | 1024)")
+    ap.add_argument("--bq-lds", type=int, default=-1, help="bytes of LDS a cascade workgroup claims under overlap")
     ap.add_argument("--shard", default=None, help="RANK/WORLD: run that one shard of the program on this GPU alone (what one rank of a WORLD-GPU job does)")
     ap.add_argument("--host-buffers", action="store_true", help="also time dspRuntimeBlock_N with HOST buffers (PCIe inclusive), reported beside value")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -230,6 +232,10 @@ def main():
     r.set_option("biquad_impl", args.biquad_impl)
     if args.overlap >= 0:
         r.set_option("overlap", args.overlap)
+    if args.bq_block >= 0:
+        r.set_option("bq_block", args.bq_block)
+    if args.bq_lds >= 0:
+        r.set_option("bq_lds", args.bq_lds)
     r.set_option("profile", 1)
     r.set_shard(shard_rank, shard_world)
     info = r.shard_info()
