@@ -798,6 +798,206 @@ __global__ __launch_bounds__(kBlock, NG == 1 ? 5 : 4) void fir_mfma(const FirArg
     }
 }
 
+
+/* ------------------------------------------------------------------------------------------
+ * fir_tile<FMT, R>: the FIR contraction with one WAVE per (channel, tile of 256 R frames) and nothing shared
+ * between waves -- no workgroup barrier anywhere in the tap loop.
+ *
+ *   y[F0 + 16R a + 16r + i] = sum_m A_r[i][m] * Bm[m][a],   A_r[i][m] = h[m + 16r + i],   Bm[m][a] = x[F0 + 16R a - m]
+ *   r = 0 .. R-1 (row tiles, one accumulator each), i = 0 .. 15, a = 0 .. 15, m = -16R .. T-1 in k-steps of 4, ascending
+ *   = the reference's tap order (dsp_firSTD.h:45-50): every accumulator is the reference's sequential sum, bit for bit.
+ *
+ * The row tiles share the window operand Bm, and A_r at step m is A_0 at step m + 16 r: each taps operand that is read
+ * from LDS serves R MFMAs, 4 k-steps apart, out of a register queue.  One ds_read_b64 of taps and one of the window
+ * per k-step feed R MFMAs (fir_mfma reads two per MFMA), and every address inside an unrolled group of 16 k-steps is
+ * the lane's base plus an immediate.
+ *
+ * Operands: the taps are converted to double ONCE, when the plan is made (avdsp_hip_prog_add_plan: Hbuf[j] =
+ * mulop(h[j - 64]), zero padded on both sides), so staging them is a copy.  The window comes from the chain's float ring
+ * and is converted while it is staged, 15 R*16 + 4 CK frames per chunk of CK k-steps, into a transposed image
+ * pos(u) = (u mod 16R) * row + u / 16R: the 16 lanes of one k read 16 consecutive doubles.
+ * ---------------------------------------------------------------------------------------- */
+constexpr int kTapsLead = 64;                /* zeros in front of a chain's taps in the f64 copy */
+constexpr int kTapsTail = 384;               /* zeros behind them (the last k-steps and the operand prefetch read on) */
+__host__ __device__ inline int taps64_pitch(int max_taps) { return (kTapsLead + max_taps + kTapsTail + 1) & ~1; }
+
+template <int R> struct TileGeom {
+    static constexpr int NR = 16 * R;                        /* rows of the output tile: frames per column step */
+    static constexpr int FW = 256 * R;                       /* frames per wave */
+    static constexpr int WPC = 4 / R;                        /* waves per channel and launch */
+    static constexpr int QD = 4 * (R - 1);                   /* k-steps a taps operand waits for its last use */
+    static constexpr int CKMAX = R == 4 ? 160 : R == 2 ? 208 : 256;          /* k-steps per chunk, multiple of 16 */
+    static constexpr int ROW = R == 4 ? 27 : R == 2 ? 43 : 81;               /* doubles per window row, odd: >= 16 + ceil(4 (CKMAX-1) / NR) */
+    static constexpr int HLEN = 4 * CKMAX + 16 * (R - 1) + 28;               /* doubles of the taps image (even) */
+    static constexpr int WLEN = NR * ROW + (NR * ROW & 1);
+    static constexpr int LDS_DOUBLES = HLEN + WLEN;          /* per wave */
+    static constexpr int NW = (NR * ROW + 63) / 64;          /* window elements a lane stages per chunk */
+};
+static_assert(TileGeom<4>::ROW >= 16 + (4 * (TileGeom<4>::CKMAX - 1) + 63) / 64 && TileGeom<2>::ROW >= 16 + (4 * (TileGeom<2>::CKMAX - 1) + 31) / 32 &&
+              TileGeom<1>::ROW >= 16 + (4 * (TileGeom<1>::CKMAX - 1) + 15) / 16, "window rows hold a chunk");
+
+struct FirTileArgs {
+    int *buf; const avdsp_chain *chains; const int *group; int ngroup; Ring ring; int per_xcd;
+    const double *taps64; int pitch64;       /* f64 copy of the taps, [chain id][pitch64] */
+    BlockIO io;
+};
+
+/* one taps double per lane and k-step, the window double of lane (a, k) likewise; offsets inside a group of 16 k-steps */
+template <int R> __device__ __forceinline__ constexpr int win_off(int j)
+{
+    constexpr int NR = 16 * R;
+    /* row part ((-4 j) mod NR) * ROW, entry part -(ceil(4 j / NR)), shifted so that the smallest offset of a group is 0 */
+    return ((NR - (4 * j) % NR) % NR) * TileGeom<R>::ROW - (4 * j + NR - 1) / NR + (64 / NR - 1);
+}
+
+template <int FMT, int R>
+__global__ __launch_bounds__(kBlock, 2) void fir_tile(const FirTileArgs a)
+{
+    using G = TileGeom<R>;
+    constexpr int NR = G::NR;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int B = a.io.nframes;
+    const int blk = xcd_remap(blockIdx.x, a.per_xcd);
+    /* FIR-only chains: the FIR's input is (float)X of the load stage; the workgroup's chains get theirs appended first
+     * (the waves of one chain sit in one workgroup) */
+    {
+        FirArgs fa{};
+        fa.ring = a.ring; fa.io = a.io;
+        for (int q = 0; q < 4 / G::WPC; q++) {
+            const int sl = blk * (4 / G::WPC) + q;
+            if (sl < a.ngroup) {
+                const int ci = a.group[sl];
+                const avdsp_chain cc = a.chains[ci];
+                if (cc.nsec == 0) fir_append_input<FMT>(fa, cc, ci);
+            }
+        }
+        __syncthreads();
+    }
+    const int unit = blk * 4 + wv;
+    const int slot = unit / G::WPC, F0 = (unit % G::WPC) * G::FW;
+    if (slot >= a.ngroup || F0 >= B) return;                /* from here on a wave is on its own: no barrier below */
+    const int cid = a.group[slot];
+    const avdsp_chain c = a.chains[cid];
+    const int T = c.fir_taps;
+    double *hs = lds + (size_t)wv * G::LDS_DOUBLES, *ws = hs + G::HLEN;
+    const double *hbuf = a.taps64 + (size_t)cid * a.pitch64;
+    const float *ringrow = a.ring.base + (size_t)cid * a.ring.R;
+    const int rmask = a.ring.R - 1;
+
+    const int i16 = lane & 15, k = lane >> 4;
+    /* k-steps: m_s = -NR + 4 s, s = 0 .. S-1, S a multiple of 16; chunks of ck <= CKMAX of them */
+    const int S = (((T + NR + 3) >> 2) + 15) & ~15;
+    const int nch = (S + G::CKMAX - 1) / G::CKMAX;
+    const int ck = (((S + nch - 1) / nch) + 15) & ~15;
+
+    v4f64 acc[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = v4f64{0.0, 0.0, 0.0, 0.0};
+
+    /* window element e = lane + 64 t of a chunk's image: row e % NR, entry e / NR */
+    const int wrow = lane % NR, went = lane / NR;
+    float wreg[G::NW];
+    auto win_fetch = [&](int s0, int ckc) {
+        const int JT = (4 * (ckc - 1) + NR - 1) / NR;
+        /* frame of (row, entry): F0 - 3 + NR (entry + 1 - 4 s0 / NR - JT) + row */
+        const int f0 = F0 - 3 + NR * (went + 1 - 4 * s0 / NR - JT) + wrow;
+#pragma unroll
+        for (int t = 0; t < G::NW; t++) wreg[t] = ringrow[(a.ring.wpos + f0 + 64 * t) & rmask];
+    };
+    auto win_store = [&]() {
+        double *wp = ws + wrow * G::ROW + went;
+#pragma unroll
+        for (int t = 0; t < G::NW; t++) {
+            if (t * 64 + 63 < NR * G::ROW || lane + t * 64 < NR * G::ROW) {
+                const float v = wreg[t];
+                double d = (double)v;
+                if (__builtin_amdgcn_classf(v, 0x297)) d = mulop(v);      /* NaN, Inf, subnormal: the reference's bit-field operand */
+                wp[t * (64 / NR)] = d;
+            }
+        }
+    };
+    auto taps_stage = [&](int s0, int ckc) {
+        /* image u = 0 .. 4 ckc + 16 (R-1) + 27 <- Hbuf[48 - 16 (R-1) + 4 s0 + u]: 16-byte pieces, 64 lanes */
+        const double *src = hbuf + (kTapsLead - 16) - 16 * (R - 1) + 4 * s0;
+        const int np = (4 * ckc + 16 * (R - 1) + 28) / 2;
+        constexpr int NP = (G::HLEN / 2 + 63) / 64;
+        double2 piece[NP];
+#pragma unroll
+        for (int t = 0; t < NP; t++) {
+            const int pi = lane + 64 * t;
+            piece[t] = pi < np ? reinterpret_cast<const double2 *>(src)[pi] : double2{0.0, 0.0};
+        }
+#pragma unroll
+        for (int t = 0; t < NP; t++) {
+            const int pi = lane + 64 * t;
+            if (pi < np) reinterpret_cast<double2 *>(hs)[pi] = piece[t];
+        }
+    };
+
+    win_fetch(0, min(ck, S));
+    for (int s0 = 0; s0 < S; s0 += ck) {
+        const int ckc = min(ck, S - s0);
+        const int JT = (4 * (ckc - 1) + NR - 1) / NR;
+        __builtin_amdgcn_wave_barrier();
+        win_store();
+        taps_stage(s0, ckc);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (s0 + ckc < S) win_fetch(s0 + ckc, min(ck, S - s0 - ckc));
+
+        /* lane bases: taps u = (k + i) + 16 (R-1) + 4 sc; window row (3 - k) + ..., entry a + JT - ... (win_off) */
+        const double *hp = hs + k + i16;                                       /* oldest operand of step sc at hp[4 sc] */
+        const double *wp = ws + (3 - k) * G::ROW + i16 + JT - (64 / NR - 1);   /* group g: wp - g * (64 / NR) + win_off(j) */
+        double q[16], bq[4];
+        /* the queue as the chunk's first step finds it, and the operands of its first two steps */
+#pragma unroll
+        for (int j = 0; j < G::QD; j++) q[(16 - G::QD + j) & 15] = hp[4 * j];
+        q[0] = hp[16 * (R - 1)]; q[1] = hp[16 * (R - 1) + 4];
+        bq[0] = wp[win_off<R>(0)]; bq[1] = wp[win_off<R>(1)];
+        for (int g = 0; g < ckc / 16; g++) {
+            const double *hg = hp + 16 * (R - 1) + 64 * g, *wg = wp - g * (64 / NR);
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                /* operands of step j + 2 (of the next group for j = 14, 15: the same code, offsets continue) */
+                q[(j + 2) & 15] = hg[4 * (j + 2)];
+                bq[(j + 2) & 3] = j + 2 < 16 ? wg[win_off<R>((j + 2) & 15)] : (wg - 64 / NR)[win_off<R>((j + 2) & 15)];
+                __builtin_amdgcn_sched_barrier(0);          /* the reads stay two steps ahead of their MFMAs */
+#pragma unroll
+                for (int r = 0; r < R; r++)
+                    acc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(q[(j - 4 * (R - 1 - r)) & 15], bq[j & 3], acc[r], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    /* C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg */
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const int n = F0 + NR * i16 + 16 * r + 4 * v + k;
+            if (n < B) {
+                unsigned word = store_stage<FMT>(acc[r][v], c.sat, a.io.store_mask);
+                if constexpr (FMT == 6) word = ftz_bits(word);      /* default MODE here: flush the float by hand */
+                emit_out(a.io, c, n, word);
+            }
+        }
+}
+
+/* the f64 copy of a chain's taps, made once per plan: Hbuf[j] = mulop(h[j - kTapsLead]), zeros around */
+struct Taps64Args { const int *buf; const avdsp_chain *chains; const int *group; double *taps64; int pitch64; };
+__global__ __launch_bounds__(kBlock) void taps_to_f64(const Taps64Args a)
+{
+    const int cid = a.group[blockIdx.x];
+    const avdsp_chain c = a.chains[cid];
+    const float *taps = reinterpret_cast<const float *>(a.buf + c.fir_coef_word);
+    double *dst = a.taps64 + (size_t)cid * a.pitch64;
+    for (int j = threadIdx.x; j < a.pitch64; j += blockDim.x) {
+        const int t = j - kTapsLead;
+        dst[j] = (t >= 0 && t < c.fir_taps) ? mulop(taps[t]) : 0.0;
+    }
+}
+
 /* cross-check path: one thread per output frame, the reference's loop verbatim (ascending taps),
  * operands straight from the ring and the program words (L1/L2)                                */
 template <int FMT>
@@ -921,6 +1121,7 @@ struct Plan {
     int io_in_min = 0, io_in_max = -1, io_out_min = 0, io_out_max = -1;
     bool wave_ok = false; unsigned carried_io[8] = {0, 0, 0, 0, 0, 0, 0, 0};      /* frame-parallel interpreter */
     int *d_own = nullptr;                                /* owned mirror ranges (pairs), generic plans */
+    double *d_taps64 = nullptr; int pitch64 = 0;         /* fir_tile: the taps as doubles, [chain][pitch64] */
     bool overlap_ok = false;                             /* every cascade of the plan feeds a FIR: its launches may run under the previous block's FIR */
 };
 
@@ -950,6 +1151,7 @@ struct avdsp_hip_prog {
     hipEvent_t fork = nullptr;
     /* cascade of block k+1 under the FIR of block k ("overlap"): the cascades run on a stream of their own */
     int overlap = 0, bq_block = 512, bq_lds = 140 * 1024;
+    int fir_rows = 0;                    /* fir_tile: row tiles per wave (1, 2, 4), 0 = by the number of chains */
     hipStream_t s_bq = nullptr;
     hipEvent_t ev_bq[2] = {nullptr, nullptr}, ev_fir[2] = {nullptr, nullptr};
     bool ev_fir_set[2] = {false, false};
@@ -974,7 +1176,7 @@ void free_plan(Plan &p)
 {
     (void)hipFree(p.d_chains); (void)hipFree(p.d_sec_coef); (void)hipFree(p.d_sec_state);
     for (auto &g : p.bq) (void)hipFree(g.d_ids);
-    (void)hipFree(p.d_fir_ids); (void)hipFree(p.d_pass_ids); (void)hipFree(p.d_ring); (void)hipFree(p.d_own);
+    (void)hipFree(p.d_fir_ids); (void)hipFree(p.d_pass_ids); (void)hipFree(p.d_ring); (void)hipFree(p.d_own); (void)hipFree(p.d_taps64);
 }
 
 int fir_groups_per_chunk(int max_taps)
@@ -1076,12 +1278,36 @@ int launch_biquad(avdsp_hip_prog *prog, Plan &pl, const Plan::Group &g, const in
     return 0;
 }
 
+template <int FMT, int R>
+int launch_fir_tile(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, BlockIO io, hipStream_t stream)
+{
+    (void)prog;
+    FirTileArgs a{};
+    a.buf = prog->d_buf; a.chains = pl.d_chains; a.group = ids; a.ngroup = n;
+    a.ring = plan_ring(pl); a.io = io; a.taps64 = pl.d_taps64; a.pitch64 = pl.pitch64;
+    const int nwg = (n * TileGeom<R>::WPC + 3) / 4;
+    a.per_xcd = (nwg + 7) / 8;
+    const size_t lds = (size_t)4 * TileGeom<R>::LDS_DOUBLES * sizeof(double);
+    hipLaunchKernelGGL((fir_tile<FMT, R>), dim3(a.per_xcd * 8), dim3(kBlock), lds, stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+/* fir_impl: 0 = fir_plain (the reference's loop), 1 = fir_tile (default), 2 = fir_mfma (round 1's workgroup-per-channel kernel) */
 template <int FMT>
 int launch_fir(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, BlockIO io, int fir_impl, hipStream_t stream)
 {
     if constexpr (FMT == 2) { (void)prog; (void)pl; (void)ids; (void)n; (void)io; (void)fir_impl; (void)stream; return 0; }
     else {
         ProfileScope scope(prog, stream, AVDSP_KERNEL_FIR);
+        if (fir_impl == 1) {
+            /* row tiles per wave: as many as leave the chip two waves per SIMD (2048) -- a bigger tile reads fewer operands per MFMA */
+            int rows = prog->fir_rows;
+            if (rows != 1 && rows != 2 && rows != 4) rows = n >= 2048 ? 4 : n >= 1024 ? 2 : 1;
+            return rows == 4 ? launch_fir_tile<FMT, 4>(prog, pl, ids, n, io, stream)
+                 : rows == 2 ? launch_fir_tile<FMT, 2>(prog, pl, ids, n, io, stream)
+                             : launch_fir_tile<FMT, 1>(prog, pl, ids, n, io, stream);
+        }
         FirArgs a{};
         a.buf = prog->d_buf; a.chains = pl.d_chains; a.group = ids; a.ngroup = n;
         a.ring = plan_ring(pl); a.io = io;
@@ -1275,6 +1501,22 @@ int avdsp_hip_prog_add_plan(avdsp_hip_prog *prog, const avdsp_plan_desc *d)
         hipError_t e = hipMalloc((void **)&pl.d_ring, (size_t)d->nchains * pl.ring_R * sizeof(float));
         if (e != hipSuccess) { free_plan(pl); return set_err("hipMalloc(FIR rings, %d x %d): %s", d->nchains, pl.ring_R, hipGetErrorString(e)); }
         pl.wpos = 0;
+        {   /* fir_tile: LDS opt-in per variant, and the taps as doubles */
+            const void *tiles[3] = { d->format == 4 ? (const void *)fir_tile<4, 1> : (const void *)fir_tile<6, 1>,
+                                     d->format == 4 ? (const void *)fir_tile<4, 2> : (const void *)fir_tile<6, 2>,
+                                     d->format == 4 ? (const void *)fir_tile<4, 4> : (const void *)fir_tile<6, 4> };
+            const int tlds[3] = { 4 * TileGeom<1>::LDS_DOUBLES * 8, 4 * TileGeom<2>::LDS_DOUBLES * 8, 4 * TileGeom<4>::LDS_DOUBLES * 8 };
+            for (int v = 0; v < 3; v++) {
+                hipError_t e2 = hipFuncSetAttribute(tiles[v], hipFuncAttributeMaxDynamicSharedMemorySize, tlds[v]);
+                if (e2 != hipSuccess) { free_plan(pl); return set_err("hipFuncSetAttribute(fir_tile LDS %d): %s", tlds[v], hipGetErrorString(e2)); }
+            }
+            pl.pitch64 = taps64_pitch(pl.max_taps);
+            hipError_t e2 = hipMalloc((void **)&pl.d_taps64, (size_t)d->nchains * pl.pitch64 * sizeof(double));
+            if (e2 != hipSuccess) { free_plan(pl); return set_err("hipMalloc(f64 taps, %d x %d): %s", d->nchains, pl.pitch64, hipGetErrorString(e2)); }
+            Taps64Args ta{prog->d_buf, pl.d_chains, pl.d_fir_ids, pl.d_taps64, pl.pitch64};
+            hipLaunchKernelGGL(taps_to_f64, dim3(pl.n_fir), dim3(kBlock), 0, nullptr, ta);
+            if (hipGetLastError() != hipSuccess) { free_plan(pl); return set_err("taps_to_f64 failed to launch"); }
+        }
         RingConvArgs ca{prog->d_buf, pl.d_chains, pl.d_fir_ids, pl.n_fir, plan_ring(pl)};
         hipLaunchKernelGGL(state_to_ring, dim3(pl.n_fir), dim3(kBlock), 0, nullptr, ca);   /* history the caller's buffer holds */
         if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) { free_plan(pl); return set_err("state_to_ring failed"); }
@@ -1847,6 +2089,8 @@ int avdsp_hip_prog_set_option(avdsp_hip_prog *prog, int key, int value)
     case AVDSP_OPT_OVERLAP:  prog->overlap = value != 0; prog->ev_fir_set[0] = prog->ev_fir_set[1] = false; return 0;
     case AVDSP_OPT_BQ_BLOCK: if (value != 256 && value != 512 && value != 1024) return set_err("cascade workgroups have 256, 512 or 1024 threads");
                              prog->bq_block = value; return 0;
+    case AVDSP_OPT_FIR_ROWS: if (value != 0 && value != 1 && value != 2 && value != 4) return set_err("fir_tile row tiles: 0 (auto), 1, 2 or 4");
+                             prog->fir_rows = value; return 0;
     case AVDSP_OPT_BQ_LDS:   if (value < 0 || value > 160 * 1024) return set_err("LDS claim %d outside [0, 160 KiB]", value);
                              prog->bq_lds = value; return 0;
     }

@@ -159,7 +159,7 @@ int avdsp_hip_profile_read(avdsp_hip_prog *prog, int kind, double *total_ms, int
  * block k (side stream, whole-CU workgroups; see launch_all in avdsp_kernels.hip) -- the caller then guarantees that
  * a block's input is complete in memory when the call is made.  AVDSP_OPT_BQ_BLOCK 256 | 1024 and AVDSP_OPT_BQ_LDS
  * (bytes of LDS a cascade workgroup claims so that it has its CU to itself) shape those launches.               */
-enum { AVDSP_OPT_OVERLAP = 0, AVDSP_OPT_BQ_BLOCK = 1, AVDSP_OPT_BQ_LDS = 2 };
+enum { AVDSP_OPT_OVERLAP = 0, AVDSP_OPT_BQ_BLOCK = 1, AVDSP_OPT_BQ_LDS = 2, AVDSP_OPT_FIR_ROWS = 3 };   /* FIR_ROWS: row tiles per wave of fir_tile, 0 = auto */
 int avdsp_hip_prog_set_option(avdsp_hip_prog *prog, int key, int value);
 
 int avdsp_hip_synchronize(void *stream);

@@ -1,0 +1,92 @@
+"""fir_tile<FMT, R> (one wave per channel tile of 256 R frames, R row tiles sharing each taps operand; no workgroup barrier in
+the tap loop) against the oracle, bit for bit, for every R, and against round 1's fir_mfma and the plain tap loop.  Tap counts
+around the kernel's seams (k-steps of 4, unrolled groups of 16 k-steps, chunks of 160 / 208 / 256 k-steps), ragged blocks,
+FIR-only chains (the kernel appends their input itself) and chains behind a cascade, both float models."""
+import numpy as np
+import pytest
+
+from avdsp_amd import progbuilder as pb
+from avdsp_amd import runtime as rt
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _release():
+    yield
+    rt.lib().dspRuntimeSetOption(b"fir_rows", 0)
+    rt.lib().dspRuntimeRelease()
+
+
+def words(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def run_vs_oracle(fmt, prog, x, C, blocks, rows, fir_impl=1):
+    o = po.OracleProgram(fmt, prog)
+    r = rt.Runtime(fmt, prog)
+    r.set_option("fir_impl", fir_impl)
+    r.set_option("fir_rows", rows)
+    pos = 0
+    for b in blocks:
+        want = o.run_block(x[pos:pos + b], C, C)
+        got = r.run_block(x[pos:pos + b], C, C)
+        bad = np.nonzero((words(got) != words(want)).any(axis=0))[0]
+        assert bad.size == 0, f"rows {rows}: block at frame {pos} ({b} frames): channels {bad[:8].tolist()} differ, first frame " \
+                              f"{int(np.argmax((words(got) != words(want)).any(axis=1)))}"
+        pos += b
+    assert (r.sync_state() == o.state).all(), "state differs after the last block"
+    r.set_option("fir_impl", 1)
+
+
+@pytest.mark.parametrize("rows", [1, 2, 4])
+@pytest.mark.parametrize("taps", [1, 3, 4, 7, 60, 61, 64, 65, 255, 256, 257, 580, 641, 1000, 1030])
+def test_fir_only_chains_every_row_count(rows, taps):
+    C = 5
+    prog = pb.synth_program(6, C, 0, taps)
+    blocks = [1024, 1, 37, 256, 257, 700, 1024, 513]
+    x = pb.lcg_input(sum(blocks), C, True, seed=taps)
+    run_vs_oracle(6, prog, x, C, blocks, rows)
+
+
+@pytest.mark.parametrize("rows", [1, 2, 4])
+@pytest.mark.parametrize("fmt,C,S,T", [(6, 9, 3, 2048), (6, 3, 16, 4096), (4, 6, 2, 4100), (6, 2, 1, 5000), (4, 4, 0, 2560), (6, 21, 5, 130)])
+def test_long_fir_behind_a_cascade(rows, fmt, C, S, T):
+    prog = pb.synth_program(fmt, C, S, T)
+    blocks = [1024, 1024, 300, 1024, 1024, 1024, 724]
+    x = pb.lcg_input(sum(blocks), C, fmt == 6, seed=C + T)
+    run_vs_oracle(fmt, prog, x, C, blocks, rows)
+
+
+@pytest.mark.parametrize("rows", [0, 1, 2, 4])
+def test_many_channels_auto_rows_and_other_kernels_agree(rows):
+    """enough chains for every automatic choice (>= 2048: 4 row tiles), short taps so that the oracle keeps up; the same blocks
+    through fir_mfma (fir_impl 2) and the plain tap loop (fir_impl 0) must give the same bits"""
+    C, T = 2100, 70
+    taps = pb.lcg_taps_all(C, T)
+    prog = pb.synth_program(6, C, 0, T, taps=taps)
+    x = pb.lcg_input(1024 + 500, C, True, seed=3)
+    o = po.OracleProgram(6, prog)
+    want = np.concatenate([o.run_block(x[:1024], C, C), o.run_block(x[1024:], C, C)])
+    for impl in ((1, 2, 0) if rows == 0 else (1,)):
+        r = rt.Runtime(6, prog)
+        r.set_option("fir_impl", impl)
+        r.set_option("fir_rows", rows)
+        got = np.concatenate([r.run_block(x[:1024], C, C), r.run_block(x[1024:], C, C)])
+        assert (words(got) == words(want)).all(), f"fir_impl {impl}"
+        assert (r.sync_state() == o.state).all()
+        r.set_option("fir_impl", 1)
+        r.release()
+
+
+def test_nan_inf_and_subnormal_samples_in_the_window():
+    """the window is converted while it is staged: exponent 255 reads as 1.m x 2^128 and subnormals as zero, like the reference's
+    bit-field product (dsp_ieee754.h:377-410)"""
+    C, T = 3, 300
+    prog = pb.synth_program(6, C, 0, T)
+    x = pb.lcg_input(2048, C, True, seed=11)
+    xi = x.view(np.uint32)
+    xi[5, 0] = 0x7F800000; xi[9, 1] = 0xFFC00001; xi[700, 2] = 0x7F812345; xi[1030, 0] = 0x00000012; xi[1500, 1] = 0x80000400
+    for rows in (1, 2, 4):
+        run_vs_oracle(6, prog, x, C, [1024, 1024], rows)
