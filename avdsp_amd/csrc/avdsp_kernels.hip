@@ -712,6 +712,7 @@ __device__ __forceinline__ void fir_chunk_to_lds(const FirArgs &a, const ChunkRe
 }
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
+typedef double v2f64 __attribute__((ext_vector_type(2)));
 
 /* FIR as a dense contraction on v_mfma_f64_16x16x4_f64.
  *   Y[i][a] = y[16a + i] = sum_m A[i][m] * Bm[m][a],   A[i][m] = h[m + i],   Bm[m][a] = x[16a - m],
@@ -905,8 +906,8 @@ __global__ __launch_bounds__(kBlock, 2) void fir_tile(const FirTileArgs a)
 #pragma unroll
         for (int t = 0; t < G::NW; t++) wreg[t] = ringrow[(a.ring.wpos + f0 + 64 * t) & rmask];
     };
-    auto win_store = [&]() {
-        double *wp = ws + wrow * G::ROW + went;
+    auto win_store = [&](double *wdst) {
+        double *wp = wdst + wrow * G::ROW + went;
 #pragma unroll
         for (int t = 0; t < G::NW; t++) {
             if (t * 64 + 63 < NR * G::ROW || lane + t * 64 < NR * G::ROW) {
@@ -917,58 +918,74 @@ __global__ __launch_bounds__(kBlock, 2) void fir_tile(const FirTileArgs a)
             }
         }
     };
-    auto taps_stage = [&](int s0, int ckc) {
+    auto taps_stage = [&](double *hdst, int s0, int ckc) {
         /* image u = 0 .. 4 ckc + 16 (R-1) + 27 <- Hbuf[48 - 16 (R-1) + 4 s0 + u]: 16-byte pieces, 64 lanes */
         const double *src = hbuf + (kTapsLead - 16) - 16 * (R - 1) + 4 * s0;
         const int np = (4 * ckc + 16 * (R - 1) + 28) / 2;
         constexpr int NP = (G::HLEN / 2 + 63) / 64;
-        double2 piece[NP];
+        v2f64 piece[NP];
 #pragma unroll
         for (int t = 0; t < NP; t++) {
             const int pi = lane + 64 * t;
-            piece[t] = pi < np ? reinterpret_cast<const double2 *>(src)[pi] : double2{0.0, 0.0};
+            piece[t] = pi < np ? reinterpret_cast<const v2f64 *>(src)[pi] : v2f64{0.0, 0.0};
         }
 #pragma unroll
         for (int t = 0; t < NP; t++) {
             const int pi = lane + 64 * t;
-            if (pi < np) reinterpret_cast<double2 *>(hs)[pi] = piece[t];
+            if (pi < np) reinterpret_cast<v2f64 *>(hdst)[pi] = piece[t];
         }
     };
 
+    double q[16], bq[4];
+    /* the queue as a chunk's first step finds it, and the operands of its first two steps
+     * lane bases: taps u = (k + i) + 16 (R-1) + 4 sc; window row (3 - k) + ..., entry a + JT - ... (win_off) */
+    auto chunk_begin = [&](const double *hp, const double *wp) {
+#pragma unroll
+        for (int j = 0; j < G::QD; j++) q[(16 - G::QD + j) & 15] = hp[4 * j];
+        q[0] = hp[16 * (R - 1)]; q[1] = hp[16 * (R - 1) + 4];
+        bq[0] = wp[win_off<R>(0)]; bq[1] = wp[win_off<R>(1)];
+    };
+    /* one k-step: the reads of step j + 2 (of the next group for j = 14, 15: the same code, offsets continue), R MFMAs */
+    auto kstep = [&](const double *hg, const double *wg, auto jc) {
+        constexpr int j = decltype(jc)::value;
+        q[(j + 2) & 15] = hg[4 * (j + 2)];
+        bq[(j + 2) & 3] = j + 2 < 16 ? wg[win_off<R>((j + 2) & 15)] : (wg - 64 / NR)[win_off<R>((j + 2) & 15)];
+        __builtin_amdgcn_sched_barrier(0);          /* the reads stay two steps ahead of their MFMAs */
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            acc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(q[(j - 4 * (R - 1 - r)) & 15], bq[j & 3], acc[r], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto group16 = [&](const double *hg, const double *wg) {
+        kstep(hg, wg, std::integral_constant<int, 0>{});  kstep(hg, wg, std::integral_constant<int, 1>{});
+        kstep(hg, wg, std::integral_constant<int, 2>{});  kstep(hg, wg, std::integral_constant<int, 3>{});
+        kstep(hg, wg, std::integral_constant<int, 4>{});  kstep(hg, wg, std::integral_constant<int, 5>{});
+        kstep(hg, wg, std::integral_constant<int, 6>{});  kstep(hg, wg, std::integral_constant<int, 7>{});
+        kstep(hg, wg, std::integral_constant<int, 8>{});  kstep(hg, wg, std::integral_constant<int, 9>{});
+        kstep(hg, wg, std::integral_constant<int, 10>{}); kstep(hg, wg, std::integral_constant<int, 11>{});
+        kstep(hg, wg, std::integral_constant<int, 12>{}); kstep(hg, wg, std::integral_constant<int, 13>{});
+        kstep(hg, wg, std::integral_constant<int, 14>{}); kstep(hg, wg, std::integral_constant<int, 15>{});
+    };
+
+    /* A chunk: write the images (the window samples were requested a chunk ago), request the next chunk's window, run the
+     * k-steps.  While a wave stages, the other wave of its SIMD has the matrix pipe to itself.  (Tried and dropped, both
+     * measured slower: a second pair of images filled in slices between the MFMAs -- the slices' address arithmetic and
+     * conversions cost the f64 matrix pipe more than the stop they replace, fir 83 -> 95 us on a 512-chain shard; and
+     * requesting the taps a chunk ahead into registers as well, 515 -> 539 us on the north-star program.)          */
     win_fetch(0, min(ck, S));
     for (int s0 = 0; s0 < S; s0 += ck) {
         const int ckc = min(ck, S - s0);
         const int JT = (4 * (ckc - 1) + NR - 1) / NR;
         __builtin_amdgcn_wave_barrier();
-        win_store();
-        taps_stage(s0, ckc);
+        win_store(ws);
+        taps_stage(hs, s0, ckc);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (s0 + ckc < S) win_fetch(s0 + ckc, min(ck, S - s0 - ckc));
-
-        /* lane bases: taps u = (k + i) + 16 (R-1) + 4 sc; window row (3 - k) + ..., entry a + JT - ... (win_off) */
         const double *hp = hs + k + i16;                                       /* oldest operand of step sc at hp[4 sc] */
         const double *wp = ws + (3 - k) * G::ROW + i16 + JT - (64 / NR - 1);   /* group g: wp - g * (64 / NR) + win_off(j) */
-        double q[16], bq[4];
-        /* the queue as the chunk's first step finds it, and the operands of its first two steps */
-#pragma unroll
-        for (int j = 0; j < G::QD; j++) q[(16 - G::QD + j) & 15] = hp[4 * j];
-        q[0] = hp[16 * (R - 1)]; q[1] = hp[16 * (R - 1) + 4];
-        bq[0] = wp[win_off<R>(0)]; bq[1] = wp[win_off<R>(1)];
-        for (int g = 0; g < ckc / 16; g++) {
-            const double *hg = hp + 16 * (R - 1) + 64 * g, *wg = wp - g * (64 / NR);
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-                /* operands of step j + 2 (of the next group for j = 14, 15: the same code, offsets continue) */
-                q[(j + 2) & 15] = hg[4 * (j + 2)];
-                bq[(j + 2) & 3] = j + 2 < 16 ? wg[win_off<R>((j + 2) & 15)] : (wg - 64 / NR)[win_off<R>((j + 2) & 15)];
-                __builtin_amdgcn_sched_barrier(0);          /* the reads stay two steps ahead of their MFMAs */
-#pragma unroll
-                for (int r = 0; r < R; r++)
-                    acc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(q[(j - 4 * (R - 1 - r)) & 15], bq[j & 3], acc[r], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
+        chunk_begin(hp, wp);
+        for (int g = 0; g < ckc / 16; g++) group16(hp + 16 * (R - 1) + 64 * g, wp - g * (64 / NR));
     }
     /* C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg */
 #pragma unroll

@@ -184,6 +184,7 @@ def main():
     ap.add_argument("--fir-impl", type=int, default=1)
     ap.add_argument("--biquad-impl", type=int, default=1)
     ap.add_argument("--overlap", type=int, default=-1, help="cascade of the next block under the FIR of this one: 0 off, 1 on, -1 library default")
+    ap.add_argument("--fir-rows", type=int, default=-1, help="fir_tile row tiles per wave: 0 auto, 1, 2, 4")
     ap.add_argument("--bq-block", type=int, default=-1, help="threads per cascade workgroup under overlap (256 | 1024)")
     ap.add_argument("--bq-lds", type=int, default=-1, help="bytes of LDS a cascade workgroup claims under overlap")
     ap.add_argument("--shard", default=None, help="RANK/WORLD: run that one shard of the program on this GPU alone (what one rank of a WORLD-GPU job does)")
@@ -232,6 +233,8 @@ def main():
     r.set_option("biquad_impl", args.biquad_impl)
     if args.overlap >= 0:
         r.set_option("overlap", args.overlap)
+    if args.fir_rows >= 0:
+        r.set_option("fir_rows", args.fir_rows)
     if args.bq_block >= 0:
         r.set_option("bq_block", args.bq_block)
     if args.bq_lds >= 0:
@@ -317,7 +320,7 @@ def main():
             # 2*T flop per sample; the Cl*B samples of a step are spread over fir_n/steps launches
             flops = 2.0 * T * B * Cl * args.steps / fir_n
             ach = flops / per_launch / 1e12
-            kname = "fir_mfma" if args.fir_impl else "fir_plain"
+            kname = {0: "fir_plain", 1: "fir_tile", 2: "fir_mfma"}[args.fir_impl]
             fir_bytes = (4.0 * Cl * B + 4.0 * (T - 1 + B) * Cl + 4.0 * T * Cl) * args.steps / fir_n   # out, window, taps
             roof = dict(bound="mfma", kernel=kname, achieved=ach,
                         peak=PEAK_F64_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_F64_TFLOPS,

@@ -40,7 +40,10 @@ def run_vs_oracle(fmt, prog, x, C, blocks, rows, fir_impl=1):
     r.set_option("fir_impl", 1)
 
 
-@pytest.mark.parametrize("rows", [1, 2, 4])
+ROWS = [1, 2, 4]                 # row tiles per wave
+
+
+@pytest.mark.parametrize("rows", ROWS)
 @pytest.mark.parametrize("taps", [1, 3, 4, 7, 60, 61, 64, 65, 255, 256, 257, 580, 641, 1000, 1030])
 def test_fir_only_chains_every_row_count(rows, taps):
     C = 5
@@ -50,7 +53,7 @@ def test_fir_only_chains_every_row_count(rows, taps):
     run_vs_oracle(6, prog, x, C, blocks, rows)
 
 
-@pytest.mark.parametrize("rows", [1, 2, 4])
+@pytest.mark.parametrize("rows", ROWS)
 @pytest.mark.parametrize("fmt,C,S,T", [(6, 9, 3, 2048), (6, 3, 16, 4096), (4, 6, 2, 4100), (6, 2, 1, 5000), (4, 4, 0, 2560), (6, 21, 5, 130)])
 def test_long_fir_behind_a_cascade(rows, fmt, C, S, T):
     prog = pb.synth_program(fmt, C, S, T)
@@ -59,7 +62,7 @@ def test_long_fir_behind_a_cascade(rows, fmt, C, S, T):
     run_vs_oracle(fmt, prog, x, C, blocks, rows)
 
 
-@pytest.mark.parametrize("rows", [0, 1, 2, 4])
+@pytest.mark.parametrize("rows", [0] + ROWS)
 def test_many_channels_auto_rows_and_other_kernels_agree(rows):
     """enough chains for every automatic choice (>= 2048: 4 row tiles), short taps so that the oracle keeps up; the same blocks
     through fir_mfma (fir_impl 2) and the plain tap loop (fir_impl 0) must give the same bits"""
@@ -88,5 +91,5 @@ def test_nan_inf_and_subnormal_samples_in_the_window():
     x = pb.lcg_input(2048, C, True, seed=11)
     xi = x.view(np.uint32)
     xi[5, 0] = 0x7F800000; xi[9, 1] = 0xFFC00001; xi[700, 2] = 0x7F812345; xi[1030, 0] = 0x00000012; xi[1500, 1] = 0x80000400
-    for rows in (1, 2, 4):
+    for rows in ROWS:
         run_vs_oracle(6, prog, x, C, [1024, 1024], rows)
