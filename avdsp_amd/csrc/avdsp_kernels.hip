@@ -311,6 +311,57 @@ __device__ __forceinline__ Hand<FMT> hand_rotate(Hand<FMT> h)
     return h;
 }
 
+/* One chain's cascade over the block in the reference's own order -- frames outer, sections inner, state in memory
+ * (dsp_biquadSTD.h:37-74, 87-117), every product through mulop(), i.e. with the bit-field reading of exponent 255.
+ * Slow and obviously sequential: biquad_simple runs it for every chain (cross-check path, cascades longer than 64
+ * sections), biquad_pipe for a chain whose block turned up an Inf or NaN.                                        */
+template <int FMT>
+__device__ void cascade_in_reference_order(const BiquadArgs &a, int cid, const avdsp_chain &c)
+{
+    using alu_t = typename Alu<FMT>::type;
+    const unsigned *inp = a.io.in + (c.in_io - a.io.in_base);
+    for (int n = 0; n < a.io.nframes; n++) {
+        alu_t X = load_stage<FMT>(inp[(size_t)n * a.io.in_stride], c.load_mode, c.gain_bits);
+        unsigned xin = narrow_stage<FMT>(X);
+        for (int s = 0; s < c.nsec; s++) {
+            const int *co = a.buf + a.sec_coef[c.sec_base + s];
+            int *st = a.buf + a.sec_state[c.sec_base + s];
+            const unsigned long long raw = ((unsigned long long)(unsigned)st[1] << 32) | (unsigned)st[0];
+            const unsigned x1 = (unsigned)st[2], x2 = (unsigned)st[3], y1 = (unsigned)st[4], y2 = (unsigned)st[5];
+            unsigned yn;
+            unsigned long long keep;
+            if constexpr (FMT == 2) {
+                unsigned long long u = raw;
+                u += (unsigned long long)((long long)(int)xin * co[0]);
+                u += (unsigned long long)((long long)(int)x1 * co[1]);
+                u += (unsigned long long)((long long)(int)x2 * co[2]);
+                u += (unsigned long long)((long long)(int)y1 * co[3]);
+                u += (unsigned long long)((long long)(int)y2 * co[4]);
+                long long acc = (long long)u;
+                const int hi = (int)(acc >> 32);
+                if (hi >= (1 << 27)) acc = (1ll << 59) - 1;
+                else if (hi <= 1 - (1 << 27)) acc = -(1ll << 59);
+                X = acc; keep = (unsigned long long)acc;
+                yn = (unsigned)(int)(acc >> 28);
+            } else {
+                double acc = __longlong_as_double((long long)raw);
+                acc = __builtin_fma(mulop(__uint_as_float(xin)), mulop(__int_as_float(co[0])), acc);
+                acc = __builtin_fma(mulop(__uint_as_float(x1)), mulop(__int_as_float(co[1])), acc);
+                acc = __builtin_fma(mulop(__uint_as_float(x2)), mulop(__int_as_float(co[2])), acc);
+                acc = __builtin_fma(mulop(__uint_as_float(y1)), mulop(__int_as_float(co[3])), acc);
+                acc = __builtin_fma(mulop(__uint_as_float(y2)), mulop(__int_as_float(co[4])), acc);
+                X = acc; keep = (unsigned long long)__double_as_longlong(acc);
+                yn = __float_as_uint(narrow_f32(acc));
+            }
+            st[0] = (int)(unsigned)keep; st[1] = (int)(unsigned)(keep >> 32);
+            st[2] = (int)xin; st[3] = (int)x1; st[4] = (int)yn; st[5] = (int)y1;
+            xin = yn;
+        }
+        if (c.fir_taps) *ring_at(a.ring, cid, n) = __uint_as_float(narrow_stage<FMT>(X));
+        else emit_out(a.io, c, n, store_stage<FMT>(X, c.sat, a.io.store_mask));
+    }
+}
+
 /* BLK = threads per workgroup.  256 normally.  1024 for the launches that run UNDER the previous block's FIR
  * (avdsp_hip_run_block, "overlap"): sixteen waves per workgroup, and the launch claims most of a CU's LDS without
  * using it, so that a cascade workgroup has its CU to itself -- its v_fma_f64 chain shares the FP64 datapath with
@@ -551,7 +602,23 @@ __global__ __launch_bounds__(BLK) void biquad_pipe(const BiquadArgs a)
         }
     }
 
-    if (lane_on) {
+    /* Inf / NaN.  The loop above computes with IEEE values; the reference's products read exponent 255 as 1.m x 2^128
+     * (mulop).  The two only differ when such a value turns up, and then it leaves a trace: an Inf or NaN sample or
+     * result makes the section's accumulator non-finite for good (Inf * 0 is NaN), or -- in the block's last frames --
+     * sits in its x / y state.  One look at the end of the block, no cost inside the loop: a chain with a trace in any of
+     * its sections writes nothing back (the mirror still holds the state the block started from) and its first lane
+     * runs the block again in the reference's own order with the reference's products.  Audio never gets here.   */
+    bool replay = false;
+    if constexpr (FMT != 2) {
+        const unsigned long long ab = (unsigned long long)__double_as_longlong(acc);
+        const bool odd = lane_on && ((ab >> 52 & 0x7FF) == 0x7FF || (x1 & 0x7F800000u) == 0x7F800000u || (x2 & 0x7F800000u) == 0x7F800000u ||
+                                     (y1 & 0x7F800000u) == 0x7F800000u || (y2 & 0x7F800000u) == 0x7F800000u);
+        const unsigned long long m = __ballot(odd);
+        const int lane64 = tid & 63, base = lane64 - (lane64 % P);
+        const unsigned long long chainmask = (P == 64 ? ~0ull : ((1ull << P) - 1)) << base;
+        replay = (m & chainmask) != 0;
+    }
+    if (lane_on && !replay) {
         int *st = a.buf + sw;
         unsigned long long bits;
         if constexpr (FMT == 2) bits = (unsigned long long)acc;
@@ -559,60 +626,20 @@ __global__ __launch_bounds__(BLK) void biquad_pipe(const BiquadArgs a)
         st[0] = (int)(unsigned)bits; st[1] = (int)(unsigned)(bits >> 32);
         st[2] = (int)x1; st[3] = (int)x2; st[4] = (int)y1; st[5] = (int)y2;
     }
+    if constexpr (FMT != 2) {
+        if (replay && have_chain && s == 0) cascade_in_reference_order<FMT>(a, cid, c);
+    }
 }
 
-/* lane per chain, state in memory: slow, obviously sequential, used as a cross-check and for
- * cascades longer than 64 sections                                                             */
+/* lane per chain, the reference's loop order: cross-check path, and cascades longer than 64 sections */
 template <int FMT>
 __global__ __launch_bounds__(64) void biquad_simple(const BiquadArgs a)
 {
     if constexpr (FMT != 2) flush_f32_subnormals_like_the_reference();
-    using alu_t = typename Alu<FMT>::type;
     const int slot = blockIdx.x * 64 + threadIdx.x;
     if (slot >= a.ngroup) return;
     const int cid = a.group[slot];
-    const avdsp_chain c = a.chains[cid];
-    const unsigned *inp = a.io.in + (c.in_io - a.io.in_base);
-    for (int n = 0; n < a.io.nframes; n++) {
-        alu_t X = load_stage<FMT>(inp[(size_t)n * a.io.in_stride], c.load_mode, c.gain_bits);
-        unsigned xin = narrow_stage<FMT>(X);
-        for (int s = 0; s < c.nsec; s++) {
-            const int *co = a.buf + a.sec_coef[c.sec_base + s];
-            int *st = a.buf + a.sec_state[c.sec_base + s];
-            const unsigned long long raw = ((unsigned long long)(unsigned)st[1] << 32) | (unsigned)st[0];
-            const unsigned x1 = (unsigned)st[2], x2 = (unsigned)st[3], y1 = (unsigned)st[4], y2 = (unsigned)st[5];
-            unsigned yn;
-            unsigned long long keep;
-            if constexpr (FMT == 2) {
-                unsigned long long u = raw;
-                u += (unsigned long long)((long long)(int)xin * co[0]);
-                u += (unsigned long long)((long long)(int)x1 * co[1]);
-                u += (unsigned long long)((long long)(int)x2 * co[2]);
-                u += (unsigned long long)((long long)(int)y1 * co[3]);
-                u += (unsigned long long)((long long)(int)y2 * co[4]);
-                long long acc = (long long)u;
-                const int hi = (int)(acc >> 32);
-                if (hi >= (1 << 27)) acc = (1ll << 59) - 1;
-                else if (hi <= 1 - (1 << 27)) acc = -(1ll << 59);
-                X = acc; keep = (unsigned long long)acc;
-                yn = (unsigned)(int)(acc >> 28);
-            } else {
-                double acc = __longlong_as_double((long long)raw);
-                acc = __builtin_fma(mulop(__uint_as_float(xin)), mulop(__int_as_float(co[0])), acc);
-                acc = __builtin_fma(mulop(__uint_as_float(x1)), mulop(__int_as_float(co[1])), acc);
-                acc = __builtin_fma(mulop(__uint_as_float(x2)), mulop(__int_as_float(co[2])), acc);
-                acc = __builtin_fma(mulop(__uint_as_float(y1)), mulop(__int_as_float(co[3])), acc);
-                acc = __builtin_fma(mulop(__uint_as_float(y2)), mulop(__int_as_float(co[4])), acc);
-                X = acc; keep = (unsigned long long)__double_as_longlong(acc);
-                yn = __float_as_uint(narrow_f32(acc));
-            }
-            st[0] = (int)(unsigned)keep; st[1] = (int)(unsigned)(keep >> 32);
-            st[2] = (int)xin; st[3] = (int)x1; st[4] = (int)yn; st[5] = (int)y1;
-            xin = yn;
-        }
-        if (c.fir_taps) *ring_at(a.ring, cid, n) = __uint_as_float(narrow_stage<FMT>(X));
-        else emit_out(a.io, c, n, store_stage<FMT>(X, c.sat, a.io.store_mask));
-    }
+    cascade_in_reference_order<FMT>(a, cid, a.chains[cid]);
 }
 
 /* ------------------------------------------------------------------------------------------

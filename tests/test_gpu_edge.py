@@ -285,12 +285,14 @@ def test_c_host_links_and_matches_the_oracle(tmp_path, fmt, which):
 
 def test_inf_and_nan_samples_follow_the_reference_products():
     """dspMulFloatDouble builds its products from bit fields and reads exponent 255 as 1.m x 2^128
-    (dsp_ieee754.h:377-410); the FIR, the lane-per-channel cascade and the interpreter do the same.
-    The pipelined cascade does not: it is left out here on purpose."""
+    (dsp_ieee754.h:377-410).  The FIR, the lane-per-channel cascade and the interpreter compute that way throughout; the
+    pipelined cascade (the default) computes with IEEE values, notices at the end of a block that an Inf or NaN has been
+    through a chain (non-finite accumulator or exponent-255 state) and runs that chain's block again in the reference's
+    order from the untouched state."""
     prog = pb.synth_program(6, 2, 2, 5)
     x = np.zeros((24, 2), dtype=np.float32)
     x[0, 0] = np.inf; x[5, 0] = np.nan; x[9, 1] = -np.inf; x[12, 0] = 3e38; x[13, 1] = -3.4e38
-    for opts in (dict(biquad_impl=0, fir_impl=1), dict(biquad_impl=0, fir_impl=0), dict(generic=1)):
+    for opts in (dict(biquad_impl=1, fir_impl=1), dict(biquad_impl=0, fir_impl=1), dict(biquad_impl=0, fir_impl=0), dict(generic=1)):
         o = po.OracleProgram(6, prog)
         r = rt.Runtime(6, prog)
         for k, v in opts.items():
@@ -302,7 +304,37 @@ def test_inf_and_nan_samples_follow_the_reference_products():
             assert (r.sync_state() == o.state).all(), opts
         finally:
             r.set_option("generic", 0)
+            r.set_option("biquad_impl", 1)
             r.release()
+
+
+@pytest.mark.parametrize("fmt", [4, 6])
+@pytest.mark.parametrize("sections,taps", [(16, 0), (5, 40), (24, 0), (40, 7)])
+def test_pipelined_cascade_replays_chains_that_met_inf_or_nan(fmt, sections, taps):
+    """Some channels of a wide program get Inf, NaN, overflowing or exponent-255 input at odd places (first and last frame of a
+    block, inside), the others ordinary noise; several blocks, so that exponent-255 STATE is carried into a block as well.
+    Every channel must be the oracle's, bit for bit: the odd ones through the replay, the rest untouched by it.  Format 4
+    reaches Inf only through overflow (int samples): a gain of 4 on a cascade that amplifies does it."""
+    C = 37
+    prog = pb.synth_program(fmt, C, sections, taps, gain=1.0)
+    blocks = [64, 1, 300, 17, 200]
+    n = sum(blocks)
+    x = pb.lcg_input(n, C, fmt == 6, seed=77)
+    if fmt == 6:
+        xi = x.view(np.uint32)
+        xi[0, 3] = 0x7F800000; xi[63, 5] = 0xFF800000; xi[64, 9] = 0x7FC00001; xi[100, 16] = 0x7F7FFFFF; xi[101, 16] = 0x7F7FFFFF
+        xi[364, 20] = 0xFFFFFFFF; xi[365 + 16, 31] = 0x7F812345; xi[n - 1, 36] = 0x7F800000
+        x[200:230, 12] = 3.0e38                                # overflows inside the cascade, not at its input
+    o = po.OracleProgram(fmt, prog)
+    r = rt.Runtime(fmt, prog)
+    pos = 0
+    for b in blocks:
+        want = o.run_block(x[pos:pos + b], C, C)
+        got = r.run_block(x[pos:pos + b], C, C)
+        bad = np.nonzero((got.view(np.uint32) != want.view(np.uint32)).any(axis=0))[0]
+        assert bad.size == 0, f"block at {pos}: channels {bad.tolist()} differ"
+        pos += b
+    assert (r.sync_state() == o.state).all()
 
 
 def test_reset_keeps_store_mem_words_like_the_reference():
