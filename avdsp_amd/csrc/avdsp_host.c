@@ -85,12 +85,14 @@ static struct {
     int             last_levels, last_cores, last_pieces;  /* of the latest dspRuntimeBlockAll: dspRuntimeGetOption("levels" / "cores" / "pieces") */
     int             opt_strand_split, next_tpdf_role;
     int             shard_rank, shard_world;               /* dspRuntimeSetShard: this process's slice of every chain core */
+    int             numfreq_at_init;                       /* dspChangeFormat's view of the rate count (see dspRuntimeInit) */
     int             opt_overlap, opt_bq_block, opt_bq_lds, opt_fir_rows; /* launch arrangement of the chain kernels (avdsp_hip_prog_set_option) */
     arrangement     arr[MAX_ARRANGEMENTS]; int arr_next;   /* how the cores / pieces go to the device: [0] whole program, [1..] single cores */
 } G = { .opt_fir_impl = 1, .opt_biquad_impl = 1, .opt_device = -1, .opt_interp_impl = 1, .opt_strand_split = 1, .shard_world = 1, .opt_bq_block = 512, .opt_bq_lds = 140 * 1024 };
 
 static char g_err[512];
 static int  g_err_code;
+static int  ensure_encoding(int format);
 
 static int fail(int code, const char *fmt, ...)
 {
@@ -145,6 +147,9 @@ int dspRuntimeSetOption(const char *key, int value)
         *slot = value;
         return 0;
     }
+    /* the reference's dspNumSamplingFreq static as a fresh process would have it (0), or as an earlier program left it:
+     * what dspChangeFormat converts depends on it (dspRuntimeInit); a test hook, a process restart does the same */
+    if (!strcmp(key, "rate_count_static")) { G.num_freq = value; return 0; }
     if (!strcmp(key, "profile")) {
         G.opt_profile = value;
         if (G.dev) avdsp_hip_profile_enable(G.dev, value);
@@ -277,12 +282,118 @@ int dspRuntimeInit(opcode_t *codePtr, int maxSize, const int fs, int random, int
     if (dspHeaderPtr->maxOpcode >= DSP_MAX_OPCODE)
         return fail(-5, "program uses opcodes newer than this runtime");
     dspMantissa = DSP_MANT;
-    if (dspHeaderPtr->format != 0 && dspHeaderPtr->format != DSP_MANT)
-        return fail(-7, "integer encoding with %d mantissa bits: only Q%d programs are accepted "
-                        "(dspChangeFormat is not carried over, see DESIGN.md)", dspHeaderPtr->format, DSP_MANT);
+    /* dsp_runtime.c:181-190 converts the parameters to the runtime's encoding right here.  This library serves every
+     * DSP_FORMAT, so which encoding is wanted is only known when the first entry point is called: the conversion runs
+     * then (ensure_encoding), with the rate count the reference would have used at THIS point -- the one the previous
+     * dspRuntimeReset of the process left behind, 0 the first time (dspNumSamplingFreq is a static that Init does not
+     * touch, :106,131), which is why a freshly loaded program's biquad banks stay unconverted there and here. */
+    G.numfreq_at_init = G.num_freq;
     G.total_words = length + size;
     if (fs) { int r = dspRuntimeReset(fs, random, defaultDither); if (r) return r; }
     return length;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * dspChangeFormat (dsp_runtime.c:198-299): rewrite the encoded parameters in place, Q(old) -> Q(new), Q -> float or
+ * float -> Q, walking the opcode stream from the header to the end of the program.  Which words are rewritten follows
+ * the reference opcode by opcode, its blind spots included: nothing for DSP_FIR (":267 TODO"), only the first word of a
+ * DATA_TABLE, and per-rate tables only as far as the rate count it happens to know (see dspRuntimeInit).  The reference
+ * follows every offset on trust; here a target outside the program words is refused (-8) before anything is written.
+ * ---------------------------------------------------------------------------------------- */
+static void change_datum(opcode_t *w, int oldf, int newf)                    /* dspChangeThisData, :198-209 */
+{
+    if (oldf) {
+        if (newf) {
+            int d = newf - oldf;
+            if (d > 0) w->u32 <<= d;
+            if (d < 0) w->i32 >>= -d;
+        } else w->f32 = (float)w->i32 / (float)(1 << oldf);
+    } else if (newf) w->i32 = (int)dspQNM(w->f32, 32 - newf, newf);          /* the call of :208 with the argument it lacks */
+}
+
+static int change_format(int newf, int numfreq)
+{
+    const int total = dspHeaderPtr->totalLength, oldf = dspHeaderPtr->format;
+    /* two passes over the same walk: check every target, then write */
+    for (int pass = 0; pass < 2; pass++) {
+        opcode_t *p = G.code;
+        for (;;) {
+            const int at = (int)(p - G.code);
+            if (at < 0 || at >= total) return fail(-8, "opcode stream runs past the program (word %d)", at);
+            const unsigned skip = p->op.skip;
+            if (skip == 0) break;
+            if ((long long)at + skip > total) return fail(-8, "word %d: opcode longer than the program", at);
+#define CF_AT(ptr) do { long long w_ = (ptr) - G.code; if (w_ < 12 || w_ >= total) return fail(-8, "word %d: parameter at word %lld outside the program", at, w_); \
+                        if (pass) change_datum((ptr), oldf, newf); } while (0)
+#define CF_NEED(n) do { if ((unsigned)(1 + (n)) > skip) return fail(-8, "word %d: opcode payload shorter than %d words", at, (n)); } while (0)
+            opcode_t *a = p + 1;
+            switch (p->op.opcode) {
+            case DSP_DIRAC: case DSP_SQUAREWAVE:
+                CF_NEED(2); a++;                       /* immediate behind a data pointer */
+                CF_AT(a); break;
+            case DSP_MUL_VALUE: case DSP_DIV_VALUE: case DSP_DATA_TABLE: case DSP_CLIP:
+                CF_NEED(1); CF_AT(a); break;
+            case DSP_LOAD_GAIN:
+                CF_NEED(2); a++;                       /* IO number, then the gain's offset */
+                CF_AT(p + a->i32); break;
+            case DSP_GAIN: case DSP_SAT0DB_GAIN: case DSP_SAT0DB_TPDF_GAIN:
+                CF_NEED(1); CF_AT(p + a->i32); break;
+            case DSP_LOAD_MUX: {
+                CF_NEED(1);
+                opcode_t *t = p + a->i32;
+                if (t - G.code < 12 || t - G.code >= total) return fail(-8, "word %d: mux table outside the program", at);
+                const int n = (short)t->i32;
+                t++;
+                for (int i = 0; i < n; i++) { t++; CF_AT(t); t++; }
+                break; }
+            case DSP_BIQUADS: {
+                CF_NEED(2); a++;
+                opcode_t *t = p + a->i32;
+                if (t - G.code < 12 || t - G.code >= total) return fail(-8, "word %d: biquad bank outside the program", at);
+                const int ns = (short)t->i32;
+                t += 3;
+                for (int i = 0; i < ns; i++) {
+                    t += 2;
+                    for (int j = 0; j < numfreq; j++) { for (int k = 0; k < 5; k++) { CF_AT(t); t++; } t++; }
+                }
+                break; }
+            case DSP_DITHER_NS2: {
+                CF_NEED(2); a++;
+                opcode_t *t = p + a->i32;
+                for (int i = 0; i < 3 * numfreq; i++) { CF_AT(t); t++; }
+                break; }
+            case DSP_DCBLOCK:
+                a++;
+                for (int i = 0; i < numfreq; i++) { CF_NEED(2 + i); CF_AT(a); a++; }
+                break;
+            case DSP_SINE:
+                CF_NEED(2); a++;
+                CF_AT(a); a++;
+                for (int i = 0; i < numfreq; i++) { CF_NEED(3 + i); CF_AT(a); a++; }
+                break;
+            default: break;
+            }
+#undef CF_AT
+#undef CF_NEED
+            p += skip;
+        }
+    }
+    dspHeaderPtr->format = (unsigned short)newf;
+    return 0;
+}
+
+/* the program's parameters in the encoding the entry point DSP_FORMAT `format` computes with */
+static int ensure_encoding(int format)
+{
+    const int want = format == DSP_FORMAT_INT64 ? DSP_MANT : 0;
+    if (dspHeaderPtr->format == want) return 0;
+    /* the program words change under the device's feet: bring its state home first, rebuild it afterwards */
+    if (G.dev && G.dev_state_valid) {
+        const int first = (int)(sizeof(dspHeader_t) / sizeof(int));
+        if (avdsp_hip_download_words(G.dev, (int32_t *)G.code, first, G.total_words - first)) return fail(-10, "%s", avdsp_hip_last_error());
+    }
+    drop_device();
+    return change_format(want, G.numfreq_at_init);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -359,9 +470,7 @@ static int lower_core(int format, opcode_t *core, lowered *L)
     memset(&cur, 0, sizeof cur);
     memset(L, 0, sizeof *L);
 
-    if ((format == DSP_FORMAT_INT64) != (dspHeaderPtr->format != 0))
-        return fail(-7, "program is %s-encoded but dspRuntime_%d was called: the reference's "
-                        "dspChangeFormat conversion is not provided", dspHeaderPtr->format ? "Q28" : "float", format);
+    if (ensure_encoding(format)) return g_err_code;
 
     for (;;) {
         const int op = p->op.opcode;
@@ -688,9 +797,7 @@ static unsigned char *store_mem_map(void)
 static int scan_generic(int format, opcode_t *core, int end_word, avdsp_generic_desc *d, core_deps *deps)
 {
     if (format < 2 || format > 6) return fail(-1, "DSP_FORMAT %d is not one of 2..6", format);
-    if ((format == DSP_FORMAT_INT64) != (dspHeaderPtr->format != 0))
-        return fail(-7, "program is %s-encoded but dspRuntime_%d was called: the reference's "
-                        "dspChangeFormat conversion is not provided", dspHeaderPtr->format ? "Q28" : "float", format);
+    if (ensure_encoding(format)) return g_err_code;
     const int alu_int = (format == DSP_FORMAT_INT64);
     const int nf = G.num_freq, fi = G.freq_index;
     gscan S;
@@ -1422,6 +1529,38 @@ int dspRuntimeBlockPcm(int format, opcode_t *core, int *rundata, int pcm, const 
     if (avdsp_hip_run_block_pcm_host(G.dev, cp->plan_id, pcm, src, in_stride, in_io_base, dst, out_stride, out_io_base,
                                      nframes, G.opt_fir_impl, G.opt_biquad_impl))
         return fail(-10, "%s", avdsp_hip_last_error());
+    return 0;
+}
+
+/* ---- linux/avdsp_plugin.c:133-137 ---- */
+int dspRuntimeTagOutputDevice(void *d_out, int out_stride, int column, int nframes, void *stream)
+{
+    if (!G.dev) return fail(-1, "no device program yet: run a block first");
+    if (column < 0 || column >= out_stride) return fail(-1, "tag column %d outside the output window of %d", column, out_stride);
+    if (avdsp_hip_tag_output(G.dev, (int *)d_out + column, out_stride, nframes, 0, 0, stream)) return fail(-10, "%s", avdsp_hip_last_error());
+    return 0;
+}
+
+int dspRuntimeTagOutputReset(int previoussample)
+{
+    if (!G.dev) return fail(-1, "no device program yet: run a block first");
+    if (avdsp_hip_tag_output(G.dev, 0, 0, 0, 1, previoussample, 0)) return fail(-10, "%s", avdsp_hip_last_error());
+    return 0;
+}
+
+int dspRuntimeTagOutput(int *out, int out_stride, int column, int nframes)
+{
+    if (!G.dev) return fail(-1, "no device program yet: run a block first");
+    if (column < 0 || column >= out_stride) return fail(-1, "tag column %d outside the output window of %d", column, out_stride);
+    if (nframes <= 0) return 0;
+    /* one column through the device: the carried value lives there */
+    int *col = (int *)malloc((size_t)nframes * sizeof(int));
+    if (!col) return fail(-9, "out of memory");
+    for (int n = 0; n < nframes; n++) col[n] = out[(size_t)n * out_stride + column];
+    int rc = avdsp_hip_tag_column_host(G.dev, col, nframes);
+    if (!rc) for (int n = 0; n < nframes; n++) out[(size_t)n * out_stride + column] = col[n];
+    free(col);
+    if (rc) return fail(-10, "%s", avdsp_hip_last_error());
     return 0;
 }
 

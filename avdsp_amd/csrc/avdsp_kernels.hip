@@ -1141,6 +1141,40 @@ __global__ __launch_bounds__(kBlock) void pcm_unpack(const UnpackArgs a)
     }
 }
 
+
+/* ------------------------------------------------------------------------------------------
+ * "tagoutput" of the ALSA plugin (linux/avdsp_plugin.c:133-137): the first output channel of a core carries, in bits
+ * 8..15 of every sample, a count derived from the PREVIOUS sample's upper half -- a transport check for bit-perfect
+ * playback.  sample' = (sample & 0xFFFF0000) | (prev & 0xFF00), prev = ((sample & 0xFFFF0000) >> 8) + 0x100: the carried
+ * value depends on the previous frame's own sample only, so every frame of a block is independent given the block's
+ * column; `prev` of the last frame is kept on the device for the next call (cores in program order, blocks in order).
+ * ---------------------------------------------------------------------------------------- */
+struct TagArgs { int *out; int stride, nframes; int *prev; };
+__global__ __launch_bounds__(kBlock) void tag_column(const TagArgs a)
+{
+    __shared__ int first_prev;
+    if (threadIdx.x == 0) first_prev = *a.prev;
+    __syncthreads();
+    int last = 0;
+    bool have_last = false;
+    /* one workgroup: frame n reads frame n-1's ORIGINAL sample, so originals are fetched before anything is stored */
+    for (int n0 = 0; n0 < a.nframes; n0 += blockDim.x) {
+        const int n = n0 + (int)threadIdx.x;
+        int cur = 0, before = 0;
+        if (n < a.nframes) {
+            cur = a.out[(size_t)n * a.stride] & (int)0xFFFF0000;
+            before = n ? ((a.out[(size_t)(n - 1) * a.stride] & (int)0xFFFF0000) >> 8) + 0x100 : first_prev;
+        }
+        __syncthreads();
+        if (n < a.nframes) {
+            a.out[(size_t)n * a.stride] = cur | (before & 0x0000FF00);
+            if (n == a.nframes - 1) { last = (cur >> 8) + 0x100; have_last = true; }
+        }
+        __syncthreads();
+    }
+    if (have_last) *a.prev = last;
+}
+
 #include "avdsp_interp.inc"
 
 /* ------------------------------------------------------------------------------------------
@@ -1198,6 +1232,7 @@ struct avdsp_hip_prog {
     int fir_rows = 0;                    /* fir_tile: row tiles per wave (1, 2, 4), 0 = by the number of chains */
     hipStream_t s_bq = nullptr;
     hipEvent_t ev_bq[2] = {nullptr, nullptr}, ev_fir[2] = {nullptr, nullptr};
+    int *d_tag_prev = nullptr;           /* tagoutput: the plugin's `previoussample` */
     bool ev_fir_set[2] = {false, false};
     unsigned long long blk = 0;
 };
@@ -1469,6 +1504,7 @@ void avdsp_hip_prog_destroy(avdsp_hip_prog *p)
     for (auto st : p->side) (void)hipStreamDestroy(st);
     for (auto e : p->join) (void)hipEventDestroy(e);
     if (p->fork) (void)hipEventDestroy(p->fork);
+    (void)hipFree(p->d_tag_prev);
     if (p->s_bq) (void)hipStreamDestroy(p->s_bq);
     for (int i = 0; i < 2; i++) { if (p->ev_bq[i]) (void)hipEventDestroy(p->ev_bq[i]); if (p->ev_fir[i]) (void)hipEventDestroy(p->ev_fir[i]); }
     (void)hipFree(p->d_buf); (void)hipFree(p->d_in); (void)hipFree(p->d_out); (void)hipFree(p->d_tpdf); (void)hipFree(p->d_frame);
@@ -2124,6 +2160,32 @@ int avdsp_hip_run_levels_pcm_host(avdsp_hip_prog *prog, const int *plans, const 
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(h_out, prog->d_out, out_words * 4, hipMemcpyDeviceToHost));
     return 0;
+}
+
+int avdsp_hip_tag_output(avdsp_hip_prog *prog, void *d_column, int stride, int nframes, int reset, int reset_value, void *stream)
+{
+    if (!prog->d_tag_prev) {
+        HIP_TRY(hipMalloc((void **)&prog->d_tag_prev, sizeof(int)));
+        HIP_TRY(hipMemset(prog->d_tag_prev, 0, sizeof(int)));
+    }
+    if (reset) HIP_TRY(hipMemcpyAsync(prog->d_tag_prev, &reset_value, sizeof(int), hipMemcpyHostToDevice, (hipStream_t)stream));
+    if (reset) HIP_TRY(hipStreamSynchronize((hipStream_t)stream));           /* reset_value lives on the caller's stack */
+    if (nframes <= 0) return 0;
+    TagArgs a{(int *)d_column, stride, nframes, prog->d_tag_prev};
+    hipLaunchKernelGGL(tag_column, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int avdsp_hip_tag_column_host(avdsp_hip_prog *prog, int *h_column, int nframes)
+{
+    int *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, (size_t)nframes * sizeof(int)));
+    hipError_t e = hipMemcpy(d, h_column, (size_t)nframes * sizeof(int), hipMemcpyHostToDevice);
+    int rc = e == hipSuccess ? avdsp_hip_tag_output(prog, d, 1, nframes, 0, 0, nullptr) : set_err("hipMemcpy: %s", hipGetErrorString(e));
+    if (!rc) { e = hipMemcpy(h_column, d, (size_t)nframes * sizeof(int), hipMemcpyDeviceToHost); if (e != hipSuccess) rc = set_err("hipMemcpy: %s", hipGetErrorString(e)); }
+    (void)hipFree(d);
+    return rc;
 }
 
 int avdsp_hip_prog_set_option(avdsp_hip_prog *prog, int key, int value)

@@ -30,11 +30,11 @@ EXPORTED = [
     "dspRuntimeBlockDevice", "dspRuntimeBlockPcm", "dspRuntimeUnpackPcmDevice", "dspRuntimeBlockAll", "dspRuntimeBlockAllDevice", "dspRuntimeBlockAllPcm",
     "dspRuntimeSyncState", "dspRuntimeUploadState", "dspRuntimeUploadParams", "dspRuntimeSetOption", "dspRuntimeGetOption",
     "dspRuntimeCoreInfo", "dspRuntimeKernelTime", "dspRuntimeLastError", "dspRuntimeRelease",
-    "dspRuntimeSetShard", "dspRuntimeShardInfo",
+    "dspRuntimeSetShard", "dspRuntimeShardInfo", "dspRuntimeTagOutput", "dspRuntimeTagOutputDevice", "dspRuntimeTagOutputReset",
     # thin HIP ABI (include/avdsp_hip.h)
     "avdsp_hip_device_count", "avdsp_hip_set_device", "avdsp_hip_prog_create", "avdsp_hip_prog_destroy",
     "avdsp_hip_prog_add_plan", "avdsp_hip_prog_add_generic", "avdsp_hip_prog_clear_plans", "avdsp_hip_tpdf_reset", "avdsp_hip_upload_words", "avdsp_hip_download_words", "avdsp_hip_zero_words",
-    "avdsp_hip_run_block", "avdsp_hip_run_block_host", "avdsp_hip_run_levels", "avdsp_hip_run_levels_host", "avdsp_hip_run_levels_pcm_host", "avdsp_hip_unpack_pcm", "avdsp_hip_run_block_pcm_host", "avdsp_hip_profile_enable", "avdsp_hip_profile_read", "avdsp_hip_prog_set_option",
+    "avdsp_hip_run_block", "avdsp_hip_run_block_host", "avdsp_hip_run_levels", "avdsp_hip_run_levels_host", "avdsp_hip_run_levels_pcm_host", "avdsp_hip_unpack_pcm", "avdsp_hip_run_block_pcm_host", "avdsp_hip_profile_enable", "avdsp_hip_profile_read", "avdsp_hip_prog_set_option", "avdsp_hip_tag_output", "avdsp_hip_tag_column_host",
     "avdsp_hip_synchronize", "avdsp_hip_last_error",
 ]
 
@@ -110,6 +110,9 @@ def lib() -> C.CDLL:
         L.dspRuntimeGetOption.restype = i32; L.dspRuntimeGetOption.argtypes = [C.c_char_p]
         L.dspRuntimeCoreInfo.restype = i32
         L.dspRuntimeCoreInfo.argtypes = [i32, vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+        L.dspRuntimeTagOutput.restype = i32; L.dspRuntimeTagOutput.argtypes = [vp, i32, i32, i32]
+        L.dspRuntimeTagOutputDevice.restype = i32; L.dspRuntimeTagOutputDevice.argtypes = [vp, i32, i32, i32, vp]
+        L.dspRuntimeTagOutputReset.restype = i32; L.dspRuntimeTagOutputReset.argtypes = [i32]
         L.dspRuntimeSetShard.restype = i32; L.dspRuntimeSetShard.argtypes = [i32, i32]
         L.dspRuntimeShardInfo.restype = i32
         L.dspRuntimeShardInfo.argtypes = [i32, vp] + [C.POINTER(i32)] * 7
@@ -190,6 +193,11 @@ class Runtime:
         a, b, c = C.c_int(), C.c_int(), C.c_int()
         self._check(self.L.dspRuntimeCoreInfo(self.fmt, self.cores[core_index], C.byref(a), C.byref(b), C.byref(c)))
         return dict(chains=a.value, max_sections=b.value, max_taps=c.value)
+
+    def tag_output(self, out: np.ndarray, column: int):
+        """dspRuntimeTagOutput on a host block [frames][out_stride] of int32, in place (linux/avdsp_plugin.c:133-137)."""
+        assert out.dtype == np.int32 and out.flags.c_contiguous
+        self._check(self.L.dspRuntimeTagOutput(out.ctypes.data, out.shape[1], column, out.shape[0]))
 
     def set_shard(self, rank: int, world: int):
         """dspRuntimeSetShard: this process runs chains shard_range(total, world, rank) of every chain core."""

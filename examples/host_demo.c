@@ -13,14 +13,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
-#include "avdsp_runtime.h"
-
-#ifndef DSP_FORMAT
-#define DSP_FORMAT 2
-#endif
-#define CAT_(a, b) a##_##b
-#define CAT(a, b) CAT_(a, b)
-#define DSP_RUNTIME_FORMAT(name) CAT(name, DSP_FORMAT)         /* dsp_runtime.h:63,85,99,113,127 */
+#include "compat/dsp_runtime.h"          /* the reference's names: DSP_RUNTIME_FORMAT(), dspSample_t (dsp_runtime.h:24-131) */
 
 #define OPCODES_MAX 20000
 #define CORES_MAX 8

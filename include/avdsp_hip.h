@@ -162,6 +162,12 @@ int avdsp_hip_profile_read(avdsp_hip_prog *prog, int kind, double *total_ms, int
 enum { AVDSP_OPT_OVERLAP = 0, AVDSP_OPT_BQ_BLOCK = 1, AVDSP_OPT_BQ_LDS = 2, AVDSP_OPT_FIR_ROWS = 3 };   /* FIR_ROWS: row tiles per wave of fir_tile, 0 = auto */
 int avdsp_hip_prog_set_option(avdsp_hip_prog *prog, int key, int value);
 
+/* the plugin's "tagoutput" (linux/avdsp_plugin.c:133-137) on one column of a device-resident S32 output block:
+ * d_column = address of the column's sample in frame 0, stride in words; reset != 0 first sets the carried value */
+int avdsp_hip_tag_output(avdsp_hip_prog *prog, void *d_column, int stride, int nframes, int reset, int reset_value, void *stream);
+
+int avdsp_hip_tag_column_host(avdsp_hip_prog *prog, int *h_column, int nframes);      /* the same on a host copy of the column */
+
 int avdsp_hip_synchronize(void *stream);
 const char *avdsp_hip_last_error(void);
 

@@ -127,6 +127,15 @@ int dspRuntimeBlockPcm(int format, opcode_t *core, int *rundata, int pcm, const 
                        int *dst, int out_stride, int out_io_base, int nframes);
 int dspRuntimeUnpackPcmDevice(int pcm, const void *d_src, int *d_dst, long long nsamples, void *stream);
 
+/* The plugin's "tagoutput" option (linux/avdsp_plugin.c:133-137, key :262): bits 8..15 of the first output channel of a core
+ * carry a count derived from the previous sample's upper half, so that a bit-perfect transport can be verified downstream:
+ *     sample' = (sample & 0xFFFF0000) | (previoussample & 0x0000FF00);   previoussample = ((sample & 0xFFFF0000) >> 8) + 0x100
+ * Call it after a core's block, on that core's first output column (column = its IO number - out_io_base), cores in program
+ * order as the plugin's loop runs them; the carried value lives on the device.  Device-resident block, or host block.  */
+int dspRuntimeTagOutputDevice(void *d_out, int out_stride, int column, int nframes, void *stream);
+int dspRuntimeTagOutput(int *out, int out_stride, int column, int nframes);
+int dspRuntimeTagOutputReset(int previoussample);
+
 /* device state -> rundata (the buffer stays the checkpoint) / rundata -> device state (restore).
  * Sync also brings back the program words (DSP_STORE_MEM writes into the program's parameter
  * section, dsp_runtime.c:755-760).                                                              */

@@ -74,13 +74,19 @@ class OracleProgram:
     """One loaded program: the caller-visible shape of dspRuntimeInit + dspRuntime_N on the CPU."""
 
     def __init__(self, fmt: int, prog_words: np.ndarray, fs: int = 48000, random: int = 0,
-                 dither: int = 31, max_size: int | None = None):
+                 dither: int = 31, max_size: int | None = None, after: "OracleProgram | None" = None):
+        """`after`: load this program into the context another program was loaded into before (the reference keeps its
+        rate count and dither state in statics that survive a dspRuntimeInit); that program must not be used afterwards."""
         self.L = lib()
         self.fmt = fmt
         n = int(prog_words[1]) + max(int(np.int32(prog_words[2])), 0)
         self.buf = np.zeros(max(n, len(prog_words)) + 64, dtype=np.uint32)
         self.buf[:len(prog_words)] = prog_words
-        self.ctx = self.L.oracle_new(fmt)
+        if after is not None:
+            assert after.fmt == fmt
+            self.ctx, after.ctx = after.ctx, None
+        else:
+            self.ctx = self.L.oracle_new(fmt)
         if not self.ctx:
             raise ValueError(f"unsupported DSP_FORMAT {fmt}")
         self.rc = self.L.oracle_init(self.ctx, self.buf.ctypes.data, n if max_size is None else max_size,

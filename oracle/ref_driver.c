@@ -13,6 +13,9 @@
  *   MAXSIZE 0 = totalLength + dataSize.  Prints "init=<rc>" and, on success, "cores=<n>".
  *   REPEAT > 1 runs the NFRAMES input that many times back to back (timing runs for bench.py's
  *   cpu_baseline leg); the first WARM passes are excluded from the "elapsed=<s> frames=<n>" line.
+ *   A 21st argument PRIMER.bin is a program initialised (at FS) BEFORE the real one, in the same process: the reference
+ *   keeps its rate count in a static that dspRuntimeInit's format conversion reads before dspRuntimeReset refreshes it
+ *   (dsp_runtime.c:106,131,181-190), so what a load converts depends on what was loaded before.
  */
 #include <dlfcn.h>
 #include <stdio.h>
@@ -66,6 +69,16 @@ int main(int argc, char **argv)
     run_fn   f_run   = (run_fn)dlsym(h, name);
     if (!f_init || !f_find || !f_begin || !f_run) { fprintf(stderr, "missing symbol\n"); return 2; }
 
+    if (argc > 20) {                                   /* prime the reference's statics with another program first */
+        size_t qb;
+        void *q = slurp(argv[20], &qb);
+        const dspHeader_t *qh = (const dspHeader_t *)q;
+        size_t qn = (size_t)qh->totalLength + (size_t)(qh->dataSize > 0 ? qh->dataSize : 0);
+        if (qn < qb / 4) qn = qb / 4;
+        opcode_t *qc = (opcode_t *)calloc(qn + 64, 4);
+        memcpy(qc, q, qb);
+        printf("primer_init=%d\n", f_init(qc, (int)qn, fs, rnd, dither));
+    }
     size_t pbytes;
     void *raw = slurp(progpath, &pbytes);
     const dspHeader_t *hd = (const dspHeader_t *)raw;

@@ -89,10 +89,10 @@ def test_path_selection_and_refusals():
     with pytest.raises(rt.AvdspError) as e:
         r.core_info()
     assert e.value.code == -8 and "undefined behaviour" in str(e.value)
-    r = rt.Runtime(2, pb.synth_program(6, 2, 1))             # float-encoded program, int64 entry point
-    with pytest.raises(rt.AvdspError) as e:
-        r.core_info()
-    assert e.value.code == -7
+    r = rt.Runtime(2, pb.synth_program(6, 2, 1))             # float-encoded program, int64 entry point: converted in place
+    assert int(r.buf[6]) & 0xFFFF == 0                       # (dspChangeFormat, dsp_runtime.c:198-299; tests/test_changeformat.py)
+    assert r.core_info()["chains"] == 2
+    assert int(r.buf[6]) & 0xFFFF == 28
     # a chain that loads what another chain of the same core stores is a sequential dependency:
     # not parallel chains, so the frame-sequential interpreter takes it
     pw = pb.ProgramWriter(6)

@@ -411,3 +411,29 @@ def test_live_parameter_edit_in_an_interpreted_core():
     r.upload_params()
     assert (r.run_block(x[60:], 32, 8, 0, block=30) == o.run_block(x[60:], 32, 8, 0, scratch_len=40, block=30)).all()
     assert (r.sync_state() == o.state).all()
+
+
+def test_tagoutput_like_the_plugin():
+    """linux/avdsp_plugin.c:133-137: the first output channel of each core carries (previoussample & 0xFF00) in bits 8..15;
+    previoussample runs through cores (outer) and frames (inner) of a block and on into the next block."""
+    prog = np.fromfile(os.path.join(os.path.dirname(__file__), "golden", "crossoverLV6.bin"), dtype=np.uint32)
+    x = pb.lcg_input(600, 16, False, seed=21)
+    o = po.OracleProgram(2, prog, fs=48000, random=3, dither=24)
+    r = rt.Runtime(2, prog, fs=48000, random=3, dither=24)
+    first_out = [25 - 0, 28 - 0]                    # cores' first output IO: usedOutputs 0x0E000000 and 0x30000000 (SURVEY appendix C)
+    prev = 0
+    assert rt.lib().dspRuntimeTagOutputReset(0) == -1           # nothing on the device yet
+    for b0, b1 in ((0, 257), (257, 258), (258, 600)):
+        want = np.zeros((b1 - b0, 32), dtype=np.int32)
+        got = np.zeros((b1 - b0, 32), dtype=np.int32)
+        for k, core in enumerate(o.cores):
+            o.L.oracle_run_block(o.ctx, core, o.data_ptr, x[b0:b1].ctypes.data, 16, 8, want.ctypes.data, 32, 0, b1 - b0, 40)
+            for n in range(b1 - b0):                             # the plugin's lines, frame by frame
+                new = int(want[n, first_out[k]]) & -65536
+                want[n, first_out[k]] = np.int32(new | (prev & 0xFF00))
+                prev = ((new >> 8) + 0x100) & 0xFFFFFFFF
+                prev = prev - (1 << 32) if prev & 0x80000000 else prev
+            f = getattr(r.L, "dspRuntimeBlock_2")
+            assert f(r.cores[k], r.rundata, x[b0:b1].ctypes.data, 16, 8, got.ctypes.data, 32, 0, b1 - b0) == 0
+            r.tag_output(got, first_out[k])
+        assert (got == want).all(), (b0, b1)
