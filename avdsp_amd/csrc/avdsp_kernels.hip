@@ -1200,6 +1200,7 @@ struct Plan {
     bool wave_ok = false; unsigned carried_io[8] = {0, 0, 0, 0, 0, 0, 0, 0};      /* frame-parallel interpreter */
     int *d_own = nullptr;                                /* owned mirror ranges (pairs), generic plans */
     double *d_taps64 = nullptr; int pitch64 = 0;         /* fir_tile: the taps as doubles, [chain][pitch64] */
+    bool stores_whole_window = false;                    /* every IO of [io_out_min, io_out_max] is stored by some chain */
     bool overlap_ok = false;                             /* every cascade of the plan feeds a FIR: its launches may run under the previous block's FIR */
 };
 
@@ -1233,6 +1234,13 @@ struct avdsp_hip_prog {
     hipStream_t s_bq = nullptr;
     hipEvent_t ev_bq[2] = {nullptr, nullptr}, ev_fir[2] = {nullptr, nullptr};
     int *d_tag_prev = nullptr;           /* tagoutput: the plugin's `previoussample` */
+    /* host-pointer block calls: the caller's buffers pinned in place (cache), copies and kernels on three streams */
+    struct Pinned { const void *ptr; size_t bytes; bool ours; };
+    std::vector<Pinned> pinned;
+    hipStream_t s_h2d = nullptr, s_run = nullptr, s_d2h = nullptr;
+    std::vector<hipEvent_t> ev_host;
+    int host_split = 0;                  /* frames per piece of a host block (0 = one piece; pieces only pay with host_pin) */
+    int host_pin = 0;                    /* pin the caller's buffers in place and remember them: only for a host that keeps them allocated */
     bool ev_fir_set[2] = {false, false};
     unsigned long long blk = 0;
 };
@@ -1383,6 +1391,7 @@ int launch_fir(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, BlockIO io
             /* row tiles per wave: as many as leave the chip two waves per SIMD (2048) -- a bigger tile reads fewer operands per MFMA */
             int rows = prog->fir_rows;
             if (rows != 1 && rows != 2 && rows != 4) rows = n >= 2048 ? 4 : n >= 1024 ? 2 : 1;
+            while (rows > 1 && 128 * rows >= io.nframes) rows >>= 1;       /* a tile twice the block would multiply zeros */
             return rows == 4 ? launch_fir_tile<FMT, 4>(prog, pl, ids, n, io, stream)
                  : rows == 2 ? launch_fir_tile<FMT, 2>(prog, pl, ids, n, io, stream)
                              : launch_fir_tile<FMT, 1>(prog, pl, ids, n, io, stream);
@@ -1505,6 +1514,9 @@ void avdsp_hip_prog_destroy(avdsp_hip_prog *p)
     for (auto e : p->join) (void)hipEventDestroy(e);
     if (p->fork) (void)hipEventDestroy(p->fork);
     (void)hipFree(p->d_tag_prev);
+    for (auto &pn : p->pinned) if (pn.ours) (void)hipHostUnregister(const_cast<void *>(pn.ptr));
+    for (auto st : {p->s_h2d, p->s_run, p->s_d2h}) if (st) (void)hipStreamDestroy(st);
+    for (auto e : p->ev_host) (void)hipEventDestroy(e);
     if (p->s_bq) (void)hipStreamDestroy(p->s_bq);
     for (int i = 0; i < 2; i++) { if (p->ev_bq[i]) (void)hipEventDestroy(p->ev_bq[i]); if (p->ev_fir[i]) (void)hipEventDestroy(p->ev_fir[i]); }
     (void)hipFree(p->d_buf); (void)hipFree(p->d_in); (void)hipFree(p->d_out); (void)hipFree(p->d_tpdf); (void)hipFree(p->d_frame);
@@ -1600,6 +1612,11 @@ int avdsp_hip_prog_add_plan(avdsp_hip_prog *prog, const avdsp_plan_desc *d)
         RingConvArgs ca{prog->d_buf, pl.d_chains, pl.d_fir_ids, pl.n_fir, plan_ring(pl)};
         hipLaunchKernelGGL(state_to_ring, dim3(pl.n_fir), dim3(kBlock), 0, nullptr, ca);   /* history the caller's buffer holds */
         if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) { free_plan(pl); return set_err("state_to_ring failed"); }
+    }
+    {
+        long long nout = 0;
+        for (int i = 0; i < d->nchains; i++) nout += chains[i].n_out;           /* check_independent (host): no IO is stored twice */
+        pl.stores_whole_window = pl.io_out_max >= pl.io_out_min && nout == (long long)pl.io_out_max - pl.io_out_min + 1;
     }
     pl.overlap_ok = pl.n_fir > 0 && !pl.bq.empty();
     for (int i = 0; i < d->nchains && pl.overlap_ok; i++)
@@ -1914,6 +1931,23 @@ int avdsp_hip_run_block(avdsp_hip_prog *prog, int plan, const void *d_in, int in
     return 0;
 }
 
+/* "host_pin": pin the caller's buffer where it lies (a host hands over the same buffers block after block): copies from and
+ * to pinned memory are true DMA and run beside kernels.  Registrations are remembered, which is only sound while the caller
+ * keeps those buffers allocated -- a registration outlives free(), and a new allocation at the same address would then
+ * receive DMA into the OLD pages.  Hence opt-in; without it the copies go through the driver's own staging.      */
+static void pin_in_place(avdsp_hip_prog *prog, const void *ptr, size_t bytes)
+{
+    for (auto &pn : prog->pinned)
+        if (pn.ptr == ptr && pn.bytes >= bytes) return;
+    if (prog->pinned.size() >= 16) {
+        for (auto &pn : prog->pinned) if (pn.ours) (void)hipHostUnregister(const_cast<void *>(pn.ptr));
+        prog->pinned.clear();
+    }
+    const hipError_t e = hipHostRegister(const_cast<void *>(ptr), bytes, hipHostRegisterDefault);
+    (void)hipGetLastError();
+    prog->pinned.push_back({ptr, bytes, e == hipSuccess});
+}
+
 int avdsp_hip_run_block_host(avdsp_hip_prog *prog, int plan, const void *h_in, int in_stride, int in_io_base,
                              void *h_out, int out_stride, int out_io_base, int nframes,
                              int fir_impl, int biquad_impl)
@@ -1933,6 +1967,41 @@ int avdsp_hip_run_block_host(avdsp_hip_prog *prog, int plan, const void *h_in, i
     if (prog->out_cap < out_words) {
         (void)hipFree(prog->d_out); prog->d_out = nullptr; prog->out_cap = 0;
         HIP_TRY(hipMalloc((void **)&prog->d_out, out_words * 4)); prog->out_cap = out_words;
+    }
+    /* The chain kernels over a block of some size: the host loop of linux/avdsp_plugin.c:98-141 as a three-stage pipeline --
+     * piece k+1 crosses PCIe while piece k is computed and piece k-1 goes back.  The output block is uploaded first only if
+     * the core leaves slots of the window untouched (they must keep the caller's content). */
+    if (!pl.generic && nframes >= 256) {
+        if (!prog->s_h2d) {
+            HIP_TRY(hipStreamCreateWithFlags(&prog->s_h2d, hipStreamNonBlocking));
+            HIP_TRY(hipStreamCreateWithFlags(&prog->s_run, hipStreamNonBlocking));
+            HIP_TRY(hipStreamCreateWithFlags(&prog->s_d2h, hipStreamNonBlocking));
+        }
+        HIP_TRY(hipDeviceSynchronize());                    /* earlier work of any stream has finished: the pipeline starts clean */
+        if (prog->host_pin) { pin_in_place(prog, h_in, in_words * 4); pin_in_place(prog, h_out, out_words * 4); }
+        const bool whole = pl.stores_whole_window && out_io_base == pl.io_out_min && out_stride == pl.io_out_max - pl.io_out_min + 1;
+        if (!whole) HIP_TRY(hipMemcpyAsync(prog->d_out, h_out, out_words * 4, hipMemcpyHostToDevice, prog->s_h2d));
+        const int split = prog->host_split > 0 ? std::max(prog->host_split, 64) : nframes;
+        const int npieces = (nframes + split - 1) / split;
+        while ((int)prog->ev_host.size() < 2 * npieces) {
+            hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            prog->ev_host.push_back(e);
+        }
+        for (int k = 0; k < npieces; k++) {
+            const int f0 = k * split, nf = std::min(split, nframes - f0);
+            const unsigned *hi = (const unsigned *)h_in + (size_t)f0 * in_stride;
+            unsigned *di = prog->d_in + (size_t)f0 * in_stride, *dout = prog->d_out + (size_t)f0 * out_stride;
+            HIP_TRY(hipMemcpyAsync(di, hi, (size_t)nf * in_stride * 4, hipMemcpyHostToDevice, prog->s_h2d));
+            HIP_TRY(hipEventRecord(prog->ev_host[2 * k], prog->s_h2d));
+            HIP_TRY(hipStreamWaitEvent(prog->s_run, prog->ev_host[2 * k], 0));
+            if (avdsp_hip_run_block(prog, plan, di, in_stride, in_io_base, dout, out_stride, out_io_base, nf, fir_impl, biquad_impl, prog->s_run)) return -1;
+            HIP_TRY(hipEventRecord(prog->ev_host[2 * k + 1], prog->s_run));
+            HIP_TRY(hipStreamWaitEvent(prog->s_d2h, prog->ev_host[2 * k + 1], 0));
+            HIP_TRY(hipMemcpyAsync((unsigned *)h_out + (size_t)f0 * out_stride, dout, (size_t)nf * out_stride * 4, hipMemcpyDeviceToHost, prog->s_d2h));
+        }
+        HIP_TRY(hipStreamSynchronize(prog->s_d2h));
+        HIP_TRY(hipStreamSynchronize(prog->s_run));
+        return 0;
     }
     HIP_TRY(hipMemcpy(prog->d_in, h_in, in_words * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(prog->d_out, h_out, out_words * 4, hipMemcpyHostToDevice));   /* unstored slots keep their content */
@@ -2197,6 +2266,10 @@ int avdsp_hip_prog_set_option(avdsp_hip_prog *prog, int key, int value)
                              prog->bq_block = value; return 0;
     case AVDSP_OPT_FIR_ROWS: if (value != 0 && value != 1 && value != 2 && value != 4) return set_err("fir_tile row tiles: 0 (auto), 1, 2 or 4");
                              prog->fir_rows = value; return 0;
+    case AVDSP_OPT_HOST_SPLIT: if (value < 0) return set_err("host_split: frames per piece, 0 = whole block"); prog->host_split = value; return 0;
+    case AVDSP_OPT_HOST_PIN: prog->host_pin = value != 0;
+                             if (!value) { for (auto &pn : prog->pinned) if (pn.ours) (void)hipHostUnregister(const_cast<void *>(pn.ptr)); prog->pinned.clear(); }
+                             return 0;
     case AVDSP_OPT_BQ_LDS:   if (value < 0 || value > 160 * 1024) return set_err("LDS claim %d outside [0, 160 KiB]", value);
                              prog->bq_lds = value; return 0;
     }

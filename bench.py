@@ -189,6 +189,8 @@ def main():
     ap.add_argument("--bq-lds", type=int, default=-1, help="bytes of LDS a cascade workgroup claims under overlap")
     ap.add_argument("--shard", default=None, help="RANK/WORLD: run that one shard of the program on this GPU alone (what one rank of a WORLD-GPU job does)")
     ap.add_argument("--host-buffers", action="store_true", help="also time dspRuntimeBlock_N with HOST buffers (PCIe inclusive), reported beside value")
+    ap.add_argument("--host-split", type=int, default=-1, help="frames per piece of a host-pointer block (0 = whole block)")
+    ap.add_argument("--host-pin", type=int, default=-1, help="pin the host buffers in place (bench.py keeps them allocated)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -235,6 +237,10 @@ def main():
         r.set_option("overlap", args.overlap)
     if args.fir_rows >= 0:
         r.set_option("fir_rows", args.fir_rows)
+    if args.host_split >= 0:
+        r.set_option("host_split", args.host_split)
+    if args.host_pin >= 0:
+        r.set_option("host_pin", args.host_pin)
     if args.bq_block >= 0:
         r.set_option("bq_block", args.bq_block)
     if args.bq_lds >= 0:
