@@ -1048,7 +1048,7 @@ static core_plan *get_plan_range(int format, opcode_t *core, int end_word)
     avdsp_generic_desc gd;
     int chains = 0;
     memset(&L, 0, sizeof L);
-    if ((format == 2 || format == 4 || format == 6) && !G.opt_generic && !end_word) {
+    if (!G.opt_generic && !end_word) {              /* formats 2, 4, 6: pipelined cascade + MFMA FIR; 3, 5: one lane per chain */
         int rc = lower_core(format, core, &L);
         if (rc == 0) chains = 1;
         else { lowered_free(&L); if (rc != -8) return 0; }
@@ -1132,7 +1132,7 @@ int dspRuntimeCoreInfo(int format, opcode_t *core, int *nchains, int *max_sectio
     if (format < 2 || format > 6) return fail(-1, "DSP_FORMAT %d is not one of 2..6", format);
     if (core < G.code || core >= G.code + dspHeaderPtr->totalLength) return fail(-1, "core pointer outside the loaded program");
     int nc = 0, ms = 0, mt = 0, rc = -8;
-    if ((format == 2 || format == 4 || format == 6) && !G.opt_generic) {
+    if (!G.opt_generic) {
         lowered L;
         rc = lower_core(format, core, &L);
         if (rc == 0) {
@@ -1166,7 +1166,7 @@ int dspRuntimeShardInfo(int format, opcode_t *core, int *total_chains, int *firs
     if (format < 2 || format > 6) return fail(-1, "DSP_FORMAT %d is not one of 2..6", format);
     if (core < G.code || core >= G.code + dspHeaderPtr->totalLength) return fail(-1, "core pointer outside the loaded program");
     int tot = 0, lo = 0, hi = 0, imin = 0, imax = -1, omin = 0, omax = -1;
-    if ((format == 2 || format == 4 || format == 6) && !G.opt_generic) {
+    if (!G.opt_generic) {
         lowered L;
         int rc = lower_core(format, core, &L);
         if (rc == 0) {

@@ -1177,6 +1177,49 @@ __global__ __launch_bounds__(kBlock) void tag_column(const TagArgs a)
 
 #include "avdsp_interp.inc"
 
+
+/* ------------------------------------------------------------------------------------------
+ * chain_lane<FMT>: the chain shape  LOAD | LOAD_GAIN -> BIQUADS* -> [FIR] -> [SAT0DB] -> STORE+  with ONE LANE PER CHAIN,
+ * frames in order, all state in the mirror in the reference's own layout (the FIR's shifting delay line included).  It is
+ * the parallel path of DSP_FORMAT 3 and 5 -- float accumulators and the truncating dspMulFloatFloat (dsp_ieee754.h:364-368),
+ * arithmetic that MFMA and v_fma_f64 cannot reproduce -- built from the interpreter's own stage functions, so its results
+ * are the interpreter's (goldens in all five models); a program of N channels runs N lanes wide instead of on one wave.
+ * ---------------------------------------------------------------------------------------- */
+struct LaneArgs {
+    int *buf; const avdsp_chain *chains; const int *sec_coef, *sec_state; int nchains; BlockIO io;
+};
+
+template <int FMT>
+__global__ __launch_bounds__(64) void chain_lane(const LaneArgs a)
+{
+    using namespace interp;
+    using alu_t = typename M<FMT>::alu;
+    flush_f32_subnormals_like_the_reference();
+    const int cid = blockIdx.x * 64 + threadIdx.x;
+    if (cid >= a.nchains) return;
+    const avdsp_chain c = a.chains[cid];
+    const unsigned *inp = a.io.in + (c.in_io - a.io.in_base);
+    for (int n = 0; n < a.io.nframes; n++) {
+        const unsigned raw = inp[(size_t)n * a.io.in_stride];
+        alu_t X;
+        if constexpr (M<FMT>::smp_int) {                                        /* dsp_runtime.c:565-607 */
+            if (c.load_mode == AVDSP_LOAD_GAIN) X = fmul<FMT>(int_to_float_scaled((int)raw, 31), __uint_as_float(c.gain_bits));
+            else X = from_int_scaled<FMT>((int)raw, 31);
+        } else {
+            X = to_alu<FMT>(__uint_as_float(raw));
+            if (c.load_mode == AVDSP_LOAD_GAIN) X *= to_alu<FMT>(__uint_as_float(c.gain_bits));
+        }
+        for (int s = 0; s < c.nsec; s++)                                        /* :827-849, section by section */
+            X = biquads<FMT>(X, a.buf + a.sec_coef[c.sec_base + s], a.buf + a.sec_state[c.sec_base + s], 1, 0);
+        if (c.fir_taps) X = fir<FMT>(to_sp<FMT>(X), a.buf + c.fir_coef_word, a.buf + c.fir_state_word, c.fir_taps);   /* :928-969 */
+        if (c.sat) X = sat0db<FMT>(X);                                          /* :464-475 */
+        unsigned word;                                                          /* :610-633 */
+        if constexpr (M<FMT>::smp_int) word = (unsigned)(s31_from_float(X.v) & a.io.store_mask);
+        else word = __float_as_uint(to_sp<FMT>(X));
+        emit_out(a.io, c, n, word);
+    }
+}
+
 /* ------------------------------------------------------------------------------------------
  * host side of the thin ABI
  * ---------------------------------------------------------------------------------------- */
@@ -1200,6 +1243,7 @@ struct Plan {
     bool wave_ok = false; unsigned carried_io[8] = {0, 0, 0, 0, 0, 0, 0, 0};      /* frame-parallel interpreter */
     int *d_own = nullptr;                                /* owned mirror ranges (pairs), generic plans */
     double *d_taps64 = nullptr; int pitch64 = 0;         /* fir_tile: the taps as doubles, [chain][pitch64] */
+    bool lane_mode = false;                              /* formats 3 and 5: chain_lane, one lane per chain, state in the mirror */
     bool stores_whole_window = false;                    /* every IO of [io_out_min, io_out_max] is stored by some chain */
     bool overlap_ok = false;                             /* every cascade of the plan feeds a FIR: its launches may run under the previous block's FIR */
 };
@@ -1526,9 +1570,10 @@ void avdsp_hip_prog_destroy(avdsp_hip_prog *p)
 
 int avdsp_hip_prog_add_plan(avdsp_hip_prog *prog, const avdsp_plan_desc *d)
 {
-    if (d->format != 2 && d->format != 4 && d->format != 6) return set_err("format %d has no device kernels", d->format);
+    if (d->format < 2 || d->format > 6) return set_err("format %d has no device kernels", d->format);
     Plan pl;
     pl.format = d->format; pl.nchains = d->nchains; pl.store_mask = d->store_mask;
+    pl.lane_mode = d->format == 3 || d->format == 5;
     std::vector<avdsp_chain> chains(d->chains, d->chains + d->nchains);
     std::vector<int> coef(d->sec_coef_word, d->sec_coef_word + d->nsections);
     std::vector<int> state(d->sec_state_word, d->sec_state_word + d->nsections);
@@ -1563,6 +1608,10 @@ int avdsp_hip_prog_add_plan(avdsp_hip_prog *prog, const avdsp_plan_desc *d)
         } else if (!c.fir_taps) pass.push_back(i);
     }
     if (upload_vec(&pl.d_chains, chains) || upload_vec(&pl.d_sec_coef, coef) || upload_vec(&pl.d_sec_state, state)) { free_plan(pl); return -1; }
+    if (pl.lane_mode) {                                  /* no launch groups, no rings: chain_lane walks the chain list itself */
+        prog->plans.push_back(pl);
+        return (int)prog->plans.size() - 1;
+    }
     for (auto &e : byN) {                                /* > 64 sections (P = 128): biquad_simple */
         /* lanes per chain: the next power of two -- but a 16-lane row per chain while the chip has SIMDs to spare
          * (<= 1024 waves): its step is shorter (one input batch per 16 steps, no mid-row section-0 lanes: cfg5's
@@ -1912,6 +1961,19 @@ int avdsp_hip_run_block(avdsp_hip_prog *prog, int plan, const void *d_in, int in
             return set_err("sample windows of %d + %d words per frame exceed the interpreter's batch buffer (%d)", in_stride, out_stride, kGenericBatchLds);
         pl.ga.batch_frames = std::max(1, std::min(64, kGenericBatchLds / std::max(1, in_stride + out_stride)));
         return launch_generic(prog, pl, io, (hipStream_t)stream);
+    }
+    if (pl.lane_mode) {
+        ProfileScope scope(prog, (hipStream_t)stream, AVDSP_KERNEL_BIQUAD);
+        LaneArgs a{};
+        a.buf = prog->d_buf; a.chains = pl.d_chains; a.sec_coef = pl.d_sec_coef; a.sec_state = pl.d_sec_state; a.nchains = pl.nchains;
+        a.io.in = (const unsigned *)d_in;  a.io.in_stride = in_stride;   a.io.in_base = in_io_base;
+        a.io.out = (unsigned *)d_out;      a.io.out_stride = out_stride; a.io.out_base = out_io_base;
+        a.io.nframes = nframes; a.io.store_mask = pl.store_mask;
+        const dim3 grid((pl.nchains + 63) / 64), block(64);
+        if (pl.format == 3) hipLaunchKernelGGL(chain_lane<3>, grid, block, 0, (hipStream_t)stream, a);
+        else                hipLaunchKernelGGL(chain_lane<5>, grid, block, 0, (hipStream_t)stream, a);
+        HIP_TRY(hipGetLastError());
+        return 0;
     }
     for (int f0 = 0; f0 < nframes; f0 += kFirChunk) {
         BlockIO io;

@@ -83,8 +83,8 @@ def test_path_selection_and_refusals():
     for name, fmt in (("tour_int.bin", 2), ("tour_float.bin", 3), ("tour_float.bin", 6)):
         r = rt.Runtime(fmt, np.fromfile(os.path.join(GOLDEN_DIR, name), dtype=np.uint32), fs=96000, dither=24)
         assert all(r.core_info(k)["chains"] == 0 for k in range(len(r.cores)))
-    r = rt.Runtime(5, pb.synth_program(6, 4, 2, 7))          # formats 3 and 5: interpreter only
-    assert r.core_info()["chains"] == 0
+    r = rt.Runtime(5, pb.synth_program(6, 4, 2, 7))          # formats 3 and 5: chains too (one lane per chain)
+    assert r.core_info() == dict(chains=4, max_sections=2, max_taps=7)
     r = rt.Runtime(2, pb.synth_program(2, 2, 1, 9))          # FIR in int64 mode: undefined in the reference
     with pytest.raises(rt.AvdspError) as e:
         r.core_info()

@@ -26,7 +26,8 @@ REL_TOL = 1e-6          # north_star: "within 1e-6 relative in its float mode"
 with open(os.path.join(GOLDEN_DIR, "manifest.json")) as _f:
     MANIFEST = json.load(_f)
 
-DEVICE_CASES = [c for c in MANIFEST["cases"] if c["fmt"] in (2, 4, 6) and c["program"]["kind"] == "synth"]
+# chain programs: formats 2, 4, 6 on the pipelined cascade + MFMA FIR, formats 3 and 5 on chain_lane (one lane per chain)
+DEVICE_CASES = [c for c in MANIFEST["cases"] if c["program"]["kind"] == "synth"]
 # the general device interpreter: every committed / reference-encoded program (none of them is a pure
 # set of chains), the random programs of tests/fuzz_programs.py in all five arithmetic models, and the
 # synthetic chain programs forced through it (formats 3 and 5 have no other path);
@@ -435,3 +436,29 @@ def test_north_star_program_sampled_oracle():
         o = po.OracleProgram(6, sub.end_of_code())
         want = o.run_block(np.ascontiguousarray(x[:, c:c + 1]), 1, 1)
         assert_close(np.ascontiguousarray(got[:, c:c + 1]), want, 6, what=f"channel {c}")
+
+
+@pytest.mark.parametrize("fmt", [3, 5])
+@pytest.mark.parametrize("channels,sections,taps", [(1, 1, 0), (70, 5, 0), (130, 16, 33), (9, 0, 120), (3, 24, 7)])
+def test_float_accumulator_models_on_chain_lane(fmt, channels, sections, taps):
+    """DSP_FORMAT 3 and 5 (float accumulator, truncating dspMulFloatFloat): chain programs run one lane per chain; ragged blocks,
+    state carried, and the same chains cut into shards, against the oracle bit for bit."""
+    prog = pb.synth_program(fmt, channels, sections, taps)
+    blocks = [1, 7, 64, 100, 33, 2]
+    x = pb.lcg_input(sum(blocks), channels, fmt == 5, seed=50 + channels)
+    r = _oracle_vs_device(fmt, prog, x, channels, channels, blocks)
+    assert r.core_info()["chains"] == channels
+    if channels >= 3:
+        o = po.OracleProgram(fmt, prog)
+        want = o.run_block(x, channels, channels)
+        r.release()
+        r = rt.Runtime(fmt, prog)
+        got = np.zeros_like(want)
+        for rank in range(3):
+            r.set_shard(rank, 3)
+            info = r.shard_info()
+            lo, n = info["first_chain"], info["nchains"]
+            got[:, lo:lo + n] = r.run_block(np.ascontiguousarray(x[:, lo:lo + n]), n, channels + lo, lo)
+        r.set_shard(0, 1)
+        assert (got.view(np.uint32) == want.view(np.uint32)).all()
+        assert (r.sync_state() == o.state).all()
