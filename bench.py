@@ -321,6 +321,7 @@ def main():
         # SURVEY.md 8(d) algorithmic bytes of one step of THIS rank: samples in+out, biquad state r+w and coefficients,
         # FIR history carry-in/out and taps
         step_bytes = 8.0 * Cl * B + 68.0 * S * Cl + (8.0 * (T - 1) * Cl + 4.0 * T * Cl if T else 0.0)
+        traffic_key = f"{args.workload} shard {args.shard}" if args.shard else (args.workload if world == 1 else None)
         if T and fir_n:
             per_launch = fir_ms / fir_n * 1e-3
             # 2*T flop per sample; the Cl*B samples of a step are spread over fir_n/steps launches
@@ -330,7 +331,7 @@ def main():
             fir_bytes = (4.0 * Cl * B + 4.0 * (T - 1 + B) * Cl + 4.0 * T * Cl) * args.steps / fir_n   # out, window, taps
             roof = dict(bound="mfma", kernel=kname, achieved=ach,
                         peak=PEAK_F64_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_F64_TFLOPS,
-                        traffic=pmc_traffic(args.workload, kname), traffic_source="profiles/traffic.json (committed rocprofv3 --pmc passes of this command, not this run)",
+                        traffic=pmc_traffic(traffic_key, kname), traffic_source="profiles/traffic.json (committed rocprofv3 --pmc passes of this command, not this run)",
                         hbm_frac=fir_bytes / per_launch / 1e9 / PEAK_HBM_GBS,
                         launch_ms=per_launch * 1e3, launches=fir_n)
         elif bq_n:
@@ -340,7 +341,7 @@ def main():
             kname = "biquad_pipe" if args.biquad_impl else "biquad_simple"
             roof = dict(bound="hbm", kernel=kname, achieved=ach,
                         peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS,
-                        traffic=pmc_traffic(args.workload, kname), traffic_source="profiles/traffic.json (committed rocprofv3 --pmc passes of this command, not this run)",
+                        traffic=pmc_traffic(traffic_key, kname), traffic_source="profiles/traffic.json (committed rocprofv3 --pmc passes of this command, not this run)",
                         launch_ms=per_launch * 1e3, launches=bq_n)
         else:
             roof = None
