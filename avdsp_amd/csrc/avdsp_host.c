@@ -86,9 +86,9 @@ static struct {
     int             opt_strand_split, next_tpdf_role;
     int             shard_rank, shard_world;               /* dspRuntimeSetShard: this process's slice of every chain core */
     int             numfreq_at_init;                       /* dspChangeFormat's view of the rate count (see dspRuntimeInit) */
-    int             opt_overlap, opt_bq_block, opt_bq_lds, opt_fir_rows, opt_host_split, opt_host_pin; /* launch arrangement of the chain kernels (avdsp_hip_prog_set_option) */
+    int             opt_overlap, opt_fir_rows, opt_host_split, opt_host_pin; /* launch arrangement of the chain kernels (avdsp_hip_prog_set_option) */
     arrangement     arr[MAX_ARRANGEMENTS]; int arr_next;   /* how the cores / pieces go to the device: [0] whole program, [1..] single cores */
-} G = { .opt_fir_impl = 1, .opt_biquad_impl = 1, .opt_device = -1, .opt_interp_impl = 1, .opt_strand_split = 1, .shard_world = 1, .opt_bq_block = 512, .opt_bq_lds = 140 * 1024 };
+} G = { .opt_fir_impl = 1, .opt_biquad_impl = 1, .opt_device = -1, .opt_interp_impl = 1, .opt_strand_split = 1, .shard_world = 1 };
 
 static char g_err[512];
 static int  g_err_code;
@@ -140,9 +140,9 @@ int dspRuntimeSetOption(const char *key, int value)
     if (!strcmp(key, "generic"))     { G.opt_generic = value; return replan(); }
     if (!strcmp(key, "interp_impl")) { G.opt_interp_impl = value; return replan(); }
     if (!strcmp(key, "strand_split")) { G.opt_strand_split = value; return replan(); }
-    if (!strcmp(key, "overlap") || !strcmp(key, "bq_block") || !strcmp(key, "bq_lds") || !strcmp(key, "fir_rows") || !strcmp(key, "host_split")) {
-        int *slot = key[0] == 'o' ? &G.opt_overlap : key[0] == 'f' ? &G.opt_fir_rows : key[0] == 'h' ? &G.opt_host_split : key[3] == 'b' ? &G.opt_bq_block : &G.opt_bq_lds;
-        const int dev_key = key[0] == 'o' ? AVDSP_OPT_OVERLAP : key[0] == 'f' ? AVDSP_OPT_FIR_ROWS : key[0] == 'h' ? AVDSP_OPT_HOST_SPLIT : key[3] == 'b' ? AVDSP_OPT_BQ_BLOCK : AVDSP_OPT_BQ_LDS;
+    if (!strcmp(key, "overlap") || !strcmp(key, "fir_rows") || !strcmp(key, "host_split")) {
+        int *slot = key[0] == 'o' ? &G.opt_overlap : key[0] == 'f' ? &G.opt_fir_rows : &G.opt_host_split;
+        const int dev_key = key[0] == 'o' ? AVDSP_OPT_OVERLAP : key[0] == 'f' ? AVDSP_OPT_FIR_ROWS : AVDSP_OPT_HOST_SPLIT;
         if (G.dev && avdsp_hip_prog_set_option(G.dev, dev_key, value)) return fail(-10, "%s", avdsp_hip_last_error());
         *slot = value;
         return 0;
@@ -176,8 +176,6 @@ int dspRuntimeGetOption(const char *key)
     if (!strcmp(key, "pieces"))      return G.last_pieces;
     if (!strcmp(key, "strand_split")) return G.opt_strand_split;
     if (!strcmp(key, "overlap"))     return G.opt_overlap;
-    if (!strcmp(key, "bq_block"))    return G.opt_bq_block;
-    if (!strcmp(key, "bq_lds"))      return G.opt_bq_lds;
     if (!strcmp(key, "fir_rows"))    return G.opt_fir_rows;
     if (!strcmp(key, "host_split"))  return G.opt_host_split;
     if (!strcmp(key, "host_pin"))    return G.opt_host_pin;
@@ -1068,8 +1066,7 @@ static core_plan *get_plan_range(int format, opcode_t *core, int end_word)
         }
         G.dev_state_valid = 1;
         avdsp_hip_profile_enable(G.dev, G.opt_profile);
-        if (avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_OVERLAP, G.opt_overlap) || avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_BQ_BLOCK, G.opt_bq_block) ||
-            avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_BQ_LDS, G.opt_bq_lds) || avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_FIR_ROWS, G.opt_fir_rows) ||
+        if (avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_OVERLAP, G.opt_overlap) || avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_FIR_ROWS, G.opt_fir_rows) ||
             avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_HOST_SPLIT, G.opt_host_split) || avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_HOST_PIN, G.opt_host_pin)) {
             fail(-10, "%s", avdsp_hip_last_error()); lowered_free(&L); drop_device(); return 0;
         }

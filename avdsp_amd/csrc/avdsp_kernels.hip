@@ -362,17 +362,13 @@ __device__ void cascade_in_reference_order(const BiquadArgs &a, int cid, const a
     }
 }
 
-/* BLK = threads per workgroup.  256 normally.  1024 for the launches that run UNDER the previous block's FIR
- * (avdsp_hip_run_block, "overlap"): sixteen waves per workgroup, and the launch claims most of a CU's LDS without
- * using it, so that a cascade workgroup has its CU to itself -- its v_fma_f64 chain shares the FP64 datapath with
- * v_mfma_f64 and crawls behind a FIR wave on the same SIMD -- while the FIR keeps every other CU.              */
-template <int FMT, int P, int BLK = kBlock>
-__global__ __launch_bounds__(BLK) void biquad_pipe(const BiquadArgs a)
+template <int FMT, int P>
+__global__ __launch_bounds__(kBlock) void biquad_pipe(const BiquadArgs a)
 {
     if constexpr (FMT != 2) flush_f32_subnormals_like_the_reference();
     using alu_t = typename Alu<FMT>::type;
     constexpr int NB = P < 16 ? P : 16;                 /* steps per IO batch */
-    constexpr int CPB = BLK / P;                        /* chains per block */
+    constexpr int CPB = kBlock / P;                       /* chains per block */
     constexpr int DEPTH = 3;                            /* input batches in flight (the batch loop is unrolled by it) */
     static_assert(DEPTH == 3, "kNext below is written out for three slots");
     const int tid = threadIdx.x, rowpos = tid & 15;
@@ -854,11 +850,12 @@ template <int R> struct TileGeom {
     static constexpr int FW = 256 * R;                       /* frames per wave */
     static constexpr int WPC = 4 / R;                        /* waves per channel and launch */
     static constexpr int QD = 4 * (R - 1);                   /* k-steps a taps operand waits for its last use */
-    static constexpr int CKMAX = R == 4 ? 160 : R == 2 ? 208 : 256;          /* k-steps per chunk, multiple of 16 */
-    static constexpr int ROW = R == 4 ? 27 : R == 2 ? 43 : 81;               /* doubles per window row, odd: >= 16 + ceil(4 (CKMAX-1) / NR) */
-    static constexpr int HLEN = 4 * CKMAX + 16 * (R - 1) + 28;               /* doubles of the taps image (even) */
+    static constexpr int CKMAX = R == 4 ? 96 : R == 2 ? 128 : 160;           /* k-steps per chunk, multiple of 16 */
+    static constexpr int ROW = R == 4 ? 23 : R == 2 ? 33 : 57;               /* doubles per window row, odd: >= 16 + ceil(4 (CKMAX-1) / NR) */
+    static constexpr int HNEED = 4 * CKMAX + 16 * (R - 1) + 28;              /* doubles of a chunk's taps image */
+    static constexpr int HLEN = (HNEED + 127) / 128 * 128;                   /* ... in whole 1-KiB pieces of the LDS-DMA that fills it */
     static constexpr int WLEN = NR * ROW + (NR * ROW & 1);
-    static constexpr int LDS_DOUBLES = HLEN + WLEN;          /* per wave */
+    static constexpr int LDS_DOUBLES = 2 * HLEN + WLEN;      /* per wave: two taps images (one being filled), one window image */
     static constexpr int NW = (NR * ROW + 63) / 64;          /* window elements a lane stages per chunk */
 };
 static_assert(TileGeom<4>::ROW >= 16 + (4 * (TileGeom<4>::CKMAX - 1) + 63) / 64 && TileGeom<2>::ROW >= 16 + (4 * (TileGeom<2>::CKMAX - 1) + 31) / 32 &&
@@ -868,7 +865,15 @@ struct FirTileArgs {
     int *buf; const avdsp_chain *chains; const int *group; int ngroup; Ring ring; int per_xcd;
     const double *taps64; int pitch64;       /* f64 copy of the taps, [chain id][pitch64] */
     BlockIO io;
+#ifdef AVDSP_FIR_STAMPS
+    unsigned long long *stamps;              /* diagnostic build (tools/fir_timeline.py): 32 s_memtime stamps per wave */
+#endif
 };
+#ifdef AVDSP_FIR_STAMPS
+#define FIR_STAMP(i) do { if (lane == 0 && (i) < 30) a.stamps[(size_t)(blockIdx.x * 4 + wv) * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FIR_STAMP(i) do { } while (0)
+#endif
 
 /* one taps double per lane and k-step, the window double of lane (a, k) likewise; offsets inside a group of 16 k-steps */
 template <int R> __device__ __forceinline__ constexpr int win_off(int j)
@@ -905,10 +910,17 @@ __global__ __launch_bounds__(kBlock, 2) void fir_tile(const FirTileArgs a)
     const int unit = blk * 4 + wv;
     const int slot = unit / G::WPC, F0 = (unit % G::WPC) * G::FW;
     if (slot >= a.ngroup || F0 >= B) return;                /* from here on a wave is on its own: no barrier below */
-    const int cid = a.group[slot];
+    FIR_STAMP(0);
+#ifdef AVDSP_FIR_STAMPS
+    if (lane == 0) a.stamps[(size_t)(blockIdx.x * 4 + wv) * 32 + 31] = ((unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) << 32) |
+                                                                       __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));    /* HW_ID | XCC_ID */
+#endif
+    /* the wave's unit -- chain, tap count, ring row, taps -- is the same for all its lanes: say so (scalar registers, scalar
+     * address arithmetic, and loads in the base + 32-bit offset form) */
+    const int cid = __builtin_amdgcn_readfirstlane(a.group[slot]);
     const avdsp_chain c = a.chains[cid];
-    const int T = c.fir_taps;
-    double *hs = lds + (size_t)wv * G::LDS_DOUBLES, *ws = hs + G::HLEN;
+    const int T = __builtin_amdgcn_readfirstlane(c.fir_taps);
+    double *hs = lds + (size_t)wv * G::LDS_DOUBLES, *ws = hs + 2 * G::HLEN;     /* taps images at hs and hs + HLEN */
     const double *hbuf = a.taps64 + (size_t)cid * a.pitch64;
     const float *ringrow = a.ring.base + (size_t)cid * a.ring.R;
     const int rmask = a.ring.R - 1;
@@ -926,40 +938,49 @@ __global__ __launch_bounds__(kBlock, 2) void fir_tile(const FirTileArgs a)
     /* window element e = lane + 64 t of a chunk's image: row e % NR, entry e / NR */
     const int wrow = lane % NR, went = lane / NR;
     float wreg[G::NW];
+    /* The boundary between two chunks is instruction work that the matrix pipe waits for (f64 MFMA and VALU share the datapath:
+     * tools/fir_timeline.py shows the SIMD's two waves taking turns, and every boundary instruction is a cycle the pipe idles),
+     * so a window sample costs two VALU instructions to request (one masked byte offset, one load from a scalar base) and two to
+     * deliver (v_cvt_f64_f32, v_cmp_class).  Round 2's first version spent ~25 on it and 2700 cycles per boundary. */
+    const char *ringbytes = reinterpret_cast<const char *>(ringrow);
+    const unsigned rmaskb = (unsigned)rmask << 2;
     auto win_fetch = [&](int s0, int ckc) {
         const int JT = (4 * (ckc - 1) + NR - 1) / NR;
         /* frame of (row, entry): F0 - 3 + NR (entry + 1 - 4 s0 / NR - JT) + row */
-        const int f0 = F0 - 3 + NR * (went + 1 - 4 * s0 / NR - JT) + wrow;
+        const unsigned b0 = (unsigned)(a.ring.wpos + F0 - 3 + NR * (went + 1 - 4 * s0 / NR - JT) + wrow) << 2;
 #pragma unroll
-        for (int t = 0; t < G::NW; t++) wreg[t] = ringrow[(a.ring.wpos + f0 + 64 * t) & rmask];
+        for (int t = 0; t < G::NW; t++) wreg[t] = *reinterpret_cast<const float *>(ringbytes + ((b0 + 256u * t) & rmaskb));
     };
     auto win_store = [&](double *wdst) {
         double *wp = wdst + wrow * G::ROW + went;
+        bool odd = false;                                   /* NaN, Inf or subnormal among the samples: the reference's bit-field operand */
 #pragma unroll
         for (int t = 0; t < G::NW; t++) {
             if (t * 64 + 63 < NR * G::ROW || lane + t * 64 < NR * G::ROW) {
-                const float v = wreg[t];
-                double d = (double)v;
-                if (__builtin_amdgcn_classf(v, 0x297)) d = mulop(v);      /* NaN, Inf, subnormal: the reference's bit-field operand */
-                wp[t * (64 / NR)] = d;
+                odd |= __builtin_amdgcn_classf(wreg[t], 0x297);
+                wp[t * (64 / NR)] = (double)wreg[t];
             }
         }
-    };
-    auto taps_stage = [&](double *hdst, int s0, int ckc) {
-        /* image u = 0 .. 4 ckc + 16 (R-1) + 27 <- Hbuf[48 - 16 (R-1) + 4 s0 + u]: 16-byte pieces, 64 lanes */
-        const double *src = hbuf + (kTapsLead - 16) - 16 * (R - 1) + 4 * s0;
-        const int np = (4 * ckc + 16 * (R - 1) + 28) / 2;
-        constexpr int NP = (G::HLEN / 2 + 63) / 64;
-        v2f64 piece[NP];
+        if (__builtin_expect(__ballot(odd) != 0, 0)) {      /* (no audio stream gets here) the same again with mulop() */
 #pragma unroll
-        for (int t = 0; t < NP; t++) {
-            const int pi = lane + 64 * t;
-            piece[t] = pi < np ? reinterpret_cast<const v2f64 *>(src)[pi] : v2f64{0.0, 0.0};
+            for (int t = 0; t < G::NW; t++)
+                if (t * 64 + 63 < NR * G::ROW || lane + t * 64 < NR * G::ROW) wp[t * (64 / NR)] = mulop(wreg[t]);
         }
+    };
+    /* A chunk's taps image u = 0 .. 4 ckc + 16 (R-1) + 27 <- Hbuf[48 - 16 (R-1) + 4 s0 + u] is a plain copy (the taps are doubles
+     * already), so it goes by LDS-DMA: 1 KiB per instruction, lane l's 16 bytes to image + 16 l, no registers, nothing to wait for
+     * until the image is read a chunk later.  (Through registers the copy stood in the way: requested at the boundary, its memory
+     * latency was 3000 of a boundary's 4000 cycles, a fifth of a wave's life -- tools/fir_timeline.py; requested a chunk ahead, the
+     * 24-36 registers it held slowed the k-step loop by more than that.) */
+    auto taps_dma = [&](double *hdst, int s0, int ckc) {
+        const char *src = reinterpret_cast<const char *>(hbuf + (kTapsLead - 16) - 16 * (R - 1) + 4 * s0);
+        const int np = (4 * ckc + 16 * (R - 1) + 28) / 2;          /* 16-byte pieces the chunk needs; lanes beyond re-read the last one */
+        __attribute__((address_space(3))) char *dst = (__attribute__((address_space(3))) char *)hdst;
 #pragma unroll
-        for (int t = 0; t < NP; t++) {
+        for (int t = 0; t < G::HLEN / 128; t++) {
             const int pi = lane + 64 * t;
-            if (pi < np) reinterpret_cast<v2f64 *>(hdst)[pi] = piece[t];
+            if (64 * t < np)
+                __builtin_amdgcn_global_load_lds(src + 16 * (pi < np ? pi : np - 1), dst + 1024 * t, 16, 0, 0);
         }
     };
 
@@ -994,25 +1015,38 @@ __global__ __launch_bounds__(kBlock, 2) void fir_tile(const FirTileArgs a)
         kstep(hg, wg, std::integral_constant<int, 14>{}); kstep(hg, wg, std::integral_constant<int, 15>{});
     };
 
-    /* A chunk: write the images (the window samples were requested a chunk ago), request the next chunk's window, run the
-     * k-steps.  While a wave stages, the other wave of its SIMD has the matrix pipe to itself.  (Tried and dropped, both
-     * measured slower: a second pair of images filled in slices between the MFMAs -- the slices' address arithmetic and
-     * conversions cost the f64 matrix pipe more than the stop they replace, fir 83 -> 95 us on a 512-chain shard; and
-     * requesting the taps a chunk ahead into registers as well, 515 -> 539 us on the north-star program.)          */
+    /* A chunk: write the window image (its samples were requested a chunk ago), request the next chunk's window samples and
+     * taps image, run the k-steps.  While a wave is at a boundary the other wave of its SIMD has the matrix pipe to itself.
+     * (Tried and dropped, measured slower: a second WINDOW image filled in slices between the MFMAs -- the slices' address
+     * arithmetic and conversions cost the f64 matrix pipe more than the stop they replace, 83 -> 95 us on a 512-chain shard.) */
     win_fetch(0, min(ck, S));
-    for (int s0 = 0; s0 < S; s0 += ck) {
+    taps_dma(hs, 0, min(ck, S));
+    [[maybe_unused]] int stamp_i = 1;
+    int cur = 0;
+    for (int s0 = 0; s0 < S; s0 += ck, cur ^= 1) {
         const int ckc = min(ck, S - s0);
         const int JT = (4 * (ckc - 1) + NR - 1) / NR;
         __builtin_amdgcn_wave_barrier();
-        win_store(ws);
-        taps_stage(hs, s0, ckc);
+        FIR_STAMP(stamp_i); stamp_i++;
+        if (s0 == ck) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); FIR_STAMP(28); }
+        win_store(ws);                                      /* (waits for the window samples requested a chunk ago) */
+        if (s0 == ck) FIR_STAMP(24);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    /* ... and for this chunk's taps image, in flight since then */
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (s0 + ckc < S) win_fetch(s0 + ckc, min(ck, S - s0 - ckc));
-        const double *hp = hs + k + i16;                                       /* oldest operand of step sc at hp[4 sc] */
+        if (s0 == ck) FIR_STAMP(25);
+        if (s0 + ckc < S) {
+            win_fetch(s0 + ckc, min(ck, S - s0 - ckc));
+            if (s0 == ck) FIR_STAMP(26);
+            taps_dma(hs + (cur ^ 1) * G::HLEN, s0 + ckc, min(ck, S - s0 - ckc));
+        }
+        if (s0 == ck) FIR_STAMP(27);
+        const double *hp = hs + cur * G::HLEN + k + i16;                       /* oldest operand of step sc at hp[4 sc] */
         const double *wp = ws + (3 - k) * G::ROW + i16 + JT - (64 / NR - 1);   /* group g: wp - g * (64 / NR) + win_off(j) */
         chunk_begin(hp, wp);
+        FIR_STAMP(stamp_i); stamp_i++;
         for (int g = 0; g < ckc / 16; g++) group16(hp + 16 * (R - 1) + 64 * g, wp - g * (64 / NR));
+        FIR_STAMP(stamp_i); stamp_i++;
     }
     /* C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg */
 #pragma unroll
@@ -1026,6 +1060,7 @@ __global__ __launch_bounds__(kBlock, 2) void fir_tile(const FirTileArgs a)
                 emit_out(a.io, c, n, word);
             }
         }
+    FIR_STAMP(30);
 }
 
 /* the f64 copy of a chain's taps, made once per plan: Hbuf[j] = mulop(h[j - kTapsLead]), zeros around */
@@ -1273,7 +1308,7 @@ struct avdsp_hip_prog {
     std::vector<hipEvent_t> join;
     hipEvent_t fork = nullptr;
     /* cascade of block k+1 under the FIR of block k ("overlap"): the cascades run on a stream of their own */
-    int overlap = 0, bq_block = 512, bq_lds = 140 * 1024;
+    int overlap = 0;
     int fir_rows = 0;                    /* fir_tile: row tiles per wave (1, 2, 4), 0 = by the number of chains */
     hipStream_t s_bq = nullptr;
     hipEvent_t ev_bq[2] = {nullptr, nullptr}, ev_fir[2] = {nullptr, nullptr};
@@ -1351,29 +1386,9 @@ struct ProfileScope {                   /* records an event pair around the laun
     }
 };
 
-/* the 1024-thread form of the cascade and the LDS it claims (bytes) when it runs under a FIR; opted in per function
- * at plan creation (nothing in the launch path may touch function attributes) */
-/* the cascade in workgroups of 256, 512 or 1024 threads */
-template <int FMT, int BLK>
-const void *biquad_fn(int P)
-{
-    switch (P) {
-    case 8:  return (const void *)biquad_pipe<FMT, 8, BLK>;
-    case 16: return (const void *)biquad_pipe<FMT, 16, BLK>;
-    case 32: return (const void *)biquad_pipe<FMT, 32, BLK>;
-    case 64: return (const void *)biquad_pipe<FMT, 64, BLK>;
-    }
-    return nullptr;
-}
-template <int FMT>
-const void *biquad_big_fn(int P, int blk)
-{
-    return blk == 1024 ? biquad_fn<FMT, 1024>(P) : blk == 512 ? biquad_fn<FMT, 512>(P) : biquad_fn<FMT, kBlock>(P);
-}
-
 template <int FMT>
 int launch_biquad(avdsp_hip_prog *prog, Plan &pl, const Plan::Group &g, const int *ids, int n, BlockIO io,
-                  int biquad_impl, hipStream_t stream, bool under_fir = false)
+                  int biquad_impl, hipStream_t stream)
 {
     ProfileScope scope(prog, stream, AVDSP_KERNEL_BIQUAD);
     BiquadArgs a{};
@@ -1381,15 +1396,6 @@ int launch_biquad(avdsp_hip_prog *prog, Plan &pl, const Plan::Group &g, const in
     a.group = ids; a.ngroup = n; a.nsec = g.nsec; a.ring = plan_ring(pl); a.io = io;
     if (biquad_impl == 0 || g.P > 64) {
         hipLaunchKernelGGL(biquad_simple<FMT>, dim3((n + 63) / 64), dim3(64), 0, stream, a);
-    } else if (under_fir && biquad_big_fn<FMT>(g.P, prog->bq_block)) {
-        /* under the previous block's FIR: workgroups of bq_block threads that claim bq_lds bytes of LDS (unused), so
-         * that no FIR workgroup shares their CU */
-        const int blk = prog->bq_block;
-        const int cpb = blk / g.P;
-        const int nblk = (n + cpb - 1) / cpb;
-        a.per_xcd = (nblk + 7) / 8;
-        void *kargs[] = {(void *)&a};
-        HIP_TRY(hipLaunchKernel(biquad_big_fn<FMT>(g.P, blk), dim3(a.per_xcd * 8), dim3(blk), kargs, (size_t)prog->bq_lds, stream));
     } else {
         const int cpb = kBlock / g.P;
         const int nblk = (n + cpb - 1) / cpb;
@@ -1409,6 +1415,18 @@ int launch_biquad(avdsp_hip_prog *prog, Plan &pl, const Plan::Group &g, const in
     return 0;
 }
 
+#ifdef AVDSP_FIR_STAMPS
+static unsigned long long *g_fir_stamps = nullptr; static int g_fir_stamp_waves = 0;
+extern "C" int avdsp_hip_debug_fir_stamps(unsigned long long *host_out, int max_waves)
+{
+    if (!g_fir_stamps) return 0;
+    const int n = std::min(max_waves, g_fir_stamp_waves);
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpy(host_out, g_fir_stamps, (size_t)n * 32 * 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return n;
+}
+#endif
+
 template <int FMT, int R>
 int launch_fir_tile(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, BlockIO io, hipStream_t stream)
 {
@@ -1419,6 +1437,13 @@ int launch_fir_tile(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, Block
     const int nwg = (n * TileGeom<R>::WPC + 3) / 4;
     a.per_xcd = (nwg + 7) / 8;
     const size_t lds = (size_t)4 * TileGeom<R>::LDS_DOUBLES * sizeof(double);
+#ifdef AVDSP_FIR_STAMPS
+    static unsigned long long *d_stamps = nullptr;
+    if (!d_stamps) { HIP_TRY(hipMalloc((void **)&d_stamps, (size_t)8192 * 4 * 32 * 8)); }
+    HIP_TRY(hipMemsetAsync(d_stamps, 0, (size_t)8192 * 4 * 32 * 8, stream));
+    a.stamps = d_stamps;
+    g_fir_stamps = d_stamps; g_fir_stamp_waves = a.per_xcd * 8 * 4;
+#endif
     hipLaunchKernelGGL((fir_tile<FMT, R>), dim3(a.per_xcd * 8), dim3(kBlock), lds, stream, a);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -1456,20 +1481,20 @@ int launch_fir(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, BlockIO io
     }
 }
 
-/* The cascade and the FIR of a block normally run back to back on the caller's stream.  Running the cascades of one
- * slice of channels underneath the FIR of another slice in the ordinary launch geometry was tried and is 30 % SLOWER:
- * the cascade's v_fma_f64 chain and v_mfma_f64 share the FP64 datapath, so a cascade step behind a saturated matrix
- * pipe waits a whole MFMA per FMA (152 us per quarter instead of 19 us).
+/* The cascade and the FIR of a block normally run back to back on the caller's stream.
  *
- * "overlap" (opt-in, dspRuntimeSetOption): the cascade of block k+1 runs under the FIR of block k after all -- on a
- * stream of its own, in 1024-thread workgroups that each claim a whole CU's LDS, so that cascade waves and FIR waves
- * never share a SIMD: the cascade of a 512-channel shard keeps 8 CUs busy, the FIR the other 248.  The cascade is a
- * latency-bound recurrence (its time hardly depends on the channel count), which is exactly what a strong-scaling
- * rank with few channels cannot afford to run in front of its FIR.  Ordering:
+ * "overlap" (opt-in, dspRuntimeSetOption): the cascade of block k+1 runs under the FIR of block k, on a stream of its
+ * own in its ordinary launch geometry.  The cascade is a latency-bound recurrence -- 8 us + 40 ns per frame whatever the
+ * channel count, a wave issuing 13 instructions per ~100 cycles -- and fir_tile's waves are independent of each other, so
+ * the two share SIMDs well: a SIMD that hosts a cascade wave runs its FIR waves slower for the cascade's duration, the
+ * others not at all, and the step shortens by 5 % (4096 channels on one GPU) to 8 % (a 512-channel shard).  (Round 2
+ * first tried cascade workgroups of 1024 threads that claimed a CU's LDS to keep FIR waves off their CU: sixteen cascade
+ * waves on four SIMDs slow each other 2.5x, and the step got LONGER, 123 -> 147 us on the 512-channel shard.)  Ordering:
  *     cascade k   waits for FIR k-2 (the ring positions it appends are free once that FIR has read its window),
  *                 NOT for the caller's stream -- the mode's contract is that the input block is complete in memory
- *                 when the call is made;
- *     FIR k       on the caller's stream, after cascade k: outputs are ordered on that stream as always.
+ *                 when the call is made (stream order would put it behind FIR k-1, which is the very thing to avoid);
+ *     FIR k       on the caller's stream, after cascade k: outputs are ordered on that stream as always, and so is
+ *                 everything the caller enqueues after the call (it may overwrite the input block).
  * Only when every cascade feeds a FIR (a cascade that stores straight to the output block would write it from the
  * side stream).                                                                                                */
 static int overlap_ready(avdsp_hip_prog *prog)
@@ -1492,7 +1517,7 @@ int launch_all(avdsp_hip_prog *prog, Plan &pl, BlockIO io, int fir_impl, int biq
         const int slot = (int)(prog->blk & 1);
         if (prog->ev_fir_set[slot]) HIP_TRY(hipStreamWaitEvent(prog->s_bq, prog->ev_fir[slot], 0));   /* FIR k-2 */
         for (auto &g : pl.bq)
-            if (launch_biquad<FMT>(prog, pl, g, g.d_ids, g.n, io, biquad_impl, prog->s_bq, true)) return -1;
+            if (launch_biquad<FMT>(prog, pl, g, g.d_ids, g.n, io, biquad_impl, prog->s_bq)) return -1;
         HIP_TRY(hipEventRecord(prog->ev_bq[slot], prog->s_bq));
         HIP_TRY(hipStreamWaitEvent(stream, prog->ev_bq[slot], 0));
         if (launch_fir<FMT>(prog, pl, pl.d_fir_ids, pl.n_fir, io, fir_impl, stream)) return -1;
@@ -1670,15 +1695,6 @@ int avdsp_hip_prog_add_plan(avdsp_hip_prog *prog, const avdsp_plan_desc *d)
     pl.overlap_ok = pl.n_fir > 0 && !pl.bq.empty();
     for (int i = 0; i < d->nchains && pl.overlap_ok; i++)
         if (chains[i].nsec && !chains[i].fir_taps) pl.overlap_ok = false;
-    if (pl.overlap_ok)
-        for (auto &g : pl.bq) {
-            for (int blk : {256, 512, 1024}) {
-                const void *fn = d->format == 4 ? biquad_big_fn<4>(g.P, blk) : biquad_big_fn<6>(g.P, blk);
-                if (!fn) continue;
-                hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                if (e != hipSuccess) { free_plan(pl); return set_err("hipFuncSetAttribute(cascade LDS claim): %s", hipGetErrorString(e)); }
-            }
-        }
     prog->plans.push_back(pl);
     return (int)prog->plans.size() - 1;
 }
@@ -2324,16 +2340,12 @@ int avdsp_hip_prog_set_option(avdsp_hip_prog *prog, int key, int value)
     HIP_TRY(hipDeviceSynchronize());                    /* nothing in flight when the launch arrangement changes */
     switch (key) {
     case AVDSP_OPT_OVERLAP:  prog->overlap = value != 0; prog->ev_fir_set[0] = prog->ev_fir_set[1] = false; return 0;
-    case AVDSP_OPT_BQ_BLOCK: if (value != 256 && value != 512 && value != 1024) return set_err("cascade workgroups have 256, 512 or 1024 threads");
-                             prog->bq_block = value; return 0;
     case AVDSP_OPT_FIR_ROWS: if (value != 0 && value != 1 && value != 2 && value != 4) return set_err("fir_tile row tiles: 0 (auto), 1, 2 or 4");
                              prog->fir_rows = value; return 0;
     case AVDSP_OPT_HOST_SPLIT: if (value < 0) return set_err("host_split: frames per piece, 0 = whole block"); prog->host_split = value; return 0;
     case AVDSP_OPT_HOST_PIN: prog->host_pin = value != 0;
                              if (!value) { for (auto &pn : prog->pinned) if (pn.ours) (void)hipHostUnregister(const_cast<void *>(pn.ptr)); prog->pinned.clear(); }
                              return 0;
-    case AVDSP_OPT_BQ_LDS:   if (value < 0 || value > 160 * 1024) return set_err("LDS claim %d outside [0, 160 KiB]", value);
-                             prog->bq_lds = value; return 0;
     }
     return set_err("unknown device option %d", key);
 }

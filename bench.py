@@ -183,10 +183,8 @@ def main():
     ap.add_argument("--workload", default="north", choices=sorted(WORKLOADS))
     ap.add_argument("--fir-impl", type=int, default=1)
     ap.add_argument("--biquad-impl", type=int, default=1)
-    ap.add_argument("--overlap", type=int, default=-1, help="cascade of the next block under the FIR of this one: 0 off, 1 on, -1 library default")
+    ap.add_argument("--overlap", type=int, default=1, help="cascade of the next block under the FIR of this one (the blocks are resident in HBM, which is that mode's contract): 0 off, 1 on")
     ap.add_argument("--fir-rows", type=int, default=-1, help="fir_tile row tiles per wave: 0 auto, 1, 2, 4")
-    ap.add_argument("--bq-block", type=int, default=-1, help="threads per cascade workgroup under overlap (256 | 1024)")
-    ap.add_argument("--bq-lds", type=int, default=-1, help="bytes of LDS a cascade workgroup claims under overlap")
     ap.add_argument("--shard", default=None, help="RANK/WORLD: run that one shard of the program on this GPU alone (what one rank of a WORLD-GPU job does)")
     ap.add_argument("--host-buffers", action="store_true", help="also time dspRuntimeBlock_N with HOST buffers (PCIe inclusive), reported beside value")
     ap.add_argument("--host-split", type=int, default=-1, help="frames per piece of a host-pointer block (0 = whole block)")
@@ -233,18 +231,13 @@ def main():
     r.set_option("device", device_index)
     r.set_option("fir_impl", args.fir_impl)
     r.set_option("biquad_impl", args.biquad_impl)
-    if args.overlap >= 0:
-        r.set_option("overlap", args.overlap)
+    r.set_option("overlap", 0)
     if args.fir_rows >= 0:
         r.set_option("fir_rows", args.fir_rows)
     if args.host_split >= 0:
         r.set_option("host_split", args.host_split)
     if args.host_pin >= 0:
         r.set_option("host_pin", args.host_pin)
-    if args.bq_block >= 0:
-        r.set_option("bq_block", args.bq_block)
-    if args.bq_lds >= 0:
-        r.set_option("bq_lds", args.bq_lds)
     r.set_option("profile", 1)
     r.set_shard(shard_rank, shard_world)
     info = r.shard_info()
@@ -263,22 +256,28 @@ def main():
     def step():
         r.run_block_device(x.data_ptr(), Cl, in_base, y.data_ptr(), Cl, out_base, B, stream)
 
+    # Every timed launch costs the stream an event pair (a few microseconds each).  In the timed region only the
+    # kernel the roofline is quoted on carries one; the cascade in front of a FIR is timed over a few extra
+    # untimed steps first (kernels_ms.biquad), back to back with the FIR (overlap off), which also gives the FIR
+    # kernel's duration with the chip to itself (roofline.frac_alone).
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
     for k in (0, 1, 2):
         r.kernel_time(k)                                   # drop warm-up launches from the kernel timers
-    # Every timed launch costs the stream an event pair (a few microseconds each).  In the timed region only the
-    # kernel the roofline is quoted on carries one; the cascade in front of a FIR is timed over a few extra
-    # untimed steps first (kernels_ms.biquad).
-    bq_side = None
+    bq_side = fir_alone = None
     if T and S:
-        for _ in range(3):
+        for _ in range(10):
             step()
         torch.cuda.synchronize()
         bq_side = r.kernel_time(0)
-        r.kernel_time(1)
+        fir_alone = r.kernel_time(1)
         r.set_option("profile", 2 * (1 << 1))              # AVDSP_KERNEL_FIR only
+        r.set_option("overlap", args.overlap)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        r.kernel_time(1)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -334,6 +333,10 @@ def main():
                         traffic=pmc_traffic(traffic_key, kname), traffic_source="profiles/traffic.json (committed rocprofv3 --pmc passes of this command, not this run)",
                         hbm_frac=fir_bytes / per_launch / 1e9 / PEAK_HBM_GBS,
                         launch_ms=per_launch * 1e3, launches=fir_n)
+            if fir_alone is not None and fir_alone[1]:
+                # the same kernel without the next block's cascade beside it (10 untimed steps, overlap off)
+                roof["launch_ms_alone"] = fir_alone[0] / fir_alone[1]
+                roof["frac_alone"] = flops / (roof["launch_ms_alone"] * 1e-3) / 1e12 / PEAK_F64_TFLOPS
         elif bq_n:
             per_launch = bq_ms / bq_n * 1e-3
             nbytes = 8.0 * Cl * B + 48.0 * S * Cl + 20.0 * S * Cl   # samples in+out, state r+w, coefficients
