@@ -226,10 +226,18 @@ struct Ring {
     float *base;
     int    R;
     int    wpos;
+    double *wide;       /* the same ring as the FIR's window operand: mulop(sample), doubles, frame n at (wpos + n + 3) & (R-1) */
 };
 __device__ __forceinline__ float *ring_at(const Ring &r, int cid, int q)
 {
     return r.base + (size_t)cid * r.R + ((r.wpos + q) & (r.R - 1));
+}
+/* every writer of the ring goes through here: the float (the reference's delay-line value) and the operand made of it */
+__device__ __forceinline__ void ring_put(const Ring &r, int cid, int q, unsigned bits)
+{
+    const size_t row = (size_t)cid * r.R;
+    r.base[row + ((r.wpos + q) & (r.R - 1))] = __uint_as_float(bits);
+    if (r.wide) r.wide[row + ((r.wpos + q + 3) & (r.R - 1))] = mulop(__uint_as_float(bits));
 }
 
 struct BlockIO {
@@ -357,7 +365,7 @@ __device__ void cascade_in_reference_order(const BiquadArgs &a, int cid, const a
             st[2] = (int)xin; st[3] = (int)x1; st[4] = (int)yn; st[5] = (int)y1;
             xin = yn;
         }
-        if (c.fir_taps) *ring_at(a.ring, cid, n) = __uint_as_float(narrow_stage<FMT>(X));
+        if (c.fir_taps) ring_put(a.ring, cid, n, narrow_stage<FMT>(X));
         else emit_out(a.io, c, n, store_stage<FMT>(X, c.sat, a.io.store_mask));
     }
 }
@@ -587,10 +595,10 @@ __global__ __launch_bounds__(kBlock) void biquad_pipe(const BiquadArgs a)
             if (owner && n >= 0 && n < B) {
                 if constexpr (FMT == 4) {
                     const double X = __longlong_as_double((long long)(((unsigned long long)ob_hi << 32) | ob_lo));
-                    if (oc.fir_taps) *ring_at(a.ring, ocid, n) = __uint_as_float(narrow_stage<FMT>(X));
+                    if (oc.fir_taps) ring_put(a.ring, ocid, n, narrow_stage<FMT>(X));
                     else emit_out(a.io, oc, n, store_stage<FMT>(X, oc.sat, a.io.store_mask));
                 } else if constexpr (FMT == 6) {
-                    if (oc.fir_taps) *ring_at(a.ring, ocid, n) = __uint_as_float(ob_lo);
+                    if (oc.fir_taps) ring_put(a.ring, ocid, n, ob_lo);
                     else emit_out(a.io, oc, n, oc.sat ? __float_as_uint(saturate_f32_0db(__uint_as_float(ob_lo))) : ob_lo);
                 } else
                     emit_out(a.io, oc, n, ob_lo & (unsigned)a.io.store_mask);
@@ -684,7 +692,7 @@ __device__ __forceinline__ void fir_append_input(const FirArgs &a, const avdsp_c
     for (int q = threadIdx.x; q < B; q += blockDim.x) {
         unsigned raw = inp[(size_t)q * a.io.in_stride];
         if constexpr (FMT == 6) raw = ftz_bits(raw);           /* fir_mfma runs in the default MODE: flush by hand */
-        *ring_at(a.ring, cid, q) = __uint_as_float(ftz_bits(narrow_stage<FMT>(load_stage<FMT>(raw, c.load_mode, c.gain_bits))));
+        ring_put(a.ring, cid, q, ftz_bits(narrow_stage<FMT>(load_stage<FMT>(raw, c.load_mode, c.gain_bits))));
     }
     __syncthreads();
 }
@@ -870,7 +878,7 @@ struct FirTileArgs {
 #endif
 };
 #ifdef AVDSP_FIR_STAMPS
-#define FIR_STAMP(i) do { if (lane == 0 && (i) < 30) a.stamps[(size_t)(blockIdx.x * 4 + wv) * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define FIR_STAMP(i) do { if (lane == 0 && (i) <= 30) a.stamps[(size_t)(blockIdx.x * 4 + wv) * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define FIR_STAMP(i) do { } while (0)
 #endif
@@ -1063,6 +1071,236 @@ __global__ __launch_bounds__(kBlock, 2) void fir_tile(const FirTileArgs a)
     FIR_STAMP(30);
 }
 
+
+/* ------------------------------------------------------------------------------------------
+ * fir_stream<FMT, R>: fir_tile's contraction (same tile, same operand order, same accumulators: see there) with NO
+ * instruction work at the chunk boundaries.
+ *
+ * What tools/fir_timeline.py showed of fir_tile: a wave that streams independent f64 MFMAs starves the VALU instructions of
+ * the other wave on its SIMD (v_mfma_f64 and VALU share the datapath and the MFMA stream wins the arbitration), so the ~100
+ * VALU instructions a boundary spent converting and placing window samples took the whole of the partner's k-step phase,
+ * the two waves ran their k-steps strictly in turns, and what was left of the boundary after the partner's last MFMA
+ * (1100-1800 cycles per chunk) was idle matrix pipe: 4-6 % of the kernel at R = 4, plus the 70.8-cycle MFMA cadence of a
+ * lone R = 1 wave.  Here
+ *   - the window operand comes ready-made: every writer of the ring also writes mulop(sample) as a double (Ring::wide),
+ *     so staging a chunk's window is a COPY, like its taps, and both go by LDS-DMA (global_load_lds, 1 KiB per
+ *     instruction, no VGPR, no conversion, nothing to wait for until the chunk starts);
+ *   - the copies of chunk c+1 are issued between the MFMAs of chunk c, three per group of 16 k-steps, into the other
+ *     half of a double-buffered image; a boundary is s_waitcnt vmcnt(0) and the first four operand reads;
+ *   - one wave per SIMD (a workgroup of four waves owns the CU's LDS): nothing shares the matrix pipe with it.
+ * Window image: the B operand of lane (a, k) at k-step s is frame F0 + NR (a+1) - 4 s - k.  In g = frame + 3 the four k
+ * of a step are an aligned quad, and the image is the ring's own order in blocks of NR doubles with 2 doubles of padding
+ * behind each: position(g) = (g - glo) + 2 floor((g - glo) / NR).  Lane (a, k) reads base + (NR + 2) a + 3 - k, the 32
+ * lanes of a ds_read_b64 pass hit 32 different bank pairs ((NR + 2) = 2 mod 32), and inside a group of 16 k-steps every
+ * address is the group's pointer plus an immediate.  The DMA's lane l of piece p copies 16 bytes = image unit U = l + 64 p
+ * = ring doubles glo + 2 (U - U / (NR/2 + 1)) and the next (the ring's g = frame + 3 numbering keeps pairs aligned and
+ * inside the ring).
+ * ---------------------------------------------------------------------------------------- */
+template <int R> struct StreamGeom {
+    static constexpr int NR = 16 * R;
+    static constexpr int FW = 256 * R;                       /* frames per unit (one wave's output tile) */
+    static constexpr int QD = 4 * (R - 1);
+    static constexpr int PD = R == 4 ? 2 : 4;                /* k-steps the operand reads run ahead of their MFMAs (an LDS round trip) */
+    static constexpr int CK = 160;                           /* k-steps per chunk, multiple of 16 */
+    static constexpr int UB = NR / 2 + 1;                    /* 16-byte units per block of the window image */
+    /* units a copy instruction advances the image by: whole blocks where several fit 64 lanes (the source of a lane is then
+     * a per-lane constant plus a per-piece scalar; the lanes past the last whole block copy what the next piece's first
+     * lanes copy, the same bytes to the same place), all 64 lanes at R = 4 (one division per lane and piece) */
+    static constexpr int UP = R == 4 ? 64 : UB * (64 / UB);
+    static constexpr int MAGIC = (65536 + UB - 1) / UB;      /* U / UB == (U * MAGIC) >> 16 for U < 1985 */
+    static constexpr int GS = 64 + 128 / NR;                 /* doubles the window pointer moves per group of 16 k-steps */
+    static constexpr int C60 = (60 + NR - 1) / NR;
+    static constexpr int LOW = 60 + 2 * C60;
+    __host__ __device__ static constexpr int wunits(int ckc) { return UB * (15 + 4 * ckc / NR) + 2; }
+    __host__ __device__ static constexpr int wpieces(int ckc) { return (wunits(ckc) - 64 + UP - 1) / UP + 1; }    /* the last piece ends at or behind the last unit */
+    __host__ __device__ static constexpr int hpieces(int ckc) { return (4 * ckc + 16 * (R - 1) + 28 + 4 * PD + 127) / 128; }
+    static constexpr int WLEN = ((wpieces(CK) - 1) * UP + 64) * 2;   /* doubles of one window image */
+    static constexpr int HLEN = hpieces(CK) * 128;                   /* doubles of one taps image */
+    static constexpr int LDS_DOUBLES = 2 * HLEN + 2 * WLEN;          /* per wave */
+    /* window offset (doubles, >= 0) of k-step j inside a group, from the group's pointer */
+    __host__ __device__ static constexpr int woff(int j) { return 4 * (15 - j) + 2 * (C60 - (4 * j + NR - 1) / NR); }
+};
+static_assert(4 * StreamGeom<4>::LDS_DOUBLES * 8 <= 160 * 1024 && StreamGeom<4>::wpieces(StreamGeom<4>::CK) * 64 < 1985, "fir_stream: a CU's LDS holds four waves");
+static_assert(4 * StreamGeom<2>::LDS_DOUBLES * 8 <= 160 * 1024 && 4 * StreamGeom<1>::LDS_DOUBLES * 8 <= 160 * 1024, "fir_stream: a CU's LDS holds four waves");
+
+/* one unit = (chain, tile of FW frames); everything here is the same in all lanes of the wave */
+struct StreamUnit {
+    int cid, F0, S, ck;                 /* chain, first frame, k-steps (multiple of 16), k-steps per chunk */
+    const double *hbuf;                 /* the chain's taps as doubles */
+    const char *ring8;                  /* the chain's row of the operand ring */
+};
+
+template <int FMT, int R>
+__global__ __launch_bounds__(kBlock, 1) void fir_stream(const FirTileArgs a)
+{
+    using G = StreamGeom<R>;
+    constexpr int NR = G::NR, PD = G::PD;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int B = a.io.nframes;
+    const int tiles = (B + G::FW - 1) / G::FW;               /* units per chain */
+    const int nunits = a.ngroup * tiles;
+    const int nwaves = gridDim.x * 4;
+    int u = xcd_remap(blockIdx.x, a.per_xcd) * 4 + wv;       /* this wave's units: u, u + nwaves, ... */
+    if (u >= nunits) return;                                 /* a wave is on its own: no barrier anywhere */
+    FIR_STAMP(0);
+#ifdef AVDSP_FIR_STAMPS
+    if (lane == 0) a.stamps[(size_t)(blockIdx.x * 4 + wv) * 32 + 31] = ((unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) << 32) |
+                                                                       __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));    /* HW_ID | XCC_ID */
+#endif
+    double *hs = lds + (size_t)wv * G::LDS_DOUBLES, *ws = hs + 2 * G::HLEN;     /* taps images at hs, hs + HLEN; window images at ws, ws + WLEN */
+    const unsigned rmask8 = (unsigned)(a.ring.R - 1) << 3;
+    const int i16 = lane & 15, k = lane >> 4;
+
+    auto unit_of = [&](int uu) {
+        StreamUnit d;
+        const int slot = uu / tiles;
+        d.cid = __builtin_amdgcn_readfirstlane(a.group[slot]);
+        d.F0 = (uu - slot * tiles) * G::FW;
+        const int T = __builtin_amdgcn_readfirstlane(a.chains[d.cid].fir_taps);
+        d.S = (((T + NR + 3) >> 2) + 15) & ~15;              /* k-steps: m_s = -NR + 4 s */
+        const int nch = (d.S + G::CK - 1) / G::CK;
+        d.ck = (((d.S + nch - 1) / nch) + 15) & ~15;
+        d.hbuf = a.taps64 + (size_t)d.cid * a.pitch64;
+        d.ring8 = reinterpret_cast<const char *>(a.ring.wide + (size_t)d.cid * a.ring.R);
+        return d;
+    };
+
+    /* per-lane constants of the copies: the lane's 16 bytes inside a piece */
+    const unsigned lane16 = (unsigned)lane * 16u;
+    [[maybe_unused]] const unsigned rel_lane8 = (2u * ((unsigned)lane - (unsigned)lane / (unsigned)G::UB)) << 3;      /* R < 4: ring bytes of the lane's unit from the piece's first */
+    /* piece p of the copies that chunk (s0, ckc) of unit d needs: window pieces first, then taps pieces */
+    auto copy_piece = [&](int p, int npw, const StreamUnit &d, int s0, int ckc, int buf) {
+        if (p < npw) {
+            const unsigned g0 = (unsigned)(a.ring.wpos + d.F0 + NR - 4 * (s0 + ckc));                  /* ring coordinate of image unit 0 */
+            unsigned off;
+            if constexpr (R == 4) {
+                const unsigned U = (unsigned)lane + 64u * (unsigned)p;
+                const unsigned rel = 2u * (U - ((U * (unsigned)G::MAGIC) >> 16));
+                off = ((g0 + rel) << 3) & rmask8;
+            } else {
+                /* piece p starts at unit p UP = block p (64 / UB): ring doubles g0 + NR p (64 / UB) */
+                off = (((g0 + (unsigned)(NR * (64 / G::UB) * p)) << 3) + rel_lane8) & rmask8;
+            }
+            __attribute__((address_space(3))) char *dst = (__attribute__((address_space(3))) char *)(ws + buf * G::WLEN + 2 * G::UP * p);
+            __builtin_amdgcn_global_load_lds(d.ring8 + off, dst, 16, 0, 0);
+        } else {
+            const int t = p - npw;                             /* (the f64 taps carry kTapsTail zeros: a whole piece may be read) */
+            const char *src = reinterpret_cast<const char *>(d.hbuf + (kTapsLead - 16) - 16 * (R - 1) + 4 * s0 + 128 * t);
+            __attribute__((address_space(3))) char *dst = (__attribute__((address_space(3))) char *)(hs + buf * G::HLEN + 128 * t);
+            __builtin_amdgcn_global_load_lds(src + lane16, dst, 16, 0, 0);
+        }
+    };
+
+    v4f64 acc[R];
+    double q[16], bq[8];
+    auto chunk_begin = [&](const double *hp, const double *wg) {
+#pragma unroll
+        for (int j = 0; j < G::QD; j++) q[(16 - G::QD + j) & 15] = hp[4 * j];
+#pragma unroll
+        for (int j = 0; j < PD; j++) { q[j] = hp[16 * (R - 1) + 4 * j]; bq[j] = wg[G::woff(j)]; }
+    };
+    auto kstep = [&](const double *hg, const double *wg, auto jc) {
+        constexpr int j = decltype(jc)::value;
+        q[(j + PD) & 15] = hg[4 * (j + PD)];
+        bq[(j + PD) & 7] = j + PD < 16 ? wg[G::woff((j + PD) & 15)] : (wg - G::GS)[G::woff((j + PD) & 15)];
+        __builtin_amdgcn_sched_barrier(0);          /* the reads stay PD steps ahead of their MFMAs */
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            acc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(q[(j - 4 * (R - 1 - r)) & 15], bq[j & 7], acc[r], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    /* The wave's units one after the other as ONE sequence of chunks: while a chunk's k-steps run, the copies of the next
+     * chunk -- of this unit, or the first of the next unit -- are issued between the MFMAs, so that a new unit starts
+     * like any other chunk and only the wave's very first chunk waits for memory. */
+    StreamUnit d = unit_of(u);
+    int s0 = 0, ckc = min(d.ck, d.S), cur = 0;
+    {
+        const int npw = G::wpieces(ckc), npa = npw + G::hpieces(ckc);
+        for (int p = 0; p < npa; p++) copy_piece(p, npw, d, 0, ckc, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = v4f64{0.0, 0.0, 0.0, 0.0};
+    [[maybe_unused]] int stamp_i = 1;
+    for (;;) {
+        /* what comes after this chunk */
+        const bool last_of_unit = s0 + ckc >= d.S;
+        const bool more = !last_of_unit || u + nwaves < nunits;
+        StreamUnit dn = d;
+        int ns0 = s0 + ckc, nck = 0;
+        if (!last_of_unit) nck = min(d.ck, d.S - ns0);
+        else if (more) { dn = unit_of(u + nwaves); ns0 = 0; nck = min(dn.ck, dn.S); }
+        const int npw = more ? G::wpieces(nck) : 0, npa = more ? npw + G::hpieces(nck) : 0;
+        int p = 0;
+        FIR_STAMP(stamp_i); stamp_i++;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    /* this chunk's images, requested a chunk ago */
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const double *hp = hs + cur * G::HLEN + k + i16;                                      /* oldest operand of step sc at hp[4 sc] */
+        const double *wg = ws + cur * G::WLEN + (NR + 2) * i16 + 3 - k - G::LOW + (ckc / 16) * G::GS;    /* group 0; group g at wg - g GS */
+        chunk_begin(hp, wg);
+        FIR_STAMP(stamp_i); stamp_i++;
+        for (int g = 0; g < ckc / 16; g++) {
+            const double *hg = hp + 16 * (R - 1) + 64 * g, *wgg = wg - g * G::GS;
+            kstep(hg, wgg, std::integral_constant<int, 0>{});  kstep(hg, wgg, std::integral_constant<int, 1>{});
+            if (p < npa) { copy_piece(p, npw, dn, ns0, nck, cur ^ 1); p++; }
+            __builtin_amdgcn_sched_barrier(0);
+            kstep(hg, wgg, std::integral_constant<int, 2>{});  kstep(hg, wgg, std::integral_constant<int, 3>{});
+            kstep(hg, wgg, std::integral_constant<int, 4>{});  kstep(hg, wgg, std::integral_constant<int, 5>{});
+            kstep(hg, wgg, std::integral_constant<int, 6>{});
+            if (p < npa) { copy_piece(p, npw, dn, ns0, nck, cur ^ 1); p++; }
+            __builtin_amdgcn_sched_barrier(0);
+            kstep(hg, wgg, std::integral_constant<int, 7>{});
+            kstep(hg, wgg, std::integral_constant<int, 8>{});  kstep(hg, wgg, std::integral_constant<int, 9>{});
+            kstep(hg, wgg, std::integral_constant<int, 10>{}); kstep(hg, wgg, std::integral_constant<int, 11>{});
+            if (p < npa) { copy_piece(p, npw, dn, ns0, nck, cur ^ 1); p++; }
+            __builtin_amdgcn_sched_barrier(0);
+            kstep(hg, wgg, std::integral_constant<int, 12>{}); kstep(hg, wgg, std::integral_constant<int, 13>{});
+            kstep(hg, wgg, std::integral_constant<int, 14>{}); kstep(hg, wgg, std::integral_constant<int, 15>{});
+        }
+        FIR_STAMP(stamp_i); stamp_i++;
+        for (; p < npa; p++) copy_piece(p, npw, dn, ns0, nck, cur ^ 1);        /* (a short chunk in front of a long one) */
+        if (last_of_unit) {
+            /* C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg */
+            const avdsp_chain c = a.chains[d.cid];
+#pragma unroll
+            for (int r = 0; r < R; r++)
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    const int n = d.F0 + NR * i16 + 16 * r + 4 * v + k;
+                    if (n < B) {
+                        unsigned word = store_stage<FMT>(acc[r][v], c.sat, a.io.store_mask);
+                        if constexpr (FMT == 6) word = ftz_bits(word);      /* default MODE here: flush the float by hand */
+                        emit_out(a.io, c, n, word);
+                    }
+                    acc[r][v] = 0.0;
+                }
+            if (!more) break;
+            u += nwaves;
+        }
+        d = dn; s0 = ns0; ckc = nck; cur ^= 1;
+    }
+    FIR_STAMP(30);
+}
+
+/* FIR-only chains: the FIR's input is (float)X of the load stage; it is appended to the rings before fir_stream starts
+ * (consecutive threads take consecutive chains: the reads of the interleaved block coalesce) */
+template <int FMT>
+__global__ __launch_bounds__(kBlock) void fir_feed(const FirTileArgs a)
+{
+    const long long total = (long long)a.ngroup * a.io.nframes;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+        const int slot = (int)(g % a.ngroup), n = (int)(g / a.ngroup);
+        const int cid = a.group[slot];
+        const avdsp_chain c = a.chains[cid];
+        if (c.nsec) continue;
+        unsigned raw = a.io.in[(size_t)n * a.io.in_stride + (c.in_io - a.io.in_base)];
+        if constexpr (FMT == 6) raw = ftz_bits(raw);
+        ring_put(a.ring, cid, n, ftz_bits(narrow_stage<FMT>(load_stage<FMT>(raw, c.load_mode, c.gain_bits))));
+    }
+}
+
 /* the f64 copy of a chain's taps, made once per plan: Hbuf[j] = mulop(h[j - kTapsLead]), zeros around */
 struct Taps64Args { const int *buf; const avdsp_chain *chains; const int *group; double *taps64; int pitch64; };
 __global__ __launch_bounds__(kBlock) void taps_to_f64(const Taps64Args a)
@@ -1116,7 +1354,7 @@ __global__ __launch_bounds__(kBlock) void state_to_ring(const RingConvArgs a)
     const int cid = a.group[blockIdx.x];
     const avdsp_chain c = a.chains[cid];
     const float *st = reinterpret_cast<const float *>(a.buf + c.fir_state_word);
-    for (int i = threadIdx.x; i < a.ring.R; i += blockDim.x) *ring_at(a.ring, cid, -1 - i) = i < c.fir_taps ? st[i] : 0.0f;
+    for (int i = threadIdx.x; i < a.ring.R; i += blockDim.x) ring_put(a.ring, cid, -1 - i, i < c.fir_taps ? __float_as_uint(st[i]) : 0u);
 }
 
 /* chains with neither biquads nor FIR: LOAD -> [SAT0DB] -> STORE */
@@ -1273,6 +1511,8 @@ struct Plan {
     int *d_pass_ids = nullptr; int n_pass = 0;
     /* FIR history rings: [nchains][ring_R] floats, frame 0 of the next block goes to index wpos */
     float *d_ring = nullptr; int ring_R = 0, wpos = 0;
+    double *d_ring64 = nullptr;                          /* fir_stream: the ring as window operands (Ring::wide) */
+    int n_fir_only = 0;                                  /* FIR chains without a cascade in front */
     int fir_gpc = 0;                  /* groups of 16 tap positions per LDS chunk */
     int io_in_min = 0, io_in_max = -1, io_out_min = 0, io_out_max = -1;
     bool wave_ok = false; unsigned carried_io[8] = {0, 0, 0, 0, 0, 0, 0, 0};      /* frame-parallel interpreter */
@@ -1294,6 +1534,7 @@ struct avdsp_hip_prog {
     std::vector<Plan> plans;
     unsigned *d_in = nullptr, *d_out = nullptr; size_t in_cap = 0, out_cap = 0;   /* host-call staging */
     /* optional per-kernel timing with HIP events on the launch stream (avdsp_hip_profile_*) */
+    int num_cus = 0;                    /* compute units of the device (fir_stream's grid) */
     unsigned profile = 0;               /* bit k: time the launches of kind k (AVDSP_KERNEL_*) */
     struct Span { int kind; hipEvent_t a, b; };
     std::vector<Span> spans;            /* recorded, not yet read */
@@ -1342,7 +1583,7 @@ void free_plan(Plan &p)
 {
     (void)hipFree(p.d_chains); (void)hipFree(p.d_sec_coef); (void)hipFree(p.d_sec_state);
     for (auto &g : p.bq) (void)hipFree(g.d_ids);
-    (void)hipFree(p.d_fir_ids); (void)hipFree(p.d_pass_ids); (void)hipFree(p.d_ring); (void)hipFree(p.d_own); (void)hipFree(p.d_taps64);
+    (void)hipFree(p.d_fir_ids); (void)hipFree(p.d_pass_ids); (void)hipFree(p.d_ring); (void)hipFree(p.d_ring64); (void)hipFree(p.d_own); (void)hipFree(p.d_taps64);
 }
 
 int fir_groups_per_chunk(int max_taps)
@@ -1360,7 +1601,7 @@ size_t fir_lds_bytes(int gpc, int *hs_cap, int *row)
     return (size_t)(*hs_cap + 16 * *row) * sizeof(double);
 }
 
-Ring plan_ring(const Plan &pl) { return Ring{pl.d_ring, pl.ring_R, pl.wpos}; }
+Ring plan_ring(const Plan &pl) { return Ring{pl.d_ring, pl.ring_R, pl.wpos, pl.d_ring64}; }
 
 hipEvent_t take_event(avdsp_hip_prog *prog)
 {
@@ -1449,6 +1690,35 @@ int launch_fir_tile(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, Block
     return 0;
 }
 
+
+template <int FMT, int R>
+int launch_fir_stream(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, BlockIO io, hipStream_t stream)
+{
+    FirTileArgs a{};
+    a.buf = prog->d_buf; a.chains = pl.d_chains; a.group = ids; a.ngroup = n;
+    a.ring = plan_ring(pl); a.io = io; a.taps64 = pl.d_taps64; a.pitch64 = pl.pitch64;
+    if (pl.n_fir_only) {
+        const long long total = (long long)n * io.nframes;
+        hipLaunchKernelGGL(fir_feed<FMT>, dim3((unsigned)std::min<long long>((total + kBlock - 1) / kBlock, 4096)), dim3(kBlock), 0, stream, a);
+        HIP_TRY(hipGetLastError());
+    }
+    /* one wave per SIMD at most: 256 workgroups of four waves, each wave takes its units in turn */
+    const int tiles = (io.nframes + StreamGeom<R>::FW - 1) / StreamGeom<R>::FW;
+    const int nwg = std::min((n * tiles + 3) / 4, prog->num_cus > 0 ? prog->num_cus : 256);
+    a.per_xcd = (nwg + 7) / 8;
+    const size_t lds = (size_t)4 * StreamGeom<R>::LDS_DOUBLES * sizeof(double);
+#ifdef AVDSP_FIR_STAMPS
+    static unsigned long long *d_stamps = nullptr;
+    if (!d_stamps) { HIP_TRY(hipMalloc((void **)&d_stamps, (size_t)8192 * 4 * 32 * 8)); }
+    HIP_TRY(hipMemsetAsync(d_stamps, 0, (size_t)8192 * 4 * 32 * 8, stream));
+    a.stamps = d_stamps;
+    g_fir_stamps = d_stamps; g_fir_stamp_waves = a.per_xcd * 8 * 4;
+#endif
+    hipLaunchKernelGGL((fir_stream<FMT, R>), dim3(a.per_xcd * 8), dim3(kBlock), lds, stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 /* fir_impl: 0 = fir_plain (the reference's loop), 1 = fir_tile (default), 2 = fir_mfma (round 1's workgroup-per-channel kernel) */
 template <int FMT>
 int launch_fir(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, BlockIO io, int fir_impl, hipStream_t stream)
@@ -1456,6 +1726,16 @@ int launch_fir(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, BlockIO io
     if constexpr (FMT == 2) { (void)prog; (void)pl; (void)ids; (void)n; (void)io; (void)fir_impl; (void)stream; return 0; }
     else {
         ProfileScope scope(prog, stream, AVDSP_KERNEL_FIR);
+        if (fir_impl == 3) {
+            /* row tiles per wave: as many as leave every SIMD a wave (1024) */
+            int rows = prog->fir_rows;
+            const int tiles1 = (io.nframes + 255) / 256;
+            if (rows != 1 && rows != 2 && rows != 4) rows = (long long)n * tiles1 >= 4 * 1024 ? 4 : (long long)n * tiles1 >= 2 * 1024 ? 2 : 1;
+            while (rows > 1 && 128 * rows >= io.nframes) rows >>= 1;
+            return rows == 4 ? launch_fir_stream<FMT, 4>(prog, pl, ids, n, io, stream)
+                 : rows == 2 ? launch_fir_stream<FMT, 2>(prog, pl, ids, n, io, stream)
+                             : launch_fir_stream<FMT, 1>(prog, pl, ids, n, io, stream);
+        }
         if (fir_impl == 1) {
             /* row tiles per wave: as many as leave the chip two waves per SIMD (2048) -- a bigger tile reads fewer operands per MFMA */
             int rows = prog->fir_rows;
@@ -1564,6 +1844,10 @@ avdsp_hip_prog *avdsp_hip_prog_create(int total_words)
 {
     auto *p = new avdsp_hip_prog();
     p->total_words = total_words;
+    {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) p->num_cus = cus;
+    }
     /* + 2 words: the interpreter fetches the two words behind every head word, also behind the last one */
     hipError_t e = hipMalloc((void **)&p->d_buf, ((size_t)(total_words > 0 ? total_words : 1) + 2) * sizeof(int));
     if (e != hipSuccess) { set_err("hipMalloc(mirror, %d words): %s", total_words, hipGetErrorString(e)); delete p; return nullptr; }
@@ -1667,6 +1951,19 @@ int avdsp_hip_prog_add_plan(avdsp_hip_prog *prog, const avdsp_plan_desc *d)
         hipError_t e = hipMalloc((void **)&pl.d_ring, (size_t)d->nchains * pl.ring_R * sizeof(float));
         if (e != hipSuccess) { free_plan(pl); return set_err("hipMalloc(FIR rings, %d x %d): %s", d->nchains, pl.ring_R, hipGetErrorString(e)); }
         pl.wpos = 0;
+        e = hipMalloc((void **)&pl.d_ring64, (size_t)d->nchains * pl.ring_R * sizeof(double));
+        if (e != hipSuccess) { free_plan(pl); return set_err("hipMalloc(FIR operand rings, %d x %d): %s", d->nchains, pl.ring_R, hipGetErrorString(e)); }
+        for (int i = 0; i < d->nchains; i++) pl.n_fir_only += chains[i].fir_taps && !chains[i].nsec;
+        {
+            const void *fns[3] = { d->format == 4 ? (const void *)fir_stream<4, 1> : (const void *)fir_stream<6, 1>,
+                                   d->format == 4 ? (const void *)fir_stream<4, 2> : (const void *)fir_stream<6, 2>,
+                                   d->format == 4 ? (const void *)fir_stream<4, 4> : (const void *)fir_stream<6, 4> };
+            const int flds[3] = { 4 * StreamGeom<1>::LDS_DOUBLES * 8, 4 * StreamGeom<2>::LDS_DOUBLES * 8, 4 * StreamGeom<4>::LDS_DOUBLES * 8 };
+            for (int v = 0; v < 3; v++) {
+                hipError_t e2 = hipFuncSetAttribute(fns[v], hipFuncAttributeMaxDynamicSharedMemorySize, flds[v]);
+                if (e2 != hipSuccess) { free_plan(pl); return set_err("hipFuncSetAttribute(fir_stream LDS %d): %s", flds[v], hipGetErrorString(e2)); }
+            }
+        }
         {   /* fir_tile: LDS opt-in per variant, and the taps as doubles */
             const void *tiles[3] = { d->format == 4 ? (const void *)fir_tile<4, 1> : (const void *)fir_tile<6, 1>,
                                      d->format == 4 ? (const void *)fir_tile<4, 2> : (const void *)fir_tile<6, 2>,

@@ -326,7 +326,7 @@ def main():
             # 2*T flop per sample; the Cl*B samples of a step are spread over fir_n/steps launches
             flops = 2.0 * T * B * Cl * args.steps / fir_n
             ach = flops / per_launch / 1e12
-            kname = {0: "fir_plain", 1: "fir_tile", 2: "fir_mfma"}[args.fir_impl]
+            kname = {0: "fir_plain", 1: "fir_tile", 2: "fir_mfma", 3: "fir_stream"}[args.fir_impl]
             fir_bytes = (4.0 * Cl * B + 4.0 * (T - 1 + B) * Cl + 4.0 * T * Cl) * args.steps / fir_n   # out, window, taps
             roof = dict(bound="mfma", kernel=kname, achieved=ach,
                         peak=PEAK_F64_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_F64_TFLOPS,

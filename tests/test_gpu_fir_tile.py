@@ -41,25 +41,28 @@ def run_vs_oracle(fmt, prog, x, C, blocks, rows, fir_impl=1):
 
 
 ROWS = [1, 2, 4]                 # row tiles per wave
+IMPLS = [3, 1]                   # fir_stream, fir_tile
 
 
+@pytest.mark.parametrize("impl", IMPLS)
 @pytest.mark.parametrize("rows", ROWS)
 @pytest.mark.parametrize("taps", [1, 3, 4, 7, 60, 61, 64, 65, 255, 256, 257, 580, 641, 1000, 1030])
-def test_fir_only_chains_every_row_count(rows, taps):
+def test_fir_only_chains_every_row_count(rows, taps, impl):
     C = 5
     prog = pb.synth_program(6, C, 0, taps)
     blocks = [1024, 1, 37, 256, 257, 700, 1024, 513]
     x = pb.lcg_input(sum(blocks), C, True, seed=taps)
-    run_vs_oracle(6, prog, x, C, blocks, rows)
+    run_vs_oracle(6, prog, x, C, blocks, rows, impl)
 
 
+@pytest.mark.parametrize("impl", IMPLS)
 @pytest.mark.parametrize("rows", ROWS)
 @pytest.mark.parametrize("fmt,C,S,T", [(6, 9, 3, 2048), (6, 3, 16, 4096), (4, 6, 2, 4100), (6, 2, 1, 5000), (4, 4, 0, 2560), (6, 21, 5, 130)])
-def test_long_fir_behind_a_cascade(rows, fmt, C, S, T):
+def test_long_fir_behind_a_cascade(rows, fmt, C, S, T, impl):
     prog = pb.synth_program(fmt, C, S, T)
     blocks = [1024, 1024, 300, 1024, 1024, 1024, 724]
     x = pb.lcg_input(sum(blocks), C, fmt == 6, seed=C + T)
-    run_vs_oracle(fmt, prog, x, C, blocks, rows)
+    run_vs_oracle(fmt, prog, x, C, blocks, rows, impl)
 
 
 @pytest.mark.parametrize("rows", [0] + ROWS)
@@ -72,7 +75,7 @@ def test_many_channels_auto_rows_and_other_kernels_agree(rows):
     x = pb.lcg_input(1024 + 500, C, True, seed=3)
     o = po.OracleProgram(6, prog)
     want = np.concatenate([o.run_block(x[:1024], C, C), o.run_block(x[1024:], C, C)])
-    for impl in ((1, 2, 0) if rows == 0 else (1,)):
+    for impl in ((3, 1, 2, 0) if rows == 0 else (3, 1)):
         r = rt.Runtime(6, prog)
         r.set_option("fir_impl", impl)
         r.set_option("fir_rows", rows)
@@ -92,4 +95,5 @@ def test_nan_inf_and_subnormal_samples_in_the_window():
     xi = x.view(np.uint32)
     xi[5, 0] = 0x7F800000; xi[9, 1] = 0xFFC00001; xi[700, 2] = 0x7F812345; xi[1030, 0] = 0x00000012; xi[1500, 1] = 0x80000400
     for rows in ROWS:
-        run_vs_oracle(6, prog, x, C, [1024, 1024], rows)
+        for impl in IMPLS:
+            run_vs_oracle(6, prog, x, C, [1024, 1024], rows, impl)

@@ -16,6 +16,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("workload", nargs="?", default="north")
 ap.add_argument("--shard", default=None)
 ap.add_argument("--fir-rows", type=int, default=0)
+ap.add_argument("--fir-impl", type=int, default=3)
 args = ap.parse_args()
 
 lib = "/tmp/libavdsp_stamps.so"
@@ -33,6 +34,7 @@ import bench                                                       # noqa: E402
 fmt, Cn, S, T, B = bench.WORKLOADS[args.workload]
 r = rt.Runtime(fmt, pb.synth_program(fmt, Cn, S, T))
 r.set_option("fir_rows", args.fir_rows)
+r.set_option("fir_impl", args.fir_impl)
 if args.shard:
     a, b = (int(v) for v in args.shard.split("/"))
     r.set_shard(a, b)
@@ -52,7 +54,7 @@ st = buf[:n]
 live = st[:, 0] != 0
 st = st[live].astype(np.int64)
 t0 = st[:, 0].min()
-print(f"{args.workload} shard {args.shard}: {Cl} chains, {live.sum()} waves ran; kernel span {(st[:, 30].max() - t0) / 2400:.1f} us (s_memtime at 2.4 GHz)")
+print(f"{args.workload} shard {args.shard}: {Cl} chains, {live.sum()} waves ran (s_memtime taken as 2.4 GHz)")
 nch = int(((st[:, 1:24] != 0).sum(axis=1).max()) // 3)
 stage = np.zeros(len(st)); mfma = np.zeros(len(st))
 for c in range(nch):
@@ -68,6 +70,13 @@ if (st[:, 24] != 0).any():
 life = st[:, 30] - st[:, 0]
 print(f"  per wave: life {np.median(life) / 2400:.1f} us, staging {np.median(stage) / 2400:.1f} us ({100 * np.median(stage / life):.1f} %), k-steps {np.median(mfma) / 2400:.1f} us, "
       f"start spread {(st[:, 0].max() - t0) / 2400:.1f} us, end spread {(st[:, 30].max() - st[:, 30].min()) / 2400:.1f} us")
+xc = st[:, 31] & 7                                    # s_memtime is per XCD: times relative to the XCD's first wave
+rel0 = np.zeros(len(st)); 
+for x_ in np.unique(xc):
+    rel0[xc == x_] = st[xc == x_, 0].min()
+starts = np.sort(st[:, 0] - rel0) / 2400; ends = np.sort(st[:, 30] - rel0) / 2400
+print("  wave starts (us after the first): p10 %.1f p25 %.1f p50 %.1f p75 %.1f p90 %.1f max %.1f;  ends: p10 %.1f p50 %.1f p90 %.1f max %.1f"
+      % (*np.percentile(starts, [10, 25, 50, 75, 90, 100]), *np.percentile(ends, [10, 50, 90, 100])))
 hw = (st[:, 31].astype(np.uint64) >> np.uint64(32)).astype(np.int64)
 simd = (hw >> 4) & 3; cu = (hw >> 8) & 15; sh = (hw >> 12) & 1; se = (hw >> 13) & 7; xcc = st[:, 31] & 7
 key = ((xcc * 8 + se) * 2 + sh) * 16 + cu
