@@ -878,9 +878,13 @@ struct FirTileArgs {
 #endif
 };
 #ifdef AVDSP_FIR_STAMPS
-#define FIR_STAMP(i) do { if (lane == 0 && (i) <= 30) a.stamps[(size_t)(blockIdx.x * 4 + wv) * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define FIR_STAMP(i) do { if (lane == 0 && (i) <= 30) a.stamps[(size_t)(blockIdx.x * 4 + stamp_row) * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define FIR_STAMP_CHUNK() do { if (stamp_i <= 21) FIR_STAMP(stamp_i); stamp_i++; } while (0)   /* three per chunk, the first seven chunks */
+#define FIR_REALTIME(i) do { if (lane == 0) a.stamps[(size_t)(blockIdx.x * 4 + stamp_row) * 32 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define FIR_STAMP(i) do { } while (0)
+#define FIR_STAMP_CHUNK() do { } while (0)
+#define FIR_REALTIME(i) do { } while (0)
 #endif
 
 /* one taps double per lane and k-step, the window double of lane (a, k) likewise; offsets inside a group of 16 k-steps */
@@ -918,7 +922,8 @@ __global__ __launch_bounds__(kBlock, 2) void fir_tile(const FirTileArgs a)
     const int unit = blk * 4 + wv;
     const int slot = unit / G::WPC, F0 = (unit % G::WPC) * G::FW;
     if (slot >= a.ngroup || F0 >= B) return;                /* from here on a wave is on its own: no barrier below */
-    FIR_STAMP(0);
+    [[maybe_unused]] const int stamp_row = wv;
+    FIR_STAMP(0); FIR_REALTIME(29);
 #ifdef AVDSP_FIR_STAMPS
     if (lane == 0) a.stamps[(size_t)(blockIdx.x * 4 + wv) * 32 + 31] = ((unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) << 32) |
                                                                        __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));    /* HW_ID | XCC_ID */
@@ -1035,8 +1040,7 @@ __global__ __launch_bounds__(kBlock, 2) void fir_tile(const FirTileArgs a)
         const int ckc = min(ck, S - s0);
         const int JT = (4 * (ckc - 1) + NR - 1) / NR;
         __builtin_amdgcn_wave_barrier();
-        FIR_STAMP(stamp_i); stamp_i++;
-        if (s0 == ck) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); FIR_STAMP(28); }
+        FIR_STAMP_CHUNK();
         win_store(ws);                                      /* (waits for the window samples requested a chunk ago) */
         if (s0 == ck) FIR_STAMP(24);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    /* ... and for this chunk's taps image, in flight since then */
@@ -1052,9 +1056,9 @@ __global__ __launch_bounds__(kBlock, 2) void fir_tile(const FirTileArgs a)
         const double *hp = hs + cur * G::HLEN + k + i16;                       /* oldest operand of step sc at hp[4 sc] */
         const double *wp = ws + (3 - k) * G::ROW + i16 + JT - (64 / NR - 1);   /* group g: wp - g * (64 / NR) + win_off(j) */
         chunk_begin(hp, wp);
-        FIR_STAMP(stamp_i); stamp_i++;
+        FIR_STAMP_CHUNK();
         for (int g = 0; g < ckc / 16; g++) group16(hp + 16 * (R - 1) + 64 * g, wp - g * (64 / NR));
-        FIR_STAMP(stamp_i); stamp_i++;
+        FIR_STAMP_CHUNK();
     }
     /* C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg */
 #pragma unroll
@@ -1068,7 +1072,7 @@ __global__ __launch_bounds__(kBlock, 2) void fir_tile(const FirTileArgs a)
                 emit_out(a.io, c, n, word);
             }
         }
-    FIR_STAMP(30);
+    FIR_STAMP(30); FIR_REALTIME(28);
 }
 
 
@@ -1120,7 +1124,7 @@ template <int R> struct StreamGeom {
     /* window offset (doubles, >= 0) of k-step j inside a group, from the group's pointer */
     __host__ __device__ static constexpr int woff(int j) { return 4 * (15 - j) + 2 * (C60 - (4 * j + NR - 1) / NR); }
 };
-static_assert(4 * StreamGeom<4>::LDS_DOUBLES * 8 <= 160 * 1024 && StreamGeom<4>::wpieces(StreamGeom<4>::CK) * 64 < 1985, "fir_stream: a CU's LDS holds four waves");
+static_assert(4 * StreamGeom<4>::LDS_DOUBLES * 8 + 64 <= 160 * 1024 && StreamGeom<4>::wpieces(StreamGeom<4>::CK) * 64 < 1985, "fir_stream: a CU's LDS holds four waves");
 static_assert(4 * StreamGeom<2>::LDS_DOUBLES * 8 <= 160 * 1024 && 4 * StreamGeom<1>::LDS_DOUBLES * 8 <= 160 * 1024, "fir_stream: a CU's LDS holds four waves");
 
 /* one unit = (chain, tile of FW frames); everything here is the same in all lanes of the wave */
@@ -1130,8 +1134,10 @@ struct StreamUnit {
     const char *ring8;                  /* the chain's row of the operand ring */
 };
 
+constexpr int kStreamBlock = 512;       /* four consumer waves and four producer waves, one of each per SIMD */
+
 template <int FMT, int R>
-__global__ __launch_bounds__(kBlock, 1) void fir_stream(const FirTileArgs a)
+__global__ __launch_bounds__(kStreamBlock, 1) void fir_stream(const FirTileArgs a)
 {
     using G = StreamGeom<R>;
     constexpr int NR = G::NR, PD = G::PD;
@@ -1140,15 +1146,26 @@ __global__ __launch_bounds__(kBlock, 1) void fir_stream(const FirTileArgs a)
     const int B = a.io.nframes;
     const int tiles = (B + G::FW - 1) / G::FW;               /* units per chain */
     const int nunits = a.ngroup * tiles;
-    const int nwaves = gridDim.x * 4;
-    int u = xcd_remap(blockIdx.x, a.per_xcd) * 4 + wv;       /* this wave's units: u, u + nwaves, ... */
-    if (u >= nunits) return;                                 /* a wave is on its own: no barrier anywhere */
-    FIR_STAMP(0);
-#ifdef AVDSP_FIR_STAMPS
-    if (lane == 0) a.stamps[(size_t)(blockIdx.x * 4 + wv) * 32 + 31] = ((unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) << 32) |
-                                                                       __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));    /* HW_ID | XCC_ID */
-#endif
-    double *hs = lds + (size_t)wv * G::LDS_DOUBLES, *ws = hs + 2 * G::HLEN;     /* taps images at hs, hs + HLEN; window images at ws, ws + WLEN */
+    const int npairs = gridDim.x * 4;
+
+    /* Who is who.  The SIMD's two waves make a pair: the first to register consumes (MFMAs), the second produces (copies).
+     * (Waves of a workgroup are dealt round the four SIMDs; should a workgroup ever come out uneven, wave w pairs with w + 4.) */
+    int *ctl = reinterpret_cast<int *>(lds + (size_t)4 * G::LDS_DOUBLES);        /* [0..3] waves per SIMD, [4 + 2 pair] filled, [5 + 2 pair] consumed */
+    if (threadIdx.x < 16) ctl[threadIdx.x] = 0;
+    __syncthreads();
+    const int simd = (__builtin_amdgcn_s_getreg((4 << 0) | (4 << 6) | (1 << 11))) & 3;      /* HW_ID.SIMD_ID */
+    int myslot = 0;
+    if (lane == 0) myslot = atomicAdd(&ctl[simd], 1);
+    myslot = __builtin_amdgcn_readfirstlane(myslot);
+    __syncthreads();
+    const bool even = ctl[0] == 2 && ctl[1] == 2 && ctl[2] == 2 && ctl[3] == 2;
+    const int pair = __builtin_amdgcn_readfirstlane(even ? simd : (wv & 3));
+    const bool producer = __builtin_amdgcn_readfirstlane(even ? myslot : (wv >> 2)) != 0;
+    int *filled = ctl + 4 + 2 * pair, *consumed = filled + 1;                    /* chunks copied / chunks multiplied, of the pair's sequence */
+
+    int u = xcd_remap(blockIdx.x, a.per_xcd) * 4 + pair;     /* the pair's units: u, u + npairs, ... */
+    if (u >= nunits) return;                                 /* (both waves of the pair; no barrier below) */
+    double *hs = lds + (size_t)pair * G::LDS_DOUBLES, *ws = hs + 2 * G::HLEN;   /* taps images at hs, hs + HLEN; window images at ws, ws + WLEN */
     const unsigned rmask8 = (unsigned)(a.ring.R - 1) << 3;
     const int i16 = lane & 15, k = lane >> 4;
 
@@ -1165,33 +1182,64 @@ __global__ __launch_bounds__(kBlock, 1) void fir_stream(const FirTileArgs a)
         d.ring8 = reinterpret_cast<const char *>(a.ring.wide + (size_t)d.cid * a.ring.R);
         return d;
     };
-
-    /* per-lane constants of the copies: the lane's 16 bytes inside a piece */
-    const unsigned lane16 = (unsigned)lane * 16u;
-    [[maybe_unused]] const unsigned rel_lane8 = (2u * ((unsigned)lane - (unsigned)lane / (unsigned)G::UB)) << 3;      /* R < 4: ring bytes of the lane's unit from the piece's first */
-    /* piece p of the copies that chunk (s0, ckc) of unit d needs: window pieces first, then taps pieces */
-    auto copy_piece = [&](int p, int npw, const StreamUnit &d, int s0, int ckc, int buf) {
-        if (p < npw) {
-            const unsigned g0 = (unsigned)(a.ring.wpos + d.F0 + NR - 4 * (s0 + ckc));                  /* ring coordinate of image unit 0 */
-            unsigned off;
-            if constexpr (R == 4) {
-                const unsigned U = (unsigned)lane + 64u * (unsigned)p;
-                const unsigned rel = 2u * (U - ((U * (unsigned)G::MAGIC) >> 16));
-                off = ((g0 + rel) << 3) & rmask8;
-            } else {
-                /* piece p starts at unit p UP = block p (64 / UB): ring doubles g0 + NR p (64 / UB) */
-                off = (((g0 + (unsigned)(NR * (64 / G::UB) * p)) << 3) + rel_lane8) & rmask8;
-            }
-            __attribute__((address_space(3))) char *dst = (__attribute__((address_space(3))) char *)(ws + buf * G::WLEN + 2 * G::UP * p);
-            __builtin_amdgcn_global_load_lds(d.ring8 + off, dst, 16, 0, 0);
-        } else {
-            const int t = p - npw;                             /* (the f64 taps carry kTapsTail zeros: a whole piece may be read) */
-            const char *src = reinterpret_cast<const char *>(d.hbuf + (kTapsLead - 16) - 16 * (R - 1) + 4 * s0 + 128 * t);
-            __attribute__((address_space(3))) char *dst = (__attribute__((address_space(3))) char *)(hs + buf * G::HLEN + 128 * t);
-            __builtin_amdgcn_global_load_lds(src + lane16, dst, 16, 0, 0);
-        }
+    auto flag_wait = [&](int *flag, int need) {
+        while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < need) __builtin_amdgcn_s_sleep(4);
+    };
+    auto flag_set = [&](int *flag, int v) {
+        if (lane == 0) __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
 
+    if (producer) {
+        /* ---- the copies: chunk n of the pair's sequence goes to image n & 1 once chunk n - 2 has been multiplied ---- */
+        const unsigned lane16 = (unsigned)lane * 16u;
+        constexpr int WPMAX = G::wpieces(G::CK);
+        /* ring bytes of the lane's unit in piece p, from the image's first unit */
+        unsigned rel8[R == 4 ? WPMAX : 1];
+        if constexpr (R == 4) {
+#pragma unroll
+            for (int p = 0; p < WPMAX; p++) {
+                const unsigned U = (unsigned)lane + 64u * (unsigned)p;
+                rel8[p] = (2u * (U - ((U * (unsigned)G::MAGIC) >> 16))) << 3;
+            }
+        } else
+            rel8[0] = (2u * ((unsigned)lane - (unsigned)lane / (unsigned)G::UB)) << 3;
+        int n = 0;
+        for (; u < nunits; u += npairs) {
+            const StreamUnit d = unit_of(u);
+            for (int s0 = 0; s0 < d.S; s0 += d.ck, n++) {
+                const int ckc = min(d.ck, d.S - s0);
+                const int npw = G::wpieces(ckc), nph = G::hpieces(ckc);
+                if (n >= 2) flag_wait(consumed, n - 1);
+                double *wdst = ws + (n & 1) * G::WLEN, *hdst = hs + (n & 1) * G::HLEN;
+                const unsigned g08 = (unsigned)(a.ring.wpos + d.F0 + NR - 4 * (s0 + ckc)) << 3;      /* ring byte of image unit 0 */
+#pragma unroll
+                for (int p = 0; p < WPMAX; p++)
+                    if (p < npw) {
+                        unsigned off;
+                        if constexpr (R == 4) off = (g08 + rel8[p]) & rmask8;
+                        else off = (g08 + (unsigned)(8 * NR * (64 / G::UB) * p) + rel8[0]) & rmask8;    /* piece p starts at block p (64 / UB) */
+                        __builtin_amdgcn_global_load_lds(d.ring8 + off, (__attribute__((address_space(3))) char *)(wdst + 2 * G::UP * p), 16, 0, 0);
+                    }
+                /* (the f64 taps carry kTapsTail zeros: a whole piece may be read) */
+                const char *src = reinterpret_cast<const char *>(d.hbuf + (kTapsLead - 16) - 16 * (R - 1) + 4 * s0);
+#pragma unroll
+                for (int t = 0; t < G::hpieces(G::CK); t++)
+                    if (t < nph)
+                        __builtin_amdgcn_global_load_lds(src + 1024 * t + lane16, (__attribute__((address_space(3))) char *)(hdst + 128 * t), 16, 0, 0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                flag_set(filled, n + 1);
+            }
+        }
+        return;
+    }
+
+    /* ---- the contraction ---- */
+    [[maybe_unused]] const int stamp_row = pair;
+    FIR_STAMP(0); FIR_REALTIME(29);
+#ifdef AVDSP_FIR_STAMPS
+    if (lane == 0) a.stamps[(size_t)(blockIdx.x * 4 + pair) * 32 + 31] = ((unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) << 32) |
+                                                                         __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));    /* HW_ID | XCC_ID */
+#endif
     v4f64 acc[R];
     double q[16], bq[8];
     auto chunk_begin = [&](const double *hp, const double *wg) {
@@ -1210,78 +1258,53 @@ __global__ __launch_bounds__(kBlock, 1) void fir_stream(const FirTileArgs a)
             acc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(q[(j - 4 * (R - 1 - r)) & 15], bq[j & 7], acc[r], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     };
-
-    /* The wave's units one after the other as ONE sequence of chunks: while a chunk's k-steps run, the copies of the next
-     * chunk -- of this unit, or the first of the next unit -- are issued between the MFMAs, so that a new unit starts
-     * like any other chunk and only the wave's very first chunk waits for memory. */
-    StreamUnit d = unit_of(u);
-    int s0 = 0, ckc = min(d.ck, d.S), cur = 0;
-    {
-        const int npw = G::wpieces(ckc), npa = npw + G::hpieces(ckc);
-        for (int p = 0; p < npa; p++) copy_piece(p, npw, d, 0, ckc, 0);
-    }
-#pragma unroll
-    for (int r = 0; r < R; r++) acc[r] = v4f64{0.0, 0.0, 0.0, 0.0};
     [[maybe_unused]] int stamp_i = 1;
-    for (;;) {
-        /* what comes after this chunk */
-        const bool last_of_unit = s0 + ckc >= d.S;
-        const bool more = !last_of_unit || u + nwaves < nunits;
-        StreamUnit dn = d;
-        int ns0 = s0 + ckc, nck = 0;
-        if (!last_of_unit) nck = min(d.ck, d.S - ns0);
-        else if (more) { dn = unit_of(u + nwaves); ns0 = 0; nck = min(dn.ck, dn.S); }
-        const int npw = more ? G::wpieces(nck) : 0, npa = more ? npw + G::hpieces(nck) : 0;
-        int p = 0;
-        FIR_STAMP(stamp_i); stamp_i++;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    /* this chunk's images, requested a chunk ago */
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const double *hp = hs + cur * G::HLEN + k + i16;                                      /* oldest operand of step sc at hp[4 sc] */
-        const double *wg = ws + cur * G::WLEN + (NR + 2) * i16 + 3 - k - G::LOW + (ckc / 16) * G::GS;    /* group 0; group g at wg - g GS */
-        chunk_begin(hp, wg);
-        FIR_STAMP(stamp_i); stamp_i++;
-        for (int g = 0; g < ckc / 16; g++) {
-            const double *hg = hp + 16 * (R - 1) + 64 * g, *wgg = wg - g * G::GS;
-            kstep(hg, wgg, std::integral_constant<int, 0>{});  kstep(hg, wgg, std::integral_constant<int, 1>{});
-            if (p < npa) { copy_piece(p, npw, dn, ns0, nck, cur ^ 1); p++; }
-            __builtin_amdgcn_sched_barrier(0);
-            kstep(hg, wgg, std::integral_constant<int, 2>{});  kstep(hg, wgg, std::integral_constant<int, 3>{});
-            kstep(hg, wgg, std::integral_constant<int, 4>{});  kstep(hg, wgg, std::integral_constant<int, 5>{});
-            kstep(hg, wgg, std::integral_constant<int, 6>{});
-            if (p < npa) { copy_piece(p, npw, dn, ns0, nck, cur ^ 1); p++; }
-            __builtin_amdgcn_sched_barrier(0);
-            kstep(hg, wgg, std::integral_constant<int, 7>{});
-            kstep(hg, wgg, std::integral_constant<int, 8>{});  kstep(hg, wgg, std::integral_constant<int, 9>{});
-            kstep(hg, wgg, std::integral_constant<int, 10>{}); kstep(hg, wgg, std::integral_constant<int, 11>{});
-            if (p < npa) { copy_piece(p, npw, dn, ns0, nck, cur ^ 1); p++; }
-            __builtin_amdgcn_sched_barrier(0);
-            kstep(hg, wgg, std::integral_constant<int, 12>{}); kstep(hg, wgg, std::integral_constant<int, 13>{});
-            kstep(hg, wgg, std::integral_constant<int, 14>{}); kstep(hg, wgg, std::integral_constant<int, 15>{});
+    int n = 0;
+    for (; u < nunits; u += npairs) {
+        const StreamUnit d = unit_of(u);
+        const avdsp_chain c = a.chains[d.cid];
+#pragma unroll
+        for (int r = 0; r < R; r++) acc[r] = v4f64{0.0, 0.0, 0.0, 0.0};
+        if (n == 0) FIR_STAMP(24);
+        for (int s0 = 0; s0 < d.S; s0 += d.ck, n++) {
+            const int ckc = min(d.ck, d.S - s0);
+            FIR_STAMP_CHUNK();
+            flag_wait(filled, n + 1);
+            const double *hp = hs + (n & 1) * G::HLEN + k + i16;                                      /* oldest operand of step sc at hp[4 sc] */
+            const double *wg = ws + (n & 1) * G::WLEN + (NR + 2) * i16 + 3 - k - G::LOW + (ckc / 16) * G::GS;    /* group 0; group g at wg - g GS */
+            chunk_begin(hp, wg);
+            FIR_STAMP_CHUNK();
+            for (int g = 0; g < ckc / 16; g++) {
+                const double *hg = hp + 16 * (R - 1) + 64 * g, *wgg = wg - g * G::GS;
+                kstep(hg, wgg, std::integral_constant<int, 0>{});  kstep(hg, wgg, std::integral_constant<int, 1>{});
+                kstep(hg, wgg, std::integral_constant<int, 2>{});  kstep(hg, wgg, std::integral_constant<int, 3>{});
+                kstep(hg, wgg, std::integral_constant<int, 4>{});  kstep(hg, wgg, std::integral_constant<int, 5>{});
+                kstep(hg, wgg, std::integral_constant<int, 6>{});  kstep(hg, wgg, std::integral_constant<int, 7>{});
+                kstep(hg, wgg, std::integral_constant<int, 8>{});  kstep(hg, wgg, std::integral_constant<int, 9>{});
+                kstep(hg, wgg, std::integral_constant<int, 10>{}); kstep(hg, wgg, std::integral_constant<int, 11>{});
+                kstep(hg, wgg, std::integral_constant<int, 12>{}); kstep(hg, wgg, std::integral_constant<int, 13>{});
+                kstep(hg, wgg, std::integral_constant<int, 14>{}); kstep(hg, wgg, std::integral_constant<int, 15>{});
+            }
+            FIR_STAMP_CHUNK();
+            flag_set(consumed, n + 1);
         }
-        FIR_STAMP(stamp_i); stamp_i++;
-        for (; p < npa; p++) copy_piece(p, npw, dn, ns0, nck, cur ^ 1);        /* (a short chunk in front of a long one) */
-        if (last_of_unit) {
-            /* C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg */
-            const avdsp_chain c = a.chains[d.cid];
+        /* C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg */
+        const bool first_unit = n * 1 == (d.S + d.ck - 1) / d.ck;
+        if (first_unit) FIR_STAMP(25);
 #pragma unroll
-            for (int r = 0; r < R; r++)
+        for (int r = 0; r < R; r++)
 #pragma unroll
-                for (int v = 0; v < 4; v++) {
-                    const int n = d.F0 + NR * i16 + 16 * r + 4 * v + k;
-                    if (n < B) {
-                        unsigned word = store_stage<FMT>(acc[r][v], c.sat, a.io.store_mask);
-                        if constexpr (FMT == 6) word = ftz_bits(word);      /* default MODE here: flush the float by hand */
-                        emit_out(a.io, c, n, word);
-                    }
-                    acc[r][v] = 0.0;
+            for (int v = 0; v < 4; v++) {
+                const int nn = d.F0 + NR * i16 + 16 * r + 4 * v + k;
+                if (nn < B) {
+                    unsigned word = store_stage<FMT>(acc[r][v], c.sat, a.io.store_mask);
+                    if constexpr (FMT == 6) word = ftz_bits(word);      /* default MODE here: flush the float by hand */
+                    emit_out(a.io, c, nn, word);
                 }
-            if (!more) break;
-            u += nwaves;
-        }
-        d = dn; s0 = ns0; ckc = nck; cur ^= 1;
+            }
+        if (first_unit) FIR_STAMP(26);
     }
-    FIR_STAMP(30);
+    FIR_STAMP(30); FIR_REALTIME(28);
 }
 
 /* FIR-only chains: the FIR's input is (float)X of the load stage; it is appended to the rings before fir_stream starts
@@ -1706,7 +1729,7 @@ int launch_fir_stream(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, Blo
     const int tiles = (io.nframes + StreamGeom<R>::FW - 1) / StreamGeom<R>::FW;
     const int nwg = std::min((n * tiles + 3) / 4, prog->num_cus > 0 ? prog->num_cus : 256);
     a.per_xcd = (nwg + 7) / 8;
-    const size_t lds = (size_t)4 * StreamGeom<R>::LDS_DOUBLES * sizeof(double);
+    const size_t lds = (size_t)4 * StreamGeom<R>::LDS_DOUBLES * sizeof(double) + 64;
 #ifdef AVDSP_FIR_STAMPS
     static unsigned long long *d_stamps = nullptr;
     if (!d_stamps) { HIP_TRY(hipMalloc((void **)&d_stamps, (size_t)8192 * 4 * 32 * 8)); }
@@ -1714,7 +1737,7 @@ int launch_fir_stream(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, Blo
     a.stamps = d_stamps;
     g_fir_stamps = d_stamps; g_fir_stamp_waves = a.per_xcd * 8 * 4;
 #endif
-    hipLaunchKernelGGL((fir_stream<FMT, R>), dim3(a.per_xcd * 8), dim3(kBlock), lds, stream, a);
+    hipLaunchKernelGGL((fir_stream<FMT, R>), dim3(a.per_xcd * 8), dim3(kStreamBlock), lds, stream, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1958,7 +1981,7 @@ int avdsp_hip_prog_add_plan(avdsp_hip_prog *prog, const avdsp_plan_desc *d)
             const void *fns[3] = { d->format == 4 ? (const void *)fir_stream<4, 1> : (const void *)fir_stream<6, 1>,
                                    d->format == 4 ? (const void *)fir_stream<4, 2> : (const void *)fir_stream<6, 2>,
                                    d->format == 4 ? (const void *)fir_stream<4, 4> : (const void *)fir_stream<6, 4> };
-            const int flds[3] = { 4 * StreamGeom<1>::LDS_DOUBLES * 8, 4 * StreamGeom<2>::LDS_DOUBLES * 8, 4 * StreamGeom<4>::LDS_DOUBLES * 8 };
+            const int flds[3] = { 4 * StreamGeom<1>::LDS_DOUBLES * 8 + 64, 4 * StreamGeom<2>::LDS_DOUBLES * 8 + 64, 4 * StreamGeom<4>::LDS_DOUBLES * 8 + 64 };
             for (int v = 0; v < 3; v++) {
                 hipError_t e2 = hipFuncSetAttribute(fns[v], hipFuncAttributeMaxDynamicSharedMemorySize, flds[v]);
                 if (e2 != hipSuccess) { free_plan(pl); return set_err("hipFuncSetAttribute(fir_stream LDS %d): %s", flds[v], hipGetErrorString(e2)); }

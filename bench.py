@@ -189,6 +189,8 @@ def main():
     ap.add_argument("--host-buffers", action="store_true", help="also time dspRuntimeBlock_N with HOST buffers (PCIe inclusive), reported beside value")
     ap.add_argument("--host-split", type=int, default=-1, help="frames per piece of a host-pointer block (0 = whole block)")
     ap.add_argument("--host-pin", type=int, default=-1, help="pin the host buffers in place (bench.py keeps them allocated)")
+    ap.add_argument("--settle", type=float, default=0.5, help="seconds of untimed steps in front of the warm-up: the chip raises its clock over the first ~0.1 s of load "
+                    "(tools/fir_timeline.py: 2.15 GHz in-kernel after 6 blocks, 2.36 GHz after 200) and a short run would be timed on the ramp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -260,6 +262,13 @@ def main():
     # kernel the roofline is quoted on carries one; the cascade in front of a FIR is timed over a few extra
     # untimed steps first (kernels_ms.biquad), back to back with the FIR (overlap off), which also gives the FIR
     # kernel's duration with the chip to itself (roofline.frac_alone).
+    r.set_option("profile", 0)
+    t_settle = time.perf_counter()
+    while time.perf_counter() - t_settle < args.settle:
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
+    r.set_option("profile", 1)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -358,7 +367,7 @@ def main():
             "config": {"workload": f"{args.workload}: {C} ch x ({S} biquads + {T}-tap FIR), block {B} frames, "
                                    f"DSP_FORMAT {fmt}; {shard_txt}, no data-path collective",
                        "channels": C, "channels_per_gpu": Cl, "sections": S, "taps": T, "block": B, "format": fmt,
-                       "overlap": r.get_option("overlap")},
+                       "overlap": r.get_option("overlap"), "settle_s": args.settle},
             "roofline": roof,
             "hbm_frac_step": step_bytes / step_s / 1e9 / PEAK_HBM_GBS,
             "kernels_ms": {"biquad": bq_ms / max(bq_n, 1), "fir": fir_ms / max(fir_n, 1)},

@@ -17,6 +17,7 @@ ap.add_argument("workload", nargs="?", default="north")
 ap.add_argument("--shard", default=None)
 ap.add_argument("--fir-rows", type=int, default=0)
 ap.add_argument("--fir-impl", type=int, default=3)
+ap.add_argument("--blocks", type=int, default=6, help="blocks run before the one that is summarised")
 args = ap.parse_args()
 
 lib = "/tmp/libavdsp_stamps.so"
@@ -42,7 +43,7 @@ info = r.shard_info()
 Cl = info["nchains"]
 x = torch.from_numpy(np.ascontiguousarray(pb.lcg_input(B, Cn, fmt == 6)[:, info["in_io_min"] - Cn:info["in_io_min"] - Cn + Cl])).cuda()
 y = torch.zeros((B, Cl), dtype=x.dtype, device="cuda")
-for _ in range(6):
+for _ in range(args.blocks):
     r.run_block_device(x.data_ptr(), Cl, info["in_io_min"], y.data_ptr(), Cl, info["out_io_min"], B, 0)
 torch.cuda.synchronize()
 L = rt.lib()
@@ -55,28 +56,32 @@ live = st[:, 0] != 0
 st = st[live].astype(np.int64)
 t0 = st[:, 0].min()
 print(f"{args.workload} shard {args.shard}: {Cl} chains, {live.sum()} waves ran (s_memtime taken as 2.4 GHz)")
-nch = int(((st[:, 1:24] != 0).sum(axis=1).max()) // 3)
+nch = int(((st[:, 1:22] != 0).sum(axis=1).max()) // 3)
 stage = np.zeros(len(st)); mfma = np.zeros(len(st))
 for c in range(nch):
     b, m0, m1 = st[:, 1 + 3 * c], st[:, 2 + 3 * c], st[:, 3 + 3 * c]
     ok = m1 != 0
     stage[ok] += (m0 - b)[ok]; mfma[ok] += (m1 - m0)[ok]
     print(f"  chunk {c}: staging {np.median((m0 - b)[ok]):8.0f} cycles (p90 {np.percentile((m0 - b)[ok], 90):8.0f})   k-steps {np.median((m1 - m0)[ok]):8.0f} cycles (p90 {np.percentile((m1 - m0)[ok], 90):8.0f})")
-if (st[:, 24] != 0).any():
+if args.fir_impl == 3 and (st[:, 26] != 0).any():
+    ok = st[:, 26] != 0
+    print("  first unit: start -> unit known %.0f cycles, -> first chunk's operands ready %.0f;  epilogue (convert and store the tile) %.0f cycles"
+          % (np.median(st[ok, 24] - st[ok, 0]), np.median(st[ok, 2] - st[ok, 0]), np.median(st[ok, 26] - st[ok, 25])))
+elif (st[:, 24] != 0).any():
     ok = st[:, 27] != 0
     b = st[ok, 4]                                    # start of chunk 1's boundary
     print("  chunk 1's boundary: requested data landed +%.0f, window image written +%.0f, taps image landed +%.0f, next window requested +%.0f, next taps requested +%.0f, first operands read +%.0f cycles"
-          % tuple(np.median(st[ok, i] - b) for i in (28, 24, 25, 26, 27, 5)))
+          % tuple(np.median(st[ok, i] - b) for i in (4, 24, 25, 26, 27, 5)))
 life = st[:, 30] - st[:, 0]
+rt_ = (st[:, 28] - st[:, 29]).astype(np.float64)
+okc = rt_ > 0
+clk = life[okc] / rt_[okc] * 100e6
+print(f"  in-kernel clock (s_memtime / s_memrealtime x 100 MHz over a wave's life): median {np.median(clk) / 1e9:.3f} GHz, p10 {np.percentile(clk, 10) / 1e9:.3f}, p90 {np.percentile(clk, 90) / 1e9:.3f};  wave life by the 100 MHz clock: median {np.median(rt_[okc]) / 100:.1f} us")
 print(f"  per wave: life {np.median(life) / 2400:.1f} us, staging {np.median(stage) / 2400:.1f} us ({100 * np.median(stage / life):.1f} %), k-steps {np.median(mfma) / 2400:.1f} us, "
       f"start spread {(st[:, 0].max() - t0) / 2400:.1f} us, end spread {(st[:, 30].max() - st[:, 30].min()) / 2400:.1f} us")
-xc = st[:, 31] & 7                                    # s_memtime is per XCD: times relative to the XCD's first wave
-rel0 = np.zeros(len(st)); 
-for x_ in np.unique(xc):
-    rel0[xc == x_] = st[xc == x_, 0].min()
-starts = np.sort(st[:, 0] - rel0) / 2400; ends = np.sort(st[:, 30] - rel0) / 2400
-print("  wave starts (us after the first): p10 %.1f p25 %.1f p50 %.1f p75 %.1f p90 %.1f max %.1f;  ends: p10 %.1f p50 %.1f p90 %.1f max %.1f"
-      % (*np.percentile(starts, [10, 25, 50, 75, 90, 100]), *np.percentile(ends, [10, 50, 90, 100])))
+rs = (st[:, 29] - st[:, 29].min()) / 100.0; re_ = (st[:, 28] - st[:, 29].min()) / 100.0        # s_memrealtime: 100 MHz, one clock for the chip
+print("  wave starts (us after the first, by the 100 MHz clock): p10 %.1f p50 %.1f p90 %.1f max %.1f;  ends: p10 %.1f p50 %.1f p90 %.1f max %.1f"
+      % (*np.percentile(rs, [10, 50, 90, 100]), *np.percentile(re_, [10, 50, 90, 100])))
 hw = (st[:, 31].astype(np.uint64) >> np.uint64(32)).astype(np.int64)
 simd = (hw >> 4) & 3; cu = (hw >> 8) & 15; sh = (hw >> 12) & 1; se = (hw >> 13) & 7; xcc = st[:, 31] & 7
 key = ((xcc * 8 + se) * 2 + sh) * 16 + cu
