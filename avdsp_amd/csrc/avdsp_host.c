@@ -1218,6 +1218,7 @@ int dspRuntimeBlockDevice(int format, opcode_t *core, int *rundata,
     if (!cp) return g_err_code;
     if (check_rundata(rundata)) return -1;
     if (nframes <= 0 || cp->empty) return 0;
+    if (avdsp_hip_wait_block_host(G.dev, 0) < 0) return fail(-10, "%s", avdsp_hip_last_error());       /* queued host blocks first */
     if (takes_pieces(cp, nframes, in_stride, in_io_base, out_stride, out_io_base))
         return block_all(format, rundata, d_in, in_stride, in_io_base, d_out, out_stride, out_io_base, nframes, 1, stream, AVDSP_PCM_S32, core);
     if (avdsp_hip_run_block(G.dev, cp->plan_id, d_in, in_stride, in_io_base, d_out, out_stride, out_io_base,
@@ -1233,12 +1234,40 @@ static int block_host(int format, opcode_t *core, int *rundata, const void *in, 
     if (!cp) return g_err_code;
     if (check_rundata(rundata)) return -1;
     if (nframes <= 0 || cp->empty) return 0;
+    if (avdsp_hip_wait_block_host(G.dev, 0) < 0) return fail(-10, "%s", avdsp_hip_last_error());       /* queued host blocks first */
     if (takes_pieces(cp, nframes, in_stride, in_io_base, out_stride, out_io_base))
         return block_all(format, rundata, in, in_stride, in_io_base, out, out_stride, out_io_base, nframes, 0, 0, AVDSP_PCM_S32, core);
     if (avdsp_hip_run_block_host(G.dev, cp->plan_id, in, in_stride, in_io_base, out, out_stride, out_io_base,
                                  nframes, G.opt_fir_impl, G.opt_biquad_impl))
         return fail(-10, "%s", avdsp_hip_last_error());
     return 0;
+}
+
+/* dspRuntimeBlock_N as a queue (linux/avdsp_plugin.c:98-141 with the next period already on its way): returns the number
+ * of blocks in flight, < 0 on error.  The buffers stay the library's until dspRuntimeBlockWait lets the block through. */
+int dspRuntimeBlockSubmit(int format, opcode_t *core, int *rundata, const void *in, int in_stride, int in_io_base,
+                          void *out, int out_stride, int out_io_base, int nframes)
+{
+    core_plan *cp = get_plan(format, core);
+    if (!cp) return g_err_code;
+    if (check_rundata(rundata)) return -1;
+    if (nframes <= 0 || cp->empty) return avdsp_hip_wait_block_host(G.dev, 1 << 30);
+    if (takes_pieces(cp, nframes, in_stride, in_io_base, out_stride, out_io_base)) {
+        if (avdsp_hip_wait_block_host(G.dev, 0) < 0) return fail(-10, "%s", avdsp_hip_last_error());
+        return block_all(format, rundata, in, in_stride, in_io_base, out, out_stride, out_io_base, nframes, 0, 0, AVDSP_PCM_S32, core);
+    }
+    const int rc = avdsp_hip_submit_block_host(G.dev, cp->plan_id, in, in_stride, in_io_base, out, out_stride, out_io_base,
+                                               nframes, G.opt_fir_impl, G.opt_biquad_impl);
+    if (rc < 0) return fail(-10, "%s", avdsp_hip_last_error());
+    return rc;
+}
+
+int dspRuntimeBlockWait(int max_in_flight)
+{
+    if (!G.dev) return 0;
+    const int rc = avdsp_hip_wait_block_host(G.dev, max_in_flight);
+    if (rc < 0) return fail(-10, "%s", avdsp_hip_last_error());
+    return rc;
 }
 
 int dspRuntimeBlock_2(opcode_t *core, int *rundata, const int *in, int in_stride, int in_io_base,

@@ -1582,6 +1582,15 @@ struct avdsp_hip_prog {
     std::vector<Pinned> pinned;
     hipStream_t s_h2d = nullptr, s_run = nullptr, s_d2h = nullptr;
     std::vector<hipEvent_t> ev_host;
+    /* queued host-pointer blocks (avdsp_hip_submit_block_host): a ring of staging pairs and three streams of their own --
+     * created WITHOUT hipStreamNonBlocking, so that everything else the library does on the null stream (state reads,
+     * resets, the synchronous block calls) is ordered behind the blocks in flight */
+    static constexpr int kHostQueue = 4;
+    struct HostSlot { unsigned *d_in = nullptr, *d_out = nullptr; size_t in_cap = 0, out_cap = 0; hipEvent_t h2d = nullptr, run = nullptr, d2h = nullptr; };
+    HostSlot hq[kHostQueue];
+    hipStream_t q_h2d = nullptr, q_run = nullptr, q_d2h = nullptr;
+    unsigned long long hq_submitted = 0, hq_waited = 0;
+    hipEvent_t input_ready = nullptr;    /* set around a run_block whose input block is still being copied in by another stream: the overlap mode's cascade waits for it */
     int host_split = 0;                  /* frames per piece of a host block (0 = one piece; pieces only pay with host_pin) */
     int host_pin = 0;                    /* pin the caller's buffers in place and remember them: only for a host that keeps them allocated */
     bool ev_fir_set[2] = {false, false};
@@ -1819,6 +1828,7 @@ int launch_all(avdsp_hip_prog *prog, Plan &pl, BlockIO io, int fir_impl, int biq
         if (overlap_ready(prog)) return -1;
         const int slot = (int)(prog->blk & 1);
         if (prog->ev_fir_set[slot]) HIP_TRY(hipStreamWaitEvent(prog->s_bq, prog->ev_fir[slot], 0));   /* FIR k-2 */
+        if (prog->input_ready) HIP_TRY(hipStreamWaitEvent(prog->s_bq, prog->input_ready, 0));           /* (queued host blocks: the copy of this block) */
         for (auto &g : pl.bq)
             if (launch_biquad<FMT>(prog, pl, g, g.d_ids, g.n, io, biquad_impl, prog->s_bq)) return -1;
         HIP_TRY(hipEventRecord(prog->ev_bq[slot], prog->s_bq));
@@ -1893,6 +1903,11 @@ void avdsp_hip_prog_destroy(avdsp_hip_prog *p)
     for (auto &pn : p->pinned) if (pn.ours) (void)hipHostUnregister(const_cast<void *>(pn.ptr));
     for (auto st : {p->s_h2d, p->s_run, p->s_d2h}) if (st) (void)hipStreamDestroy(st);
     for (auto e : p->ev_host) (void)hipEventDestroy(e);
+    for (auto st : {p->q_h2d, p->q_run, p->q_d2h}) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    for (auto &sl : p->hq) {
+        (void)hipFree(sl.d_in); (void)hipFree(sl.d_out);
+        for (auto e : {sl.h2d, sl.run, sl.d2h}) if (e) (void)hipEventDestroy(e);
+    }
     if (p->s_bq) (void)hipStreamDestroy(p->s_bq);
     for (int i = 0; i < 2; i++) { if (p->ev_bq[i]) (void)hipEventDestroy(p->ev_bq[i]); if (p->ev_fir[i]) (void)hipEventDestroy(p->ev_fir[i]); }
     (void)hipFree(p->d_buf); (void)hipFree(p->d_in); (void)hipFree(p->d_out); (void)hipFree(p->d_tpdf); (void)hipFree(p->d_frame);
@@ -2338,6 +2353,7 @@ static void pin_in_place(avdsp_hip_prog *prog, const void *ptr, size_t bytes)
     for (auto &pn : prog->pinned)
         if (pn.ptr == ptr && pn.bytes >= bytes) return;
     if (prog->pinned.size() >= 16) {
+        (void)avdsp_hip_wait_block_host(prog, 0);           /* (queued blocks may be copying from the buffers about to be released) */
         for (auto &pn : prog->pinned) if (pn.ours) (void)hipHostUnregister(const_cast<void *>(pn.ptr));
         prog->pinned.clear();
     }
@@ -2408,6 +2424,69 @@ int avdsp_hip_run_block_host(avdsp_hip_prog *prog, int plan, const void *h_in, i
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(h_out, prog->d_out, out_words * 4, hipMemcpyDeviceToHost));
     return 0;
+}
+
+/* The host-pointer block call as a queue: submit returns when the block's copies and kernels are enqueued, and up to
+ * kHostQueue blocks are in flight -- block k+1 crosses PCIe while block k is computed and block k-1 goes back, which the
+ * synchronous call (one block, three stages, one after the other) cannot do.  The caller's buffers are pinned in place
+ * (hipHostRegister) on first use and must stay allocated and untouched until avdsp_hip_wait_block_host has let the block
+ * through; blocks complete in submission order.  Cores that run through the interpreter, and blocks under 256 frames, are
+ * done on the spot (after the queue has drained).                                                                   */
+int avdsp_hip_wait_block_host(avdsp_hip_prog *prog, int max_in_flight)
+{
+    if (max_in_flight < 0) max_in_flight = 0;
+    while ((long long)(prog->hq_submitted - prog->hq_waited) > max_in_flight) {
+        auto &sl = prog->hq[prog->hq_waited % avdsp_hip_prog::kHostQueue];
+        HIP_TRY(hipEventSynchronize(sl.d2h));
+        prog->hq_waited++;
+    }
+    return (int)(prog->hq_submitted - prog->hq_waited);
+}
+
+int avdsp_hip_submit_block_host(avdsp_hip_prog *prog, int plan, const void *h_in, int in_stride, int in_io_base,
+                                void *h_out, int out_stride, int out_io_base, int nframes, int fir_impl, int biquad_impl)
+{
+    if (plan < 0 || plan >= (int)prog->plans.size()) return set_err("bad plan id %d", plan);
+    Plan &pl = prog->plans[plan];
+    if (pl.generic || nframes < 256 || in_stride <= 0 || out_stride <= 0) {
+        if (avdsp_hip_wait_block_host(prog, 0) < 0) return -1;
+        if (avdsp_hip_run_block_host(prog, plan, h_in, in_stride, in_io_base, h_out, out_stride, out_io_base, nframes, fir_impl, biquad_impl)) return -1;
+        return 0;
+    }
+    constexpr int Q = avdsp_hip_prog::kHostQueue;
+    if (avdsp_hip_wait_block_host(prog, Q - 1) < 0) return -1;            /* the slot's previous block has gone back */
+    if (!prog->q_h2d) {
+        HIP_TRY(hipStreamCreate(&prog->q_h2d)); HIP_TRY(hipStreamCreate(&prog->q_run)); HIP_TRY(hipStreamCreate(&prog->q_d2h));
+        for (auto &sl : prog->hq)
+            for (hipEvent_t *e : {&sl.h2d, &sl.run, &sl.d2h}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    }
+    auto &sl = prog->hq[prog->hq_submitted % Q];
+    const size_t in_words = (size_t)nframes * in_stride, out_words = (size_t)nframes * out_stride;
+    if (sl.in_cap < in_words) {
+        (void)hipFree(sl.d_in); sl.d_in = nullptr; sl.in_cap = 0;
+        HIP_TRY(hipMalloc((void **)&sl.d_in, in_words * 4)); sl.in_cap = in_words;
+    }
+    if (sl.out_cap < out_words) {
+        (void)hipFree(sl.d_out); sl.d_out = nullptr; sl.out_cap = 0;
+        HIP_TRY(hipMalloc((void **)&sl.d_out, out_words * 4)); sl.out_cap = out_words;
+    }
+    pin_in_place(prog, h_in, in_words * 4);
+    pin_in_place(prog, h_out, out_words * 4);
+    const bool whole = pl.stores_whole_window && out_io_base == pl.io_out_min && out_stride == pl.io_out_max - pl.io_out_min + 1;
+    if (!whole) HIP_TRY(hipMemcpyAsync(sl.d_out, h_out, out_words * 4, hipMemcpyHostToDevice, prog->q_h2d));   /* unstored slots keep their content */
+    HIP_TRY(hipMemcpyAsync(sl.d_in, h_in, in_words * 4, hipMemcpyHostToDevice, prog->q_h2d));
+    HIP_TRY(hipEventRecord(sl.h2d, prog->q_h2d));
+    HIP_TRY(hipStreamWaitEvent(prog->q_run, sl.h2d, 0));
+    prog->input_ready = sl.h2d;
+    const int rc = avdsp_hip_run_block(prog, plan, sl.d_in, in_stride, in_io_base, sl.d_out, out_stride, out_io_base, nframes, fir_impl, biquad_impl, prog->q_run);
+    prog->input_ready = nullptr;
+    if (rc) return -1;
+    HIP_TRY(hipEventRecord(sl.run, prog->q_run));
+    HIP_TRY(hipStreamWaitEvent(prog->q_d2h, sl.run, 0));
+    HIP_TRY(hipMemcpyAsync(h_out, sl.d_out, out_words * 4, hipMemcpyDeviceToHost, prog->q_d2h));
+    HIP_TRY(hipEventRecord(sl.d2h, prog->q_d2h));
+    prog->hq_submitted++;
+    return (int)(prog->hq_submitted - prog->hq_waited);
 }
 
 /* Several cores over the same block.  plans[] in program order, grouped into levels (level_size[]): the host

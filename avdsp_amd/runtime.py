@@ -27,14 +27,14 @@ EXPORTED = [
     "dspHeaderPtr", "dspBiquadFreqSkip", "dspMantissa", "dspOpcodeText", "dspQNM", "dspQM64", "dspQM32",
     # block extension (include/avdsp_runtime.h)
     "dspRuntimeBlock_2", "dspRuntimeBlock_3", "dspRuntimeBlock_4", "dspRuntimeBlock_5", "dspRuntimeBlock_6",
-    "dspRuntimeBlockDevice", "dspRuntimeBlockPcm", "dspRuntimeUnpackPcmDevice", "dspRuntimeBlockAll", "dspRuntimeBlockAllDevice", "dspRuntimeBlockAllPcm",
+    "dspRuntimeBlockSubmit", "dspRuntimeBlockWait", "dspRuntimeBlockDevice", "dspRuntimeBlockPcm", "dspRuntimeUnpackPcmDevice", "dspRuntimeBlockAll", "dspRuntimeBlockAllDevice", "dspRuntimeBlockAllPcm",
     "dspRuntimeSyncState", "dspRuntimeUploadState", "dspRuntimeUploadParams", "dspRuntimeSetOption", "dspRuntimeGetOption",
     "dspRuntimeCoreInfo", "dspRuntimeKernelTime", "dspRuntimeLastError", "dspRuntimeRelease",
     "dspRuntimeSetShard", "dspRuntimeShardInfo", "dspRuntimeTagOutput", "dspRuntimeTagOutputDevice", "dspRuntimeTagOutputReset",
     # thin HIP ABI (include/avdsp_hip.h)
     "avdsp_hip_device_count", "avdsp_hip_set_device", "avdsp_hip_prog_create", "avdsp_hip_prog_destroy",
     "avdsp_hip_prog_add_plan", "avdsp_hip_prog_add_generic", "avdsp_hip_prog_clear_plans", "avdsp_hip_tpdf_reset", "avdsp_hip_upload_words", "avdsp_hip_download_words", "avdsp_hip_zero_words",
-    "avdsp_hip_run_block", "avdsp_hip_run_block_host", "avdsp_hip_run_levels", "avdsp_hip_run_levels_host", "avdsp_hip_run_levels_pcm_host", "avdsp_hip_unpack_pcm", "avdsp_hip_run_block_pcm_host", "avdsp_hip_profile_enable", "avdsp_hip_profile_read", "avdsp_hip_prog_set_option", "avdsp_hip_tag_output", "avdsp_hip_tag_column_host",
+    "avdsp_hip_run_block", "avdsp_hip_run_block_host", "avdsp_hip_submit_block_host", "avdsp_hip_wait_block_host", "avdsp_hip_run_levels", "avdsp_hip_run_levels_host", "avdsp_hip_run_levels_pcm_host", "avdsp_hip_unpack_pcm", "avdsp_hip_run_block_pcm_host", "avdsp_hip_profile_enable", "avdsp_hip_profile_read", "avdsp_hip_prog_set_option", "avdsp_hip_tag_output", "avdsp_hip_tag_column_host",
     "avdsp_hip_synchronize", "avdsp_hip_last_error",
 ]
 
@@ -94,6 +94,9 @@ def lib() -> C.CDLL:
             f = getattr(L, n); f.restype = i32; f.argtypes = [vp, vp, vp, i32, i32, vp, i32, i32, i32]
         L.dspRuntimeBlockDevice.restype = i32
         L.dspRuntimeBlockDevice.argtypes = [i32, vp, vp, vp, i32, i32, vp, i32, i32, i32, vp]
+        L.dspRuntimeBlockSubmit.restype = i32
+        L.dspRuntimeBlockSubmit.argtypes = [i32, vp, vp, vp, i32, i32, vp, i32, i32, i32]
+        L.dspRuntimeBlockWait.restype = i32; L.dspRuntimeBlockWait.argtypes = [i32]
         L.dspRuntimeBlockAll.restype = i32
         L.dspRuntimeBlockAll.argtypes = [i32, vp, vp, i32, i32, vp, i32, i32, i32]
         L.dspRuntimeBlockAllDevice.restype = i32
@@ -232,6 +235,26 @@ class Runtime:
                 self._check(f(core, self.rundata, x[b0:b1].ctypes.data, in_stride, in_io_base,
                               out[b0:b1].ctypes.data, out_stride, out_io_base, b1 - b0))
         return out
+
+    def submit_block(self, x: np.ndarray, out: np.ndarray, in_io_base: int, out_io_base: int = 0) -> int:
+        """dspRuntimeBlockSubmit for every core: the block is queued (copies and kernels of up to four blocks overlap);
+        x and out (C-contiguous, the runtime's sample type) belong to the library until wait_blocks lets the block through.
+        Returns the number of blocks in flight."""
+        dt = sample_dtype(self.fmt)
+        if x.dtype != dt or out.dtype != dt or not x.flags.c_contiguous or not out.flags.c_contiguous:
+            raise ValueError("submit_block takes C-contiguous arrays of the runtime's sample type (they are used in place)")
+        rc = 0
+        for core in self.cores:
+            rc = self.L.dspRuntimeBlockSubmit(self.fmt, core, self.rundata, x.ctypes.data, x.shape[1], in_io_base,
+                                              out.ctypes.data, out.shape[1], out_io_base, x.shape[0])
+            self._check(min(rc, 0))
+        return rc
+
+    def wait_blocks(self, max_in_flight: int = 0) -> int:
+        """dspRuntimeBlockWait: returns when at most max_in_flight submitted blocks are unfinished."""
+        rc = self.L.dspRuntimeBlockWait(max_in_flight)
+        self._check(min(rc, 0))
+        return rc
 
     def run_block_all(self, x: np.ndarray, out_stride: int, in_io_base: int, out_io_base: int = 0,
                       out: np.ndarray | None = None, block: int | None = None) -> np.ndarray:

@@ -320,6 +320,20 @@ def main():
         for _ in range(n):
             r.run_block(xs, Cl, in_base, out_base, out=hy)
         host_rate = Cl * B * n / (time.perf_counter() - th) / 1e6
+        # ... and as a queue (dspRuntimeBlockSubmit / Wait): four blocks in flight, the host cycles through six buffer pairs
+        ring = [(xs.copy(), np.zeros((B, Cl), dtype=xs.dtype)) for _ in range(6)]
+        for k in range(30):
+            r.submit_block(*ring[k % 6], in_base, out_base); r.wait_blocks(3)
+        r.wait_blocks(0)
+        nq = max(100, args.steps)
+        th = time.perf_counter()
+        for k in range(nq):
+            r.submit_block(*ring[k % 6], in_base, out_base); r.wait_blocks(3)
+        r.wait_blocks(0)
+        host_queue_rate = Cl * B * nq / (time.perf_counter() - th) / 1e6
+        if not np.isfinite(ring[(nq - 1) % 6][1].astype(np.float64)).all():
+            sys.exit("bench.py: the queued host path left a non-finite output block")
+        r.set_option("host_pin", 0)
 
     if rank == 0:
         ranks_share = shard_world if args.shard else world
@@ -374,6 +388,7 @@ def main():
         }
         if host_rate is not None:
             line["host_buffers_msamples_s"] = host_rate
+            line["host_queue_msamples_s"] = host_queue_rate
         line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)
     r.release()

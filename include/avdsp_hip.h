@@ -136,6 +136,15 @@ int avdsp_hip_run_block_host(avdsp_hip_prog *prog, int plan, const void *h_in, i
                              void *h_out, int out_stride, int out_io_base, int nframes,
                              int fir_impl, int biquad_impl);
 
+/* The same as a queue (avdsp_kernels.hip: up to 4 blocks in flight, copies of one block under the kernels of another).
+ * submit returns the number of blocks in flight (0: done on the spot -- interpreter core or a block under 256 frames),
+ * -1 on error; the caller's buffers are pinned in place and must stay allocated and untouched until wait has let the
+ * block through.  wait blocks until at most max_in_flight submitted blocks are unfinished (oldest first) and returns
+ * how many still are.                                                                                            */
+int avdsp_hip_submit_block_host(avdsp_hip_prog *prog, int plan, const void *h_in, int in_stride, int in_io_base,
+                                void *h_out, int out_stride, int out_io_base, int nframes, int fir_impl, int biquad_impl);
+int avdsp_hip_wait_block_host(avdsp_hip_prog *prog, int max_in_flight);
+
 /* Host sample formats of linux/avdsp_plugin.c:103-121 in front of a block: packed little-endian PCM,
  * frame-interleaved, unpacked on the device to the 32-bit s.31 words the int-sample formats (2, 3, 4) load:
  * S32 as is, S24_3LE bytes b0 b1 b2 -> b0<<8 | b1<<16 | b2<<24, S16 -> sample << 16.                    */

@@ -98,6 +98,16 @@ int dspRuntimeBlock_6(opcode_t *core, int *rundata, const float *in, int in_stri
 
 /* Same, with in/out resident in HBM (device pointers) and the work enqueued on `stream`
  * (a hipStream_t passed as void*, NULL = default stream).  Asynchronous: returns after enqueue. */
+/* dspRuntimeBlock_N as a queue: submit returns once the block's copies and kernels are enqueued (its value: blocks in
+ * flight, < 0 on error); up to four blocks are in flight, the copies of one under the kernels of another.  `in` and `out`
+ * are pinned in place on first use and stay the library's -- allocated, unread, unwritten -- until dspRuntimeBlockWait
+ * has let the block through.  dspRuntimeBlockWait(m) returns when at most m submitted blocks are unfinished (oldest
+ * first; m = 0: all done) with the number that still are.  Results are those of the same dspRuntimeBlock_N calls in
+ * the same order; every other entry point waits for the queue by itself.                                         */
+int dspRuntimeBlockSubmit(int format, opcode_t *core, int *rundata, const void *in, int in_stride, int in_io_base,
+                          void *out, int out_stride, int out_io_base, int nframes);
+int dspRuntimeBlockWait(int max_in_flight);
+
 int dspRuntimeBlockDevice(int format, opcode_t *core, int *rundata,
                           const void *d_in, int in_stride, int in_io_base,
                           void *d_out, int out_stride, int out_io_base, int nframes, void *stream);
