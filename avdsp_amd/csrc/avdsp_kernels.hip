@@ -1380,6 +1380,14 @@ __global__ __launch_bounds__(kBlock) void state_to_ring(const RingConvArgs a)
     for (int i = threadIdx.x; i < a.ring.R; i += blockDim.x) ring_put(a.ring, cid, -1 - i, i < c.fir_taps ? __float_as_uint(st[i]) : 0u);
 }
 
+/* the operand ring made from the float ring, when fir_stream is first asked for (from then on every ring writer keeps it up) */
+__global__ __launch_bounds__(kBlock) void ring_widen(const RingConvArgs a)
+{
+    const int cid = a.group[blockIdx.x];
+    const size_t row = (size_t)cid * a.ring.R;
+    for (int i = threadIdx.x; i < a.ring.R; i += blockDim.x) a.ring.wide[row + ((i + 3) & (a.ring.R - 1))] = mulop(a.ring.base[row + i]);
+}
+
 /* chains with neither biquads nor FIR: LOAD -> [SAT0DB] -> STORE */
 struct PassArgs {
     const avdsp_chain *chains;
@@ -1726,6 +1734,14 @@ int launch_fir_tile(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, Block
 template <int FMT, int R>
 int launch_fir_stream(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, BlockIO io, hipStream_t stream)
 {
+    if (!pl.d_ring64) {
+        /* first use: the operand ring (8 bytes per ring entry) is made from the float ring; every ring writer keeps it up from here on */
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMalloc((void **)&pl.d_ring64, (size_t)pl.nchains * pl.ring_R * sizeof(double)));
+        RingConvArgs ca{prog->d_buf, pl.d_chains, pl.d_fir_ids, pl.n_fir, plan_ring(pl)};
+        hipLaunchKernelGGL(ring_widen, dim3(pl.n_fir), dim3(kBlock), 0, stream, ca);
+        HIP_TRY(hipGetLastError());
+    }
     FirTileArgs a{};
     a.buf = prog->d_buf; a.chains = pl.d_chains; a.group = ids; a.ngroup = n;
     a.ring = plan_ring(pl); a.io = io; a.taps64 = pl.d_taps64; a.pitch64 = pl.pitch64;
@@ -1989,8 +2005,6 @@ int avdsp_hip_prog_add_plan(avdsp_hip_prog *prog, const avdsp_plan_desc *d)
         hipError_t e = hipMalloc((void **)&pl.d_ring, (size_t)d->nchains * pl.ring_R * sizeof(float));
         if (e != hipSuccess) { free_plan(pl); return set_err("hipMalloc(FIR rings, %d x %d): %s", d->nchains, pl.ring_R, hipGetErrorString(e)); }
         pl.wpos = 0;
-        e = hipMalloc((void **)&pl.d_ring64, (size_t)d->nchains * pl.ring_R * sizeof(double));
-        if (e != hipSuccess) { free_plan(pl); return set_err("hipMalloc(FIR operand rings, %d x %d): %s", d->nchains, pl.ring_R, hipGetErrorString(e)); }
         for (int i = 0; i < d->nchains; i++) pl.n_fir_only += chains[i].fir_taps && !chains[i].nsec;
         {
             const void *fns[3] = { d->format == 4 ? (const void *)fir_stream<4, 1> : (const void *)fir_stream<6, 1>,

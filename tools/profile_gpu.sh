@@ -7,7 +7,7 @@ ROOT="$(pwd)"
 OUT="$ROOT/gpurun_out/prof_$TAG"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS=(--no-cpu-baseline --steps 20 --warmup 3 "$@")
+ARGS=(--no-cpu-baseline --steps 20 --warmup 5 "$@")
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOT/bench.py" "${ARGS[@]}" > "$OUT/trace.log" 2>&1
 echo "trace rc=$?"
 # counters in their own runs (no tracing domains mixed in), split by hardware block budget
