@@ -19,5 +19,9 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$
 echo "pmc_fetch rc=$?"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$ROOT/bench.py" "${ARGS[@]}" > "$OUT/pmc_write.log" 2>&1
 echo "pmc_write rc=$?"
-find "$OUT" -name "*.csv" | head -40
-du -sh "$OUT"
+# condense on the box (the per-dispatch csv files of a 0.5 s settle phase run to tens of MB): summary, kernel stats, traffic
+cd "$ROOT"
+python3 tools/summarize_prof.py "$OUT" > "gpurun_out/${TAG}_summary.md"
+cp "$OUT"/trace/*/*_kernel_stats.csv "gpurun_out/${TAG}_kernel_stats.csv"
+[ -n "${TRAFFIC_KEY:-}" ] && python3 tools/summarize_prof.py "$OUT" --traffic "$TRAFFIC_KEY" gpurun_out/traffic.json
+rm -rf "$OUT"
