@@ -1317,6 +1317,11 @@ static int cores_meet_ex(const core_deps *a, const core_deps *b, int ignore_tpdf
     for (int i = 0; i < a->nranges; i++)
         for (int j = 0; j < b->nranges; j++)
             if (a->range[i][0] < b->range[j][1] && b->range[j][0] < a->range[i][1]) return 1;
+    /* a data word one side reads (LOAD_MEM / LOAD_MEM_DATA, two words) inside a state range the other side's opcodes keep rewriting */
+    for (int i = 0; i < a->nrd; i++)
+        for (int j = 0; j < b->nranges; j++) if (a->rd_word[i] + 2 > b->range[j][0] && a->rd_word[i] < b->range[j][1]) return 1;
+    for (int i = 0; i < b->nrd; i++)
+        for (int j = 0; j < a->nranges; j++) if (b->rd_word[i] + 2 > a->range[j][0] && b->rd_word[i] < a->range[j][1]) return 1;
     if (!ignore_tpdf && ((a->tpdf_calc && (b->tpdf_user || b->tpdf_calc)) || (a->tpdf_user && b->tpdf_calc))) return 1;
     return 0;
 }

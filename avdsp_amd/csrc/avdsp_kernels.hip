@@ -1663,6 +1663,10 @@ struct ProfileScope {                   /* records an event pair around the laun
         hipEvent_t b = take_event(prog);
         if (!b) { prog->free_events.push_back(a); return; }
         (void)hipEventRecord(b, stream);
+        if (prog->spans.size() >= 65536) {                 /* nobody reads the timers: forget the oldest half (their events go back to the pool) */
+            for (size_t i = 0; i < 32768; i++) { prog->free_events.push_back(prog->spans[i].a); prog->free_events.push_back(prog->spans[i].b); }
+            prog->spans.erase(prog->spans.begin(), prog->spans.begin() + 32768);
+        }
         prog->spans.push_back({kind, a, b});
     }
 };
@@ -2073,11 +2077,15 @@ int avdsp_hip_prog_add_generic(avdsp_hip_prog *prog, const avdsp_generic_desc *d
     /* one samples[] frame per program, shared by its cores */
     const int want = std::max(d->io_span, kGenericFrameLds);
     if (prog->frame_words < want) {
-        for (auto &o : prog->plans) if (o.generic) return set_err("generic plan: IO span %d after a core with a smaller frame", d->io_span);
-        (void)hipFree(prog->d_frame); prog->d_frame = nullptr; prog->frame_words = 0;
-        HIP_TRY(hipMalloc((void **)&prog->d_frame, (size_t)want * 4));
-        HIP_TRY(hipMemset(prog->d_frame, 0, (size_t)want * 4));
-        prog->frame_words = want;
+        /* a later core with a wider IO span: the frame grows, keeps its content, and the earlier cores' plans follow it */
+        unsigned *grown = nullptr;
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMalloc((void **)&grown, (size_t)want * 4));
+        HIP_TRY(hipMemset(grown, 0, (size_t)want * 4));
+        if (prog->d_frame) HIP_TRY(hipMemcpy(grown, prog->d_frame, (size_t)prog->frame_words * 4, hipMemcpyDeviceToDevice));
+        (void)hipFree(prog->d_frame);
+        prog->d_frame = grown; prog->frame_words = want;
+        for (auto &o : prog->plans) if (o.generic) o.ga.scratch = grown;
     }
     a.scratch = prog->d_frame;
     a.scratch_len = prog->frame_words;
