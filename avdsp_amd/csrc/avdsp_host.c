@@ -70,7 +70,12 @@ typedef struct {
 #define MAX_ARRANGEMENTS 17
 typedef struct { int valid, format, n, nlevels, ncores; opcode_t *only; int *plans, *size; } arrangement;
 
-static struct {
+/* One loaded program = one context, found again by any pointer into its buffer (dspRuntimeInit's codePtr owns it, as the
+ * reference's host owns "opcodes").  The reference keeps this in file statics, one program per process; here the statics
+ * of the program the latest call named are swapped in (dspHeaderPtr, dspBiquadFreqSkip, dspMantissa follow), so several
+ * programs -- on several GPUs -- live in one process.  Calls that name no program (dspRuntimeReset, options, shard,
+ * timers, tagoutput, wait) address the program of the latest call that did, or dspRuntimeSelect's. */
+typedef struct avdsp_ctx {
     opcode_t       *code;
     int             total_words;         /* totalLength + dataSize */
     int             have_rate;
@@ -88,7 +93,20 @@ static struct {
     int             numfreq_at_init;                       /* dspChangeFormat's view of the rate count (see dspRuntimeInit) */
     int             opt_overlap, opt_fir_rows, opt_host_split, opt_host_pin; /* launch arrangement of the chain kernels (avdsp_hip_prog_set_option) */
     arrangement     arr[MAX_ARRANGEMENTS]; int arr_next;   /* how the cores / pieces go to the device: [0] whole program, [1..] single cores */
-} G = { .opt_fir_impl = 1, .opt_biquad_impl = 1, .opt_device = -1, .opt_interp_impl = 1, .opt_strand_split = 1, .shard_world = 1 };
+    int             biquad_freq_skip, mantissa;            /* this program's dspBiquadFreqSkip / dspMantissa */
+    int             device_ordinal;                        /* the GPU its device copy lives on (-1: none yet) */
+} avdsp_ctx;
+
+/* no program loaded: options set now are the defaults every program starts from (and keeps following, see dspRuntimeSetOption) */
+static avdsp_ctx g_template = { .opt_fir_impl = 1, .opt_biquad_impl = 1, .opt_device = -1, .opt_interp_impl = 1, .opt_strand_split = 1, .shard_world = 1,
+                                .mantissa = DSP_MANT, .device_ordinal = -1 };
+#define MAX_PROGRAMS 64
+static avdsp_ctx *g_ctx[MAX_PROGRAMS];
+static int        g_nctx;
+static avdsp_ctx *g_cur = &g_template;
+#define G (*g_cur)
+static int        g_rate_static;     /* the reference's dspNumSamplingFreq static: what the latest dspRuntimeReset of the PROCESS left behind */
+static int        g_active_device = -1;
 
 static char g_err[512];
 static int  g_err_code;
@@ -115,12 +133,66 @@ static void drop_device(void)
     G.dev_state_valid = 0;
 }
 
+/* swap a program's statics in: the exported globals of the reference runtime follow, and so does the active GPU */
+static void ctx_make_current(avdsp_ctx *c)
+{
+    if (c == g_cur) return;
+    if (g_cur != &g_template) { g_cur->biquad_freq_skip = dspBiquadFreqSkip; g_cur->mantissa = dspMantissa; }
+    g_cur = c;
+    dspHeaderPtr = (dspHeader_t *)c->code;
+    dspBiquadFreqSkip = c->biquad_freq_skip;
+    dspMantissa = c->mantissa;
+    if (c->device_selected && c->device_ordinal >= 0 && c->device_ordinal != g_active_device && !avdsp_hip_set_device(c->device_ordinal))
+        g_active_device = c->device_ordinal;
+}
+
+/* the program a pointer belongs to (its code or its data area); the current one stays if none does */
+static avdsp_ctx *ctx_of(const void *ptr)
+{
+    const opcode_t *q = (const opcode_t *)ptr;
+    if (g_cur != &g_template && g_cur->code && q >= g_cur->code && q <= g_cur->code + g_cur->total_words) return g_cur;
+    for (int i = 0; i < g_nctx; i++)
+        if (g_ctx[i]->code && q >= g_ctx[i]->code && q <= g_ctx[i]->code + g_ctx[i]->total_words) { ctx_make_current(g_ctx[i]); return g_cur; }
+    return g_cur;
+}
+
+static void ctx_destroy(avdsp_ctx *c)
+{
+    avdsp_ctx *back = g_cur != c ? g_cur : &g_template;      /* whoever was current stays current */
+    ctx_make_current(c);
+    drop_device();
+    for (int i = 0; i < MAX_ARRANGEMENTS; i++) free(c->arr[i].plans);      /* (size[] lives in the same allocation) */
+    for (int i = 0; i < g_nctx; i++)
+        if (g_ctx[i] == c) { g_ctx[i] = g_ctx[--g_nctx]; break; }
+    g_cur = &g_template;
+    dspHeaderPtr = 0; dspBiquadFreqSkip = 0; dspMantissa = DSP_MANT;
+    free(c);
+    if (back != &g_template) ctx_make_current(back);
+}
+
 void dspRuntimeRelease(void)
 {
-    drop_device();
-    G.code = 0;
+    while (g_nctx) ctx_destroy(g_ctx[g_nctx - 1]);
+    g_cur = &g_template;
     dspHeaderPtr = 0;
-    G.have_rate = 0;
+}
+
+/* one program of several: frees its device memory and forgets it (the buffer is the caller's) */
+int dspRuntimeReleaseProgram(opcode_t *codePtr)
+{
+    for (int i = 0; i < g_nctx; i++)
+        if (g_ctx[i]->code == codePtr) { ctx_destroy(g_ctx[i]); return 0; }
+    return fail(-1, "dspRuntimeReleaseProgram: no program loaded at that address");
+}
+
+/* makes the program a pointer belongs to the one that calls without a program pointer address */
+int dspRuntimeSelect(const void *ptr_into_program)
+{
+    avdsp_ctx *c = ctx_of(ptr_into_program);
+    const opcode_t *q = (const opcode_t *)ptr_into_program;
+    if (c == &g_template || !c->code || q < c->code || q > c->code + c->total_words)
+        return fail(-1, "dspRuntimeSelect: the pointer is inside no loaded program");
+    return 0;
 }
 
 /* a tunable that changes how cores are lowered: forget the plans, keep the device copy (state, TPDF globals) */
@@ -132,7 +204,7 @@ static int replan(void)
     return 0;
 }
 
-int dspRuntimeSetOption(const char *key, int value)
+static int set_option_here(const char *key, int value)
 {
     if (!strcmp(key, "fir_impl"))    { G.opt_fir_impl = value; return 0; }
     if (!strcmp(key, "biquad_impl")) { G.opt_biquad_impl = value; return 0; }
@@ -149,7 +221,7 @@ int dspRuntimeSetOption(const char *key, int value)
     }
     /* the reference's dspNumSamplingFreq static as a fresh process would have it (0), or as an earlier program left it:
      * what dspChangeFormat converts depends on it (dspRuntimeInit); a test hook, a process restart does the same */
-    if (!strcmp(key, "rate_count_static")) { G.num_freq = value; return 0; }
+    if (!strcmp(key, "rate_count_static")) { g_rate_static = value; return 0; }
     if (!strcmp(key, "host_pin")) {
         if (G.dev && avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_HOST_PIN, value)) return fail(-10, "%s", avdsp_hip_last_error());
         G.opt_host_pin = value;
@@ -161,6 +233,20 @@ int dspRuntimeSetOption(const char *key, int value)
         return 0;
     }
     return fail(-1, "unknown option '%s'", key);
+}
+
+/* An option goes to the current program AND becomes the default of programs loaded later (one program per process, the
+ * usual case, then behaves as if options were process-wide). */
+int dspRuntimeSetOption(const char *key, int value)
+{
+    int rc = set_option_here(key, value);
+    if (!rc && g_cur != &g_template) {
+        avdsp_ctx *keep = g_cur;
+        g_cur = &g_template;
+        rc = set_option_here(key, value);
+        g_cur = keep;
+    }
+    return rc;
 }
 
 int dspRuntimeGetOption(const char *key)
@@ -198,6 +284,7 @@ static void shard_range(int total, int world, int rank, int *lo, int *hi)
 int dspRuntimeSetShard(int rank, int world)
 {
     if (world < 1 || rank < 0 || rank >= world) return fail(-1, "shard %d of %d: need 0 <= rank < world", rank, world);
+    g_template.shard_rank = rank; g_template.shard_world = world;       /* programs loaded later start with it (as options do) */
     if (rank == G.shard_rank && world == G.shard_world) return 0;
     G.shard_rank = rank; G.shard_world = world;
     return replan();                     /* the FIR histories go back into the mirror; cores are lowered again */
@@ -206,6 +293,7 @@ int dspRuntimeSetShard(int rank, int world)
 /* ---- dsp_runtime.c:42-59 ---- */
 opcode_t *dspFindCore(opcode_t *codePtr, const int numCore)
 {
+    (void)ctx_of(codePtr);
     if (codePtr->op.opcode != DSP_HEADER) return 0;
     opcode_t *p = codePtr;
     int seen = 0;
@@ -224,6 +312,7 @@ opcode_t *dspFindCore(opcode_t *codePtr, const int numCore)
 /* ---- dsp_runtime.c:62-77 ---- */
 opcode_t *dspFindCoreBegin(opcode_t *p)
 {
+    if (p) (void)ctx_of(p);
     const opcode_t *end = (dspHeaderPtr && G.code && p >= G.code && p < G.code + dspHeaderPtr->totalLength)
                               ? G.code + dspHeaderPtr->totalLength : 0;        /* as in dspFindCore */
     if (p && p->op.opcode == DSP_CORE)
@@ -247,6 +336,7 @@ int dspRuntimeReset(const int fs, int random, int defaultDither)
     if (idx < mn || idx > mx) return fail(-2, "sampling frequency %d outside the program's range", fs);
     G.freq_index = idx - mn;
     G.num_freq = mx - mn + 1;
+    g_rate_static = G.num_freq;
     dspBiquadFreqSkip = 2 + 6 * G.num_freq;
     G.biquad_offset = 5 + 6 * G.freq_index;
     G.have_rate = 1;
@@ -272,10 +362,37 @@ int dspRuntimeReset(const int fs, int random, int defaultDither)
 /* ---- dsp_runtime.c:150-195 ---- */
 int dspRuntimeInit(opcode_t *codePtr, int maxSize, const int fs, int random, int defaultDither)
 {
+    /* the program's context: the one this buffer already has (loaded again: it starts clean), or a new one with the
+     * options in force now */
+    avdsp_ctx *c = 0;
+    for (int i = 0; i < g_nctx; i++) if (g_ctx[i]->code == codePtr) c = g_ctx[i];
+    /* a program that overlaps this buffer can only be one whose buffer the caller has freed since: forget it */
+    if (codePtr->op.opcode == DSP_HEADER) {
+        const dspHeader_t *h = (const dspHeader_t *)codePtr;
+        const opcode_t *lo = codePtr, *hi = codePtr + (long long)h->totalLength + (h->dataSize > 0 ? h->dataSize : 0);
+        for (int i = 0; i < g_nctx; )
+            if (g_ctx[i] != c && g_ctx[i]->code < hi && lo <= g_ctx[i]->code + g_ctx[i]->total_words) ctx_destroy(g_ctx[i]);
+            else i++;
+    }
+    if (!c) {
+        if (g_nctx == MAX_PROGRAMS) return fail(-9, "%d programs are loaded already: dspRuntimeReleaseProgram() the ones no longer used", MAX_PROGRAMS);
+        c = (avdsp_ctx *)calloc(1, sizeof *c);
+        if (!c) return fail(-9, "out of memory");
+        const avdsp_ctx *o = &g_template;
+        c->opt_fir_impl = o->opt_fir_impl; c->opt_biquad_impl = o->opt_biquad_impl; c->opt_device = o->opt_device; c->opt_profile = o->opt_profile;
+        c->opt_generic = o->opt_generic; c->opt_interp_impl = o->opt_interp_impl; c->opt_strand_split = o->opt_strand_split;
+        c->opt_overlap = o->opt_overlap; c->opt_fir_rows = o->opt_fir_rows; c->opt_host_split = o->opt_host_split; c->opt_host_pin = o->opt_host_pin;
+        c->shard_rank = o->shard_rank; c->shard_world = o->shard_world;
+        c->mantissa = DSP_MANT; c->device_ordinal = -1;
+        c->code = codePtr;
+        g_ctx[g_nctx++] = c;
+    }
+    ctx_make_current(c);
     drop_device();
     G.have_rate = 0;
     dspHeaderPtr = (dspHeader_t *)codePtr;
     G.code = codePtr;
+    G.total_words = 0;
     if (codePtr->op.opcode != DSP_HEADER) return fail(-1, "no dsp header in this program");
     int length = dspHeaderPtr->totalLength, size = dspHeaderPtr->dataSize;
     if (size + length > maxSize)
@@ -292,7 +409,7 @@ int dspRuntimeInit(opcode_t *codePtr, int maxSize, const int fs, int random, int
      * then (ensure_encoding), with the rate count the reference would have used at THIS point -- the one the previous
      * dspRuntimeReset of the process left behind, 0 the first time (dspNumSamplingFreq is a static that Init does not
      * touch, :106,131), which is why a freshly loaded program's biquad banks stay unconverted there and here. */
-    G.numfreq_at_init = G.num_freq;
+    G.numfreq_at_init = g_rate_static;
     G.total_words = length + size;
     if (fs) { int r = dspRuntimeReset(fs, random, defaultDither); if (r) return r; }
     return length;
@@ -1001,7 +1118,13 @@ static int scan_generic(int format, opcode_t *core, int end_word, avdsp_generic_
 
 static int select_device(void)
 {
-    if (G.device_selected) return 0;
+    if (G.device_selected) {
+        if (G.device_ordinal != g_active_device) {      /* another program's GPU was active */
+            if (avdsp_hip_set_device(G.device_ordinal)) return fail(-10, "%s", avdsp_hip_last_error());
+            g_active_device = G.device_ordinal;
+        }
+        return 0;
+    }
     int n = avdsp_hip_device_count();
     if (n <= 0) return fail(-10, "no HIP device: %s", avdsp_hip_last_error());
     int want = G.opt_device;
@@ -1011,6 +1134,7 @@ static int select_device(void)
     }
     if (avdsp_hip_set_device(want)) return fail(-10, "%s", avdsp_hip_last_error());
     G.device_selected = 1;
+    G.device_ordinal = want; g_active_device = want;
     return 0;
 }
 
@@ -1124,6 +1248,7 @@ int dspRuntimeKernelTime(int kind, double *total_ms, int *launches)
 /* Host-only: lowers the core (no device is touched) and reports what the plan would contain. */
 int dspRuntimeCoreInfo(int format, opcode_t *core, int *nchains, int *max_sections, int *max_taps)
 {
+    (void)ctx_of(core);
     if (!dspHeaderPtr || !G.code) return fail(-1, "no program loaded");
     if (!G.have_rate) return fail(-1, "dspRuntimeReset(fs) has not selected a sample rate yet");
     if (format < 2 || format > 6) return fail(-1, "DSP_FORMAT %d is not one of 2..6", format);
@@ -1158,6 +1283,7 @@ int dspRuntimeCoreInfo(int format, opcode_t *core, int *nchains, int *max_sectio
 int dspRuntimeShardInfo(int format, opcode_t *core, int *total_chains, int *first_chain, int *nchains,
                         int *in_io_min, int *in_io_max, int *out_io_min, int *out_io_max)
 {
+    (void)ctx_of(core);
     if (!dspHeaderPtr || !G.code) return fail(-1, "no program loaded");
     if (!G.have_rate) return fail(-1, "dspRuntimeReset(fs) has not selected a sample rate yet");
     if (format < 2 || format > 6) return fail(-1, "DSP_FORMAT %d is not one of 2..6", format);
@@ -1214,6 +1340,7 @@ int dspRuntimeBlockDevice(int format, opcode_t *core, int *rundata,
                           const void *d_in, int in_stride, int in_io_base,
                           void *d_out, int out_stride, int out_io_base, int nframes, void *stream)
 {
+    (void)ctx_of(core);
     core_plan *cp = get_plan(format, core);
     if (!cp) return g_err_code;
     if (check_rundata(rundata)) return -1;
@@ -1230,6 +1357,7 @@ int dspRuntimeBlockDevice(int format, opcode_t *core, int *rundata,
 static int block_host(int format, opcode_t *core, int *rundata, const void *in, int in_stride, int in_io_base,
                       void *out, int out_stride, int out_io_base, int nframes)
 {
+    (void)ctx_of(core);
     core_plan *cp = get_plan(format, core);
     if (!cp) return g_err_code;
     if (check_rundata(rundata)) return -1;
@@ -1248,6 +1376,7 @@ static int block_host(int format, opcode_t *core, int *rundata, const void *in, 
 int dspRuntimeBlockSubmit(int format, opcode_t *core, int *rundata, const void *in, int in_stride, int in_io_base,
                           void *out, int out_stride, int out_io_base, int nframes)
 {
+    (void)ctx_of(core);
     core_plan *cp = get_plan(format, core);
     if (!cp) return g_err_code;
     if (check_rundata(rundata)) return -1;
@@ -1538,16 +1667,19 @@ static int block_all(int format, int *rundata, const void *in, int in_stride, in
 
 int dspRuntimeBlockAll(int format, int *rundata, const void *in, int in_stride, int in_io_base,
                        void *out, int out_stride, int out_io_base, int nframes)
-{ return block_all(format, rundata, in, in_stride, in_io_base, out, out_stride, out_io_base, nframes, 0, 0, AVDSP_PCM_S32, 0); }
+{
+    (void)ctx_of(rundata); return block_all(format, rundata, in, in_stride, in_io_base, out, out_stride, out_io_base, nframes, 0, 0, AVDSP_PCM_S32, 0); }
 
 int dspRuntimeBlockAllDevice(int format, int *rundata, const void *d_in, int in_stride, int in_io_base,
                              void *d_out, int out_stride, int out_io_base, int nframes, void *stream)
-{ return block_all(format, rundata, d_in, in_stride, in_io_base, d_out, out_stride, out_io_base, nframes, 1, stream, AVDSP_PCM_S32, 0); }
+{
+    (void)ctx_of(rundata); return block_all(format, rundata, d_in, in_stride, in_io_base, d_out, out_stride, out_io_base, nframes, 1, stream, AVDSP_PCM_S32, 0); }
 
 /* linux/avdsp_plugin.c:95-142 whole: packed PCM in (:109-121), every core, S32 out */
 int dspRuntimeBlockAllPcm(int format, int *rundata, int pcm, const void *src, int in_stride, int in_io_base,
                           int *dst, int out_stride, int out_io_base, int nframes)
 {
+    (void)ctx_of(rundata);
     if (format != 2 && format != 3 && format != 4)
         return fail(-1, "packed PCM feeds the int-sample formats 2, 3 and 4 (DSP_FORMAT %d has float samples)", format);
     return block_all(format, rundata, src, in_stride, in_io_base, dst, out_stride, out_io_base, nframes, 0, 0, pcm, 0);
@@ -1557,6 +1689,7 @@ int dspRuntimeBlockAllPcm(int format, int *rundata, int pcm, const void *src, in
 int dspRuntimeBlockPcm(int format, opcode_t *core, int *rundata, int pcm, const void *src, int in_stride, int in_io_base,
                        int *dst, int out_stride, int out_io_base, int nframes)
 {
+    (void)ctx_of(core);
     if (format != 2 && format != 3 && format != 4)
         return fail(-1, "packed PCM feeds the int-sample formats 2, 3 and 4 (DSP_FORMAT %d has float samples)", format);
     core_plan *cp = get_plan(format, core);
@@ -1614,6 +1747,7 @@ int dspRuntimeUnpackPcmDevice(int pcm, const void *d_src, int *d_dst, long long 
  * array (IO numbers index it directly).  The window is the span of IO numbers the core touches. */
 static int one_frame(int format, opcode_t *core, int *rundata, void *samples)
 {
+    (void)ctx_of(core);
     core_plan *cp = get_plan(format, core);
     if (!cp) return g_err_code;
     /* the device side knows the IO span of the plan: stride 0 asks it to use that span */
@@ -1628,6 +1762,7 @@ int dspRuntime_6(opcode_t *core, int *rundata, float *samples) { return one_fram
 
 int dspRuntimeSyncState(int *rundata)
 {
+    (void)ctx_of(rundata);
     if (!dspHeaderPtr) return fail(-1, "no program loaded");
     if (check_rundata(rundata)) return -1;
     if (!G.dev || !G.dev_state_valid) return 0;              /* nothing ran yet: host copy is current */
@@ -1656,6 +1791,7 @@ int dspRuntimeUploadParams(void)
 
 int dspRuntimeUploadState(const int *rundata)
 {
+    (void)ctx_of(rundata);
     if (!dspHeaderPtr) return fail(-1, "no program loaded");
     if (check_rundata(rundata)) return -1;
     if (!G.dev) return 0;                                     /* uploaded with the whole buffer at first use */

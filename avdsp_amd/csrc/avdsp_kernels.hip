@@ -282,7 +282,15 @@ struct BiquadArgs {
     Ring            ring;           /* where (float)X goes when a FIR follows the cascade */
     int             per_xcd;
     BlockIO         io;
+#ifdef AVDSP_BQ_STAMPS
+    unsigned long long *stamps;     /* diagnostic build (tools/cascade_timeline.py): 32 s_memtime stamps per wave */
+#endif
 };
+#ifdef AVDSP_BQ_STAMPS
+#define BQ_STAMP(i) do { if ((threadIdx.x & 63) == 0 && (i) < 32) a.stamps[(size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define BQ_STAMP(i) do { } while (0)
+#endif
 
 template <int CTRL>
 __device__ __forceinline__ unsigned dpp_mov(unsigned old, unsigned src)
@@ -374,6 +382,7 @@ template <int FMT, int P>
 __global__ __launch_bounds__(kBlock) void biquad_pipe(const BiquadArgs a)
 {
     if constexpr (FMT != 2) flush_f32_subnormals_like_the_reference();
+    BQ_STAMP(0);
     using alu_t = typename Alu<FMT>::type;
     constexpr int NB = P < 16 ? P : 16;                 /* steps per IO batch */
     constexpr int CPB = kBlock / P;                       /* chains per block */
@@ -532,11 +541,13 @@ __global__ __launch_bounds__(kBlock) void biquad_pipe(const BiquadArgs a)
      * s_waitcnt (profiles/r01_cfg3: SQ_WAIT_ANY 33 %). */
     Hand<FMT> ib = hand_from_sample<FMT>(rawq[0], c);
     rawq[0] = fetch(DEPTH);
+    BQ_STAMP(1);
     for (int b0 = 0; b0 < nbatches; b0 += DEPTH) {      /* (up to DEPTH - 1 batches past the end: every step masked, nothing stored) */
 #pragma unroll
         for (int j = 0; j < DEPTH; j++) {
             const int b = b0 + j;
             const int tb = b * NB;
+            if (b >= 12 && b < 36) BQ_STAMP(2 + b - 12);
             if (tb >= 2 * nsec - 1 && tb + NB <= B + 1) {   /* every lane busy for the whole batch */
                 if constexpr (FMT == 6 && P == 16) {
                     /* The same thirteen instructions per step, in an order the compiler does not find: it issues the
@@ -612,6 +623,7 @@ __global__ __launch_bounds__(kBlock) void biquad_pipe(const BiquadArgs a)
      * sits in its x / y state.  One look at the end of the block, no cost inside the loop: a chain with a trace in any of
      * its sections writes nothing back (the mirror still holds the state the block started from) and its first lane
      * runs the block again in the reference's own order with the reference's products.  Audio never gets here.   */
+    BQ_STAMP(28);
     bool replay = false;
     if constexpr (FMT != 2) {
         const unsigned long long ab = (unsigned long long)__double_as_longlong(acc);
@@ -633,6 +645,7 @@ __global__ __launch_bounds__(kBlock) void biquad_pipe(const BiquadArgs a)
     if constexpr (FMT != 2) {
         if (replay && have_chain && s == 0) cascade_in_reference_order<FMT>(a, cid, c);
     }
+    BQ_STAMP(29);
 }
 
 /* lane per chain, the reference's loop order: cross-check path, and cascades longer than 64 sections */
@@ -1671,6 +1684,18 @@ struct ProfileScope {                   /* records an event pair around the laun
     }
 };
 
+#ifdef AVDSP_BQ_STAMPS
+static unsigned long long *g_bq_stamps = nullptr; static int g_bq_stamp_waves = 0;
+extern "C" int avdsp_hip_debug_bq_stamps(unsigned long long *host_out, int max_waves)
+{
+    if (!g_bq_stamps) return 0;
+    const int n = g_bq_stamp_waves < max_waves ? g_bq_stamp_waves : max_waves;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpy(host_out, g_bq_stamps, (size_t)n * 32 * 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return n;
+}
+#endif
+
 template <int FMT>
 int launch_biquad(avdsp_hip_prog *prog, Plan &pl, const Plan::Group &g, const int *ids, int n, BlockIO io,
                   int biquad_impl, hipStream_t stream)
@@ -1679,6 +1704,14 @@ int launch_biquad(avdsp_hip_prog *prog, Plan &pl, const Plan::Group &g, const in
     BiquadArgs a{};
     a.buf = prog->d_buf; a.chains = pl.d_chains; a.sec_coef = pl.d_sec_coef; a.sec_state = pl.d_sec_state;
     a.group = ids; a.ngroup = n; a.nsec = g.nsec; a.ring = plan_ring(pl); a.io = io;
+#ifdef AVDSP_BQ_STAMPS
+    {
+        static unsigned long long *d_stamps = nullptr;
+        if (!d_stamps) { HIP_TRY(hipMalloc((void **)&d_stamps, (size_t)65536 * 4 * 32 * 8)); }
+        HIP_TRY(hipMemsetAsync(d_stamps, 0, (size_t)65536 * 4 * 32 * 8, stream));
+        a.stamps = d_stamps; g_bq_stamps = d_stamps; g_bq_stamp_waves = ((n * g.P + kBlock - 1) / kBlock + 7) / 8 * 8 * 4;
+    }
+#endif
     if (biquad_impl == 0 || g.P > 64) {
         hipLaunchKernelGGL(biquad_simple<FMT>, dim3((n + 63) / 64), dim3(64), 0, stream, a);
     } else {

@@ -29,7 +29,7 @@ EXPORTED = [
     "dspRuntimeBlock_2", "dspRuntimeBlock_3", "dspRuntimeBlock_4", "dspRuntimeBlock_5", "dspRuntimeBlock_6",
     "dspRuntimeBlockSubmit", "dspRuntimeBlockWait", "dspRuntimeBlockDevice", "dspRuntimeBlockPcm", "dspRuntimeUnpackPcmDevice", "dspRuntimeBlockAll", "dspRuntimeBlockAllDevice", "dspRuntimeBlockAllPcm",
     "dspRuntimeSyncState", "dspRuntimeUploadState", "dspRuntimeUploadParams", "dspRuntimeSetOption", "dspRuntimeGetOption",
-    "dspRuntimeCoreInfo", "dspRuntimeKernelTime", "dspRuntimeLastError", "dspRuntimeRelease",
+    "dspRuntimeCoreInfo", "dspRuntimeKernelTime", "dspRuntimeLastError", "dspRuntimeRelease", "dspRuntimeReleaseProgram", "dspRuntimeSelect",
     "dspRuntimeSetShard", "dspRuntimeShardInfo", "dspRuntimeTagOutput", "dspRuntimeTagOutputDevice", "dspRuntimeTagOutputReset",
     # thin HIP ABI (include/avdsp_hip.h)
     "avdsp_hip_device_count", "avdsp_hip_set_device", "avdsp_hip_prog_create", "avdsp_hip_prog_destroy",
@@ -123,6 +123,8 @@ def lib() -> C.CDLL:
         L.dspRuntimeKernelTime.argtypes = [i32, C.POINTER(C.c_double), C.POINTER(i32)]
         L.dspRuntimeLastError.restype = C.c_char_p
         L.dspRuntimeRelease.restype = None
+        L.dspRuntimeReleaseProgram.restype = i32; L.dspRuntimeReleaseProgram.argtypes = [vp]
+        L.dspRuntimeSelect.restype = i32; L.dspRuntimeSelect.argtypes = [vp]
         L.dspQNM.restype = C.c_longlong; L.dspQNM.argtypes = [C.c_double, i32, i32]
         L.dspQM64.restype = C.c_longlong; L.dspQM64.argtypes = [C.c_double, i32]
         L.dspQM32.restype = i32; L.dspQM32.argtypes = [C.c_double, i32]
@@ -176,14 +178,21 @@ class Runtime:
             raise AvdspError(rc, self.last_error())
         return rc
 
+    def _select(self):
+        """Several programs may be loaded in one process: calls that carry no program pointer address the one selected last."""
+        if self.rc >= 0:
+            self.L.dspRuntimeSelect(self.buf.ctypes.data)
+
     @property
     def state(self) -> np.ndarray:
         return self.buf[self.rc:self.rc + int(self.buf[2])]
 
     def reset(self, fs: int, random: int = 0, dither: int = 31) -> int:
+        self._select()
         return self.L.dspRuntimeReset(fs, random, dither)
 
     def set_option(self, key: str, value: int):
+        self._select()
         self._check(self.L.dspRuntimeSetOption(key.encode(), value))
 
     @staticmethod
@@ -199,11 +208,13 @@ class Runtime:
 
     def tag_output(self, out: np.ndarray, column: int):
         """dspRuntimeTagOutput on a host block [frames][out_stride] of int32, in place (linux/avdsp_plugin.c:133-137)."""
+        self._select()
         assert out.dtype == np.int32 and out.flags.c_contiguous
         self._check(self.L.dspRuntimeTagOutput(out.ctypes.data, out.shape[1], column, out.shape[0]))
 
     def set_shard(self, rank: int, world: int):
         """dspRuntimeSetShard: this process runs chains shard_range(total, world, rank) of every chain core."""
+        self._select()
         self._check(self.L.dspRuntimeSetShard(rank, world))
 
     def shard_info(self, core_index: int = 0):
@@ -252,6 +263,7 @@ class Runtime:
 
     def wait_blocks(self, max_in_flight: int = 0) -> int:
         """dspRuntimeBlockWait: returns when at most max_in_flight submitted blocks are unfinished."""
+        self._select()
         rc = self.L.dspRuntimeBlockWait(max_in_flight)
         self._check(min(rc, 0))
         return rc
@@ -287,6 +299,7 @@ class Runtime:
         return out
 
     def get_option(self, key: str) -> int:
+        self._select()
         return self.L.dspRuntimeGetOption(key.encode())
 
     def run_block_pcm(self, pcm: int, raw: np.ndarray, nframes: int, in_stride: int, out_stride: int,
@@ -316,6 +329,7 @@ class Runtime:
     def kernel_time(self, kind: int):
         """(total_ms, launches) of the kernels of `kind` (0 biquad, 1 FIR, 2 pass) since the last read;
         needs set_option("profile", 1)."""
+        self._select()
         ms, n = C.c_double(), C.c_int()
         self._check(self.L.dspRuntimeKernelTime(kind, C.byref(ms), C.byref(n)))
         return ms.value, n.value
@@ -329,7 +343,16 @@ class Runtime:
 
     def upload_params(self):
         """After editing parameter words in self.buf in place."""
+        self._select()
         self._check(self.L.dspRuntimeUploadParams())
 
     def release(self):
-        self.L.dspRuntimeRelease()
+        """Frees this program's device memory (dspRuntimeReleaseProgram); other loaded programs stay."""
+        if self.rc >= 0:
+            self.L.dspRuntimeReleaseProgram(self.buf.ctypes.data)
+
+    def __del__(self):
+        try:                                                  # the buffer goes with this object: so does the program's context
+            self.release()
+        except Exception:
+            pass

@@ -195,7 +195,17 @@ int dspRuntimeKernelTime(int kind, double *total_ms, int *launches);
 int dspRuntimeCoreInfo(int format, opcode_t *core, int *nchains, int *max_sections, int *max_taps);
 
 const char *dspRuntimeLastError(void);
-void        dspRuntimeRelease(void);        /* frees device memory; the next Init starts clean */
+void        dspRuntimeRelease(void);        /* frees device memory of every loaded program; the next Init starts clean */
+/* Several programs in one process.  dspRuntimeInit(codePtr, ...) loads a program into a context of its own, keyed by the
+ * caller's buffer (loading the same buffer again restarts that program); every call that takes a pointer into a program
+ * -- a core, its data area -- addresses that program, and the reference's exported data (dspHeaderPtr, dspBiquadFreqSkip,
+ * dspMantissa) follow.  Calls without one (dspRuntimeReset, options, shard, timers, tagoutput, wait) address the program
+ * of the latest call that named one, or dspRuntimeSelect's.  Each program has its own device copy, GPU ("device"
+ * option at the time of its first block call), shard and plans; an option set while a program is current also becomes
+ * the default of programs loaded later.  One process can so drive several GPUs (one buffer per GPU, each with its
+ * dspRuntimeSetShard), or several programs on one.  Up to 64.                                                    */
+int         dspRuntimeSelect(const void *ptr_into_program);
+int         dspRuntimeReleaseProgram(opcode_t *codePtr);
 
 #ifdef __cplusplus
 }

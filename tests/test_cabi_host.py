@@ -163,3 +163,30 @@ def test_no_cpu_fallback_without_a_gpu():
     frame = np.zeros(4, dtype=np.float32)
     with pytest.raises(rt.AvdspError):
         r.run_frame(frame)
+
+
+def test_programs_are_contexts_keyed_by_their_buffer():
+    """host-only: two loaded programs, calls find theirs by pointer, the reference's exported data follow, release is per program"""
+    import ctypes as C
+    from avdsp_amd import progbuilder as pb
+    from avdsp_amd import runtime as rt
+    L = rt.lib()
+    try:
+        a = rt.Runtime(6, pb.synth_program(6, 8, 2, 40))
+        b = rt.Runtime(2, pb.synth_program(2, 5, 3, 0))
+        hdr = C.c_void_p.in_dll(L, "dspHeaderPtr")
+        assert hdr.value == b.buf.ctypes.data
+        ia = a.shard_info()                                   # names a core of program a: a becomes current
+        assert hdr.value == a.buf.ctypes.data and ia["total_chains"] == 8
+        assert b.shard_info()["total_chains"] == 5 and hdr.value == b.buf.ctypes.data
+        a.set_shard(1, 2)
+        assert a.shard_info()["nchains"] == 4 and a.shard_info()["first_chain"] == 4
+        assert b.shard_info()["nchains"] == 5                 # b keeps its own (whole) shard
+        assert L.dspRuntimeSelect(a.buf.ctypes.data + 16) == 0 and L.dspRuntimeGetOption(b"shard_rank") == 1
+        assert L.dspRuntimeSelect(0) < 0
+        a.release()
+        assert L.dspRuntimeSelect(a.buf.ctypes.data) < 0 and L.dspRuntimeSelect(b.buf.ctypes.data) == 0
+        assert L.dspRuntimeReleaseProgram(a.buf.ctypes.data) < 0
+    finally:
+        L.dspRuntimeSetShard(0, 1)
+        L.dspRuntimeRelease()
