@@ -313,10 +313,10 @@ __device__ __forceinline__ unsigned from_prev_lane(unsigned old, unsigned v)
 template <int FMT> struct Hand { unsigned y; };
 
 template <int FMT>
-__device__ __forceinline__ Hand<FMT> hand_from_sample(unsigned raw, const avdsp_chain &c)
+__device__ __forceinline__ Hand<FMT> hand_from_sample(unsigned raw, int load_mode, unsigned gain_bits)
 {
     Hand<FMT> h;
-    h.y = narrow_stage<FMT>(load_stage<FMT>(raw, c.load_mode, c.gain_bits));
+    h.y = narrow_stage<FMT>(load_stage<FMT>(raw, load_mode, gain_bits));
     return h;
 }
 
@@ -392,7 +392,9 @@ __global__ __launch_bounds__(kBlock) void biquad_pipe(const BiquadArgs a)
     const int blk = xcd_remap(blockIdx.x, a.per_xcd);
     const int slot = blk * CPB + tid / P;
     const int s = tid % P;
-    const int nsec = a.nsec, B = a.io.nframes;
+    const Ring ring_l = a.ring;                         /* by value: the lambdas below must not make the kernel arguments addressable */
+    const BlockIO io_l = a.io;
+    const int nsec = a.nsec, B = io_l.nframes;
     const bool have_chain = slot < a.ngroup;
     const int cid = have_chain ? a.group[slot] : 0;
     const avdsp_chain c = a.chains[cid];
@@ -448,11 +450,11 @@ __global__ __launch_bounds__(kBlock) void biquad_pipe(const BiquadArgs a)
     /* input batches: lane s < NB of a channel fetches frame (batch*NB + s), clamped into the block.  Every lane loads
      * (the others a word of their channel nobody looks at): a load under a branch would hide from the compiler how many
      * memory operations follow it, and it would then wait for ALL of them before each batch (s_waitcnt vmcnt(0)). */
-    const unsigned *inp = a.io.in + (c.in_io - a.io.in_base);
-    auto fetch = [&](int batch) -> unsigned {
+    const unsigned *inp = io_l.in + (c.in_io - io_l.in_base);
+    auto fetch = [&](int batch) __attribute__((always_inline)) -> unsigned {
         int n = batch * NB + (s & (NB - 1));
         n = n < B ? n : B - 1;
-        return inp[(size_t)n * a.io.in_stride];
+        return inp[(size_t)n * io_l.in_stride];
     };
     unsigned rawq[DEPTH];
 #pragma unroll
@@ -471,7 +473,7 @@ __global__ __launch_bounds__(kBlock) void biquad_pipe(const BiquadArgs a)
      * DPP move and widening conversion lie a whole step ahead of their use instead of at the head of the dependent
      * chain -- the loop-carried chain of a step is then the five accumulations alone (it was those five plus
      * cvt, DPP, cvt: 132 cycles per step with one wave per SIMD).  Costs nsec-1 more steps of fill per block.   */
-    auto step = [&](Hand<FMT> &ib, int u, auto masked) {
+    auto step = [&](Hand<FMT> &ib, int u, auto masked) __attribute__((always_inline)) {
         const Hand<FMT> ibr = hand_rotate<FMT, kRowRor15>(ib);
         Hand<FMT> xnext;
         xnext.y = from_prev_lane<P>(ib.y, hy.y);
@@ -539,17 +541,13 @@ __global__ __launch_bounds__(kBlock) void biquad_pipe(const BiquadArgs a)
      * (rawq[k] = rawq[k+1]) moves registers that loads are still in flight to, which costs a wait for the YOUNGEST
      * load at every batch -- the prefetch distance was one batch, not three, and a third of the kernel's time was
      * s_waitcnt (profiles/r01_cfg3: SQ_WAIT_ANY 33 %). */
-    Hand<FMT> ib = hand_from_sample<FMT>(rawq[0], c);
+    const int c_load_mode = c.load_mode; const unsigned c_gain_bits = c.gain_bits;      /* (scalars: the chain record itself stays out of the lambdas) */
+    Hand<FMT> ib = hand_from_sample<FMT>(rawq[0], c_load_mode, c_gain_bits);
     rawq[0] = fetch(DEPTH);
     BQ_STAMP(1);
-    for (int b0 = 0; b0 < nbatches; b0 += DEPTH) {      /* (up to DEPTH - 1 batches past the end: every step masked, nothing stored) */
-#pragma unroll
-        for (int j = 0; j < DEPTH; j++) {
-            const int b = b0 + j;
-            const int tb = b * NB;
-            if (b >= 12 && b < 36) BQ_STAMP(2 + b - 12);
-            if (tb >= 2 * nsec - 1 && tb + NB <= B + 1) {   /* every lane busy for the whole batch */
-                if constexpr (FMT == 6 && P == 16) {
+    /* the NB steps of a batch in which every lane is busy */
+    auto fast_steps = [&](int tb) __attribute__((always_inline)) {
+        if constexpr (FMT == 6 && P == 16) {
                     /* The same thirteen instructions per step, in an order the compiler does not find: it issues the
                      * five dependent v_fma_f64 back to back (each waits ~4 cycles for its predecessor) and the eight
                      * independent instructions after them.  Here one of those sits behind every FMA, and the first FMA of
@@ -593,28 +591,91 @@ __global__ __launch_bounds__(kBlock) void biquad_pipe(const BiquadArgs a)
 #pragma unroll
                     for (int i = 0; i < NB; i++) step(ib, tb + i, std::false_type{});
                 }
-            } else {
+    };
+    /* what a lane's output-batch register holds, as the word that goes to the ring (a FIR follows) or to the output block */
+    auto flush_word = [&](bool to_ring) __attribute__((always_inline)) -> unsigned {
+        if constexpr (FMT == 4) {
+            const double X = __longlong_as_double((long long)(((unsigned long long)ob_hi << 32) | ob_lo));
+            return to_ring ? narrow_stage<FMT>(X) : store_stage<FMT>(X, oc.sat, io_l.store_mask);
+        } else if constexpr (FMT == 6) {
+            return to_ring ? ob_lo : (oc.sat ? __float_as_uint(saturate_f32_0db(__uint_as_float(ob_lo))) : ob_lo);
+        } else
+            return ob_lo & (unsigned)io_l.store_mask;
+    };
+    constexpr int kNext[3] = {1 % DEPTH, 2 % DEPTH, 0};
+    /* a batch anywhere in the block: steps masked where the pipeline fills or drains, fetch clamped into the block, flush checked */
+    auto batch_any = [&](int b, auto jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;
+        const int tb = b * NB;
+        if (tb >= 2 * nsec - 1 && tb + NB <= B + 1) fast_steps(tb);
+        else {
 #pragma unroll
-                for (int i = 0; i < NB; i++) step(ib, tb + i, std::true_type{});
-            }
-            /* batch b+1's samples were requested DEPTH batches ago; its slot is then refilled for batch b+1+DEPTH */
-            constexpr int kNext[3] = {1 % DEPTH, 2 % DEPTH, 0};
-            ib = hand_from_sample<FMT>(rawq[kNext[j]], c);
-            rawq[kNext[j]] = fetch(b + 1 + DEPTH);
-            /* flush the output batch: this lane holds the result of step tb + ostep of chain `ocid` */
-            const int n = tb + ostep - 1 - 2 * (nsec - 1);
-            if (owner && n >= 0 && n < B) {
-                if constexpr (FMT == 4) {
-                    const double X = __longlong_as_double((long long)(((unsigned long long)ob_hi << 32) | ob_lo));
-                    if (oc.fir_taps) ring_put(a.ring, ocid, n, narrow_stage<FMT>(X));
-                    else emit_out(a.io, oc, n, store_stage<FMT>(X, oc.sat, a.io.store_mask));
-                } else if constexpr (FMT == 6) {
-                    if (oc.fir_taps) ring_put(a.ring, ocid, n, ob_lo);
-                    else emit_out(a.io, oc, n, oc.sat ? __float_as_uint(saturate_f32_0db(__uint_as_float(ob_lo))) : ob_lo);
-                } else
-                    emit_out(a.io, oc, n, ob_lo & (unsigned)a.io.store_mask);
-            }
+            for (int i = 0; i < NB; i++) step(ib, tb + i, std::true_type{});
         }
+        /* batch b+1's samples were requested DEPTH batches ago; its slot is then refilled for batch b+1+DEPTH */
+        ib = hand_from_sample<FMT>(rawq[kNext[j]], c_load_mode, c_gain_bits);
+        rawq[kNext[j]] = fetch(b + 1 + DEPTH);
+        /* flush the output batch: this lane holds the result of step tb + ostep of chain `ocid` */
+        const int n = tb + ostep - 1 - 2 * (nsec - 1);
+        if (owner && n >= 0 && n < B) {
+            if (FMT != 2 && oc.fir_taps) ring_put(ring_l, ocid, n, flush_word(true));
+            else emit_out(io_l, oc, n, flush_word(false));
+        }
+    };
+    /* The batches in the middle of the block -- all but the first and the last few -- need none of that: every step is busy,
+     * every fetched frame and every flushed frame lies inside the block, and from one batch to the next each lane's input
+     * pointer, output pointer and ring position advance by a constant.  (tools/cascade_timeline.py: with the checks, the 64-bit
+     * address products and the merge of the two step variants, a batch's 16 steps of 55 cycles each took 1370-1500 cycles.) */
+    const int bs = ((2 * nsec - 1 + NB - 1) / NB + DEPTH - 1) / DEPTH * DEPTH;       /* first steady batch, a multiple of DEPTH */
+    const int be = (B / NB - 1 - DEPTH) / DEPTH * DEPTH;                             /* behind the last: (b + 2 + DEPTH) NB <= B for b < be */
+    int b0 = 0;
+    for (; b0 < nbatches && (b0 < bs || be <= bs); b0 += DEPTH) {
+        batch_any(b0, std::integral_constant<int, 0>{}); batch_any(b0 + 1, std::integral_constant<int, 1>{}); batch_any(b0 + 2, std::integral_constant<int, 2>{});
+    }
+    if (b0 < be) {
+        const unsigned *in_run = inp + (size_t)((b0 + 1 + DEPTH) * NB + (s & (NB - 1))) * io_l.in_stride;
+        const size_t in_step = (size_t)NB * io_l.in_stride, out_step = (size_t)NB * io_l.out_stride;
+        const int n0 = b0 * NB + ostep - 1 - 2 * (nsec - 1);                         /* the frame this lane flushes in batch b0 */
+        const bool to_ring = FMT != 2 && oc.fir_taps != 0;
+        const unsigned rmask = (unsigned)ring_l.R - 1u;
+        unsigned ridx = ((unsigned)(ring_l.wpos + n0)) & rmask;
+        float *rrow = ring_l.base + (size_t)ocid * ring_l.R;
+        double *wrow = ring_l.wide ? ring_l.wide + (size_t)ocid * ring_l.R : nullptr;
+        unsigned *out_run = io_l.out + (size_t)n0 * io_l.out_stride + (oc.out_io[0] - io_l.out_base);
+        const bool more_stores = owner && !to_ring && oc.n_out > 1;
+        int n_run = n0;
+        auto batch_steady = [&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;
+            fast_steps(0);
+            ib = hand_from_sample<FMT>(rawq[kNext[j]], c_load_mode, c_gain_bits);
+            rawq[kNext[j]] = *in_run;
+            in_run += in_step;
+            if (owner) {
+                if (to_ring) {
+                    const unsigned w = flush_word(true);
+                    rrow[ridx] = __uint_as_float(w);
+                    if (wrow) wrow[(ridx + 3u) & rmask] = mulop(__uint_as_float(w));
+                } else {
+                    const unsigned w = flush_word(false);
+                    if (more_stores) emit_out(io_l, oc, n_run, w);      /* (several STOREs of the same value: the general way) */
+                    else *out_run = w;
+                }
+            }
+            ridx = (ridx + (unsigned)NB) & rmask;
+            out_run += out_step;
+            n_run += NB;
+        };
+        for (; b0 < be; b0 += DEPTH) {
+            if (b0 >= 12 && b0 < 36) BQ_STAMP(2 + b0 - 12);
+            batch_steady(std::integral_constant<int, 0>{});
+            if (b0 + 1 >= 12 && b0 + 1 < 36) BQ_STAMP(2 + b0 + 1 - 12);
+            batch_steady(std::integral_constant<int, 1>{});
+            if (b0 + 2 >= 12 && b0 + 2 < 36) BQ_STAMP(2 + b0 + 2 - 12);
+            batch_steady(std::integral_constant<int, 2>{});
+        }
+    }
+    for (; b0 < nbatches; b0 += DEPTH) {                /* (up to DEPTH - 1 batches past the end: every step masked, nothing stored) */
+        batch_any(b0, std::integral_constant<int, 0>{}); batch_any(b0 + 1, std::integral_constant<int, 1>{}); batch_any(b0 + 2, std::integral_constant<int, 2>{});
     }
 
     /* Inf / NaN.  The loop above computes with IEEE values; the reference's products read exponent 255 as 1.m x 2^128
@@ -643,7 +704,13 @@ __global__ __launch_bounds__(kBlock) void biquad_pipe(const BiquadArgs a)
         st[2] = (int)x1; st[3] = (int)x2; st[4] = (int)y1; st[5] = (int)y2;
     }
     if constexpr (FMT != 2) {
-        if (replay && have_chain && s == 0) cascade_in_reference_order<FMT>(a, cid, c);
+        if (replay && have_chain && s == 0) {
+            /* copies made here, in the branch nobody takes: the callee wants its arguments in memory, and without them the
+             * kernel's own arguments would live there for the whole loop */
+            const BiquadArgs a2 = a;
+            const avdsp_chain c2 = a2.chains[cid];
+            cascade_in_reference_order<FMT>(a2, cid, c2);
+        }
     }
     BQ_STAMP(29);
 }
