@@ -91,6 +91,7 @@ typedef struct avdsp_ctx {
     int             opt_strand_split, next_tpdf_role;
     int             shard_rank, shard_world;               /* dspRuntimeSetShard: this process's slice of every chain core */
     int             numfreq_at_init;                       /* dspChangeFormat's view of the rate count (see dspRuntimeInit) */
+    int             opt_profile_stride;
     int             opt_overlap, opt_fir_rows, opt_host_split, opt_host_pin; /* launch arrangement of the chain kernels (avdsp_hip_prog_set_option) */
     arrangement     arr[MAX_ARRANGEMENTS]; int arr_next;   /* how the cores / pieces go to the device: [0] whole program, [1..] single cores */
     int             biquad_freq_skip, mantissa;            /* this program's dspBiquadFreqSkip / dspMantissa */
@@ -225,6 +226,12 @@ static int set_option_here(const char *key, int value)
     if (!strcmp(key, "host_pin")) {
         if (G.dev && avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_HOST_PIN, value)) return fail(-10, "%s", avdsp_hip_last_error());
         G.opt_host_pin = value;
+        return 0;
+    }
+    if (!strcmp(key, "profile_stride")) {
+        if (value < 1) return fail(-1, "profile_stride: every n-th launch, n >= 1");
+        if (G.dev && avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_PROFILE_STRIDE, value)) return fail(-10, "%s", avdsp_hip_last_error());
+        G.opt_profile_stride = value;
         return 0;
     }
     if (!strcmp(key, "profile")) {
@@ -381,7 +388,7 @@ int dspRuntimeInit(opcode_t *codePtr, int maxSize, const int fs, int random, int
         const avdsp_ctx *o = &g_template;
         c->opt_fir_impl = o->opt_fir_impl; c->opt_biquad_impl = o->opt_biquad_impl; c->opt_device = o->opt_device; c->opt_profile = o->opt_profile;
         c->opt_generic = o->opt_generic; c->opt_interp_impl = o->opt_interp_impl; c->opt_strand_split = o->opt_strand_split;
-        c->opt_overlap = o->opt_overlap; c->opt_fir_rows = o->opt_fir_rows; c->opt_host_split = o->opt_host_split; c->opt_host_pin = o->opt_host_pin;
+        c->opt_profile_stride = o->opt_profile_stride; c->opt_overlap = o->opt_overlap; c->opt_fir_rows = o->opt_fir_rows; c->opt_host_split = o->opt_host_split; c->opt_host_pin = o->opt_host_pin;
         c->shard_rank = o->shard_rank; c->shard_world = o->shard_world;
         c->mantissa = DSP_MANT; c->device_ordinal = -1;
         c->code = codePtr;
@@ -1190,7 +1197,8 @@ static core_plan *get_plan_range(int format, opcode_t *core, int end_word)
         }
         G.dev_state_valid = 1;
         avdsp_hip_profile_enable(G.dev, G.opt_profile);
-        if (avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_OVERLAP, G.opt_overlap) || avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_FIR_ROWS, G.opt_fir_rows) ||
+        if (avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_PROFILE_STRIDE, G.opt_profile_stride > 0 ? G.opt_profile_stride : 1) ||
+            avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_OVERLAP, G.opt_overlap) || avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_FIR_ROWS, G.opt_fir_rows) ||
             avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_HOST_SPLIT, G.opt_host_split) || avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_HOST_PIN, G.opt_host_pin)) {
             fail(-10, "%s", avdsp_hip_last_error()); lowered_free(&L); drop_device(); return 0;
         }

@@ -1647,6 +1647,8 @@ struct avdsp_hip_prog {
     /* optional per-kernel timing with HIP events on the launch stream (avdsp_hip_profile_*) */
     int num_cus = 0;                    /* compute units of the device (fir_stream's grid) */
     unsigned profile = 0;               /* bit k: time the launches of kind k (AVDSP_KERNEL_*) */
+    int profile_stride = 1;             /* ... every profile_stride-th of them (an event pair costs the stream ~5 us) */
+    unsigned profile_seen[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     struct Span { int kind; hipEvent_t a, b; };
     std::vector<Span> spans;            /* recorded, not yet read */
     std::vector<hipEvent_t> free_events;
@@ -1735,7 +1737,8 @@ struct ProfileScope {                   /* records an event pair around the laun
     avdsp_hip_prog *prog; hipStream_t stream; int kind; hipEvent_t a = nullptr;
     ProfileScope(avdsp_hip_prog *p, hipStream_t s, int k) : prog(p), stream(s), kind(k)
     {
-        if ((prog->profile >> kind & 1u) && (a = take_event(prog))) (void)hipEventRecord(a, stream);
+        if ((prog->profile >> kind & 1u) && prog->profile_seen[kind & 7]++ % (unsigned)prog->profile_stride == 0 && (a = take_event(prog)))
+            (void)hipEventRecord(a, stream);
     }
     ~ProfileScope()
     {
@@ -2863,6 +2866,7 @@ int avdsp_hip_prog_set_option(avdsp_hip_prog *prog, int key, int value)
     case AVDSP_OPT_OVERLAP:  prog->overlap = value != 0; prog->ev_fir_set[0] = prog->ev_fir_set[1] = false; return 0;
     case AVDSP_OPT_FIR_ROWS: if (value != 0 && value != 1 && value != 2 && value != 4) return set_err("fir_tile row tiles: 0 (auto), 1, 2 or 4");
                              prog->fir_rows = value; return 0;
+    case AVDSP_OPT_PROFILE_STRIDE: if (value < 1) return set_err("profile_stride: every n-th launch, n >= 1"); prog->profile_stride = value; return 0;
     case AVDSP_OPT_HOST_SPLIT: if (value < 0) return set_err("host_split: frames per piece, 0 = whole block"); prog->host_split = value; return 0;
     case AVDSP_OPT_HOST_PIN: prog->host_pin = value != 0;
                              if (!value) { for (auto &pn : prog->pinned) if (pn.ours) (void)hipHostUnregister(const_cast<void *>(pn.ptr)); prog->pinned.clear(); }

@@ -288,6 +288,7 @@ def main():
             step()
         torch.cuda.synchronize()
         r.kernel_time(1)
+    r.set_option("profile_stride", 4)                      # every fourth launch: a pair costs the stream ~5 us, 4 % of a 512-chain step
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -361,10 +362,11 @@ def main():
         if T and fir_n:
             per_launch = fir_ms / fir_n * 1e-3
             # 2*T flop per sample; the Cl*B samples of a step are spread over fir_n/steps launches
-            flops = 2.0 * T * B * Cl * args.steps / fir_n
+            launches_per_step = (B + 1023) // 1024           # blocks longer than 1024 frames are cut into 1024-frame launches
+            flops = 2.0 * T * B * Cl / launches_per_step
             ach = flops / per_launch / 1e12
             kname = {0: "fir_plain", 1: "fir_tile", 2: "fir_mfma", 3: "fir_stream"}[args.fir_impl]
-            fir_bytes = (4.0 * Cl * B + 4.0 * (T - 1 + B) * Cl + 4.0 * T * Cl) * args.steps / fir_n   # out, window, taps
+            fir_bytes = (4.0 * Cl * B + 4.0 * (T - 1 + B) * Cl + 4.0 * T * Cl) / launches_per_step   # out, window, taps
             roof = dict(bound="mfma", kernel=kname, achieved=ach,
                         peak=PEAK_F64_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_F64_TFLOPS,
                         traffic=pmc_traffic(traffic_key, kname), traffic_source="profiles/traffic.json (committed rocprofv3 --pmc passes of this command, not this run)",
@@ -406,6 +408,7 @@ def main():
             line["host_queue_msamples_s"] = host_queue_rate
         line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)
+    r.set_option("profile_stride", 1)
     r.release()
     if world > 1:
         dist.barrier()

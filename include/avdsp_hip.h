@@ -167,7 +167,8 @@ int avdsp_hip_profile_read(avdsp_hip_prog *prog, int kind, double *total_ms, int
 /* Launch arrangement of the chain kernels.  AVDSP_OPT_OVERLAP 1: the cascade of block k+1 may run under the FIR of
  * block k (side stream; see launch_all in avdsp_kernels.hip) -- the caller then guarantees that a block's input is
  * complete in memory when the call is made.                                                                     */
-enum { AVDSP_OPT_OVERLAP = 0, AVDSP_OPT_FIR_ROWS = 3, AVDSP_OPT_HOST_SPLIT = 4, AVDSP_OPT_HOST_PIN = 5 };
+enum { AVDSP_OPT_OVERLAP = 0, AVDSP_OPT_PROFILE_STRIDE = 1, AVDSP_OPT_FIR_ROWS = 3, AVDSP_OPT_HOST_SPLIT = 4, AVDSP_OPT_HOST_PIN = 5 };
+/* PROFILE_STRIDE n: with profiling on, only every n-th launch of a kind is bracketed by events */
 /* FIR_ROWS: row tiles per wave of fir_tile, 0 = auto.  HOST_SPLIT: frames per piece of a host-pointer block (copies and kernels pipelined), 0 = whole block.
  * HOST_PIN 1: pin the caller's host buffers in place and remember them (the caller keeps them allocated until it sets 0 again) */
 int avdsp_hip_prog_set_option(avdsp_hip_prog *prog, int key, int value);
