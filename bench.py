@@ -358,7 +358,8 @@ def main():
         # SURVEY.md 8(d) algorithmic bytes of one step of THIS rank: samples in+out, biquad state r+w and coefficients,
         # FIR history carry-in/out and taps
         step_bytes = 8.0 * Cl * B + 68.0 * S * Cl + (8.0 * (T - 1) * Cl + 4.0 * T * Cl if T else 0.0)
-        traffic_key = f"{args.workload} shard {args.shard}" if args.shard else (args.workload if world == 1 else None)
+        # several ranks: rank 0's shard, if that shard was profiled alone (profiles/traffic.json has north and cfg5 in 8)
+        traffic_key = f"{args.workload} shard {args.shard}" if args.shard else (args.workload if world == 1 else f"{args.workload} shard 0/{world}")
         if T and fir_n:
             per_launch = fir_ms / fir_n * 1e-3
             # 2*T flop per sample; the Cl*B samples of a step are spread over fir_n/steps launches

@@ -437,3 +437,22 @@ def test_tagoutput_like_the_plugin():
             assert f(r.cores[k], r.rundata, x[b0:b1].ctypes.data, 16, 8, got.ctypes.data, 32, 0, b1 - b0) == 0
             r.tag_output(got, first_out[k])
         assert (got == want).all(), (b0, b1)
+
+
+def test_kernel_timers_sample_every_nth_launch():
+    """profile_stride n: only every n-th launch of a kind carries an event pair (bench.py's timed region uses 4)"""
+    fmt, C = 6, 8
+    prog = pb.synth_program(fmt, C, 2, 64)
+    x = pb.lcg_input(512, C, True, seed=1)
+    r = rt.Runtime(fmt, prog)
+    r.set_option("profile", 1)
+    r.set_option("profile_stride", 4)
+    for _ in range(8):
+        r.run_block(x, C, C)
+    ms, n = r.kernel_time(1)
+    assert n == 2 and ms > 0                                  # 8 FIR launches, every fourth bracketed
+    r.set_option("profile_stride", 1)
+    for _ in range(3):
+        r.run_block(x, C, C)
+    assert r.kernel_time(1)[1] == 3
+    r.set_option("profile", 0)
