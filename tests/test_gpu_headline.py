@@ -292,9 +292,10 @@ def test_world_n_ranks_hip_path_over_gloo(world, fmt, C, S, T):
 
 @pytest.mark.parametrize("fmt,C,S,T", [(6, 600, 16, 700), (6, 40, 8, 4096), (4, 70, 24, 300), (6, 40, 40, 100)])
 def test_overlap_mode_is_bit_identical(fmt, C, S, T):
-    """dspRuntimeSetOption("overlap", 1): the cascade of block k+1 runs under the FIR of block k (side stream, 1024-thread
-    workgroups that claim a CU each).  Six blocks are enqueued back to back without any host synchronisation, each with
-    buffers of its own; the result must be the oracle's, bit for bit, outputs and state -- and the same with the option off."""
+    """dspRuntimeSetOption("overlap", 1): the cascade of block k+1 runs under the FIR of block k (on a side stream; the FIR stays on
+    the caller's).  Six blocks are enqueued back to back without any host synchronisation -- with buffers of their own, and once
+    more into ONE output buffer copied out on the caller's stream after every block; the result must be the oracle's, bit for
+    bit, outputs and state -- and the same with the option off."""
     import torch
     B, nb = 1024, 6
     prog = pb.synth_program(fmt, C, S, T)
@@ -315,5 +316,17 @@ def test_overlap_mode_is_bit_identical(fmt, C, S, T):
         got = np.concatenate([y.cpu().numpy() for y in yd])
         assert (words(got) == words(want)).all(), f"overlap={overlap}"
         assert (r.sync_state() == o.state).all()
+        r.release()
+        # one output buffer for every block, copied out on the caller's stream right behind each call
+        r = rt.Runtime(fmt, prog)
+        r.set_option("overlap", overlap)
+        y1 = torch.zeros((B, C), dtype=xd[0].dtype, device="cuda")
+        outs = []
+        for k in range(nb):
+            r.run_block_device(xd[k].data_ptr(), C, C, y1.data_ptr(), C, 0, B, st)
+            outs.append(y1.clone())                           # (on the current stream: ordered behind the block)
+        torch.cuda.synchronize()
+        got = np.concatenate([y.cpu().numpy() for y in outs])
+        assert (words(got) == words(want)).all(), f"overlap={overlap}, one output buffer"
         r.set_option("overlap", 0)
         r.release()
