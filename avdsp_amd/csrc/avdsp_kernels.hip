@@ -1140,6 +1140,7 @@ __global__ __launch_bounds__(kBlock, 2) void fir_tile(const FirTileArgs a)
         for (int g = 0; g < ckc / 16; g++) group16(hp + 16 * (R - 1) + 64 * g, wp - g * (64 / NR));
         FIR_STAMP_CHUNK();
     }
+    FIR_STAMP(23);
     /* C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg */
 #pragma unroll
     for (int r = 0; r < R; r++)

@@ -67,7 +67,11 @@ if args.fir_impl == 3 and (st[:, 26] != 0).any():
     ok = st[:, 26] != 0
     print("  first unit: start -> unit known %.0f cycles, -> first chunk's operands ready %.0f;  epilogue (convert and store the tile) %.0f cycles"
           % (np.median(st[ok, 24] - st[ok, 0]), np.median(st[ok, 2] - st[ok, 0]), np.median(st[ok, 26] - st[ok, 25])))
-elif (st[:, 24] != 0).any():
+if args.fir_impl == 1 and (st[:, 23] != 0).any():
+    ok = st[:, 23] != 0
+    print("  start -> first chunk's boundary %.0f cycles;  epilogue (convert and store the tile) %.0f cycles (p90 %.0f)"
+          % (np.median(st[ok, 1] - st[ok, 0]), np.median(st[ok, 30] - st[ok, 23]), np.percentile(st[ok, 30] - st[ok, 23], 90)))
+if args.fir_impl != 3 and (st[:, 24] != 0).any():
     ok = st[:, 27] != 0
     b = st[ok, 4]                                    # start of chunk 1's boundary
     print("  chunk 1's boundary: requested data landed +%.0f, window image written +%.0f, taps image landed +%.0f, next window requested +%.0f, next taps requested +%.0f, first operands read +%.0f cycles"
