@@ -290,8 +290,9 @@ def test_world_n_ranks_hip_path_over_gloo(world, fmt, C, S, T):
     assert same and cks_ok and range_ok
 
 
+@pytest.mark.parametrize("fir_impl", [1, 3])
 @pytest.mark.parametrize("fmt,C,S,T", [(6, 600, 16, 700), (6, 40, 8, 4096), (4, 70, 24, 300), (6, 40, 40, 100)])
-def test_overlap_mode_is_bit_identical(fmt, C, S, T):
+def test_overlap_mode_is_bit_identical(fmt, C, S, T, fir_impl):
     """dspRuntimeSetOption("overlap", 1): the cascade of block k+1 runs under the FIR of block k (on a side stream; the FIR stays on
     the caller's).  Six blocks are enqueued back to back without any host synchronisation -- with buffers of their own, and once
     more into ONE output buffer copied out on the caller's stream after every block; the result must be the oracle's, bit for
@@ -304,6 +305,7 @@ def test_overlap_mode_is_bit_identical(fmt, C, S, T):
     want = o.run_block(x, C, C, block=B)
     for overlap in (1, 0):
         r = rt.Runtime(fmt, prog)
+        r.set_option("fir_impl", fir_impl)                    # fir_tile / fir_stream (the cascade then feeds the operand ring as well)
         r.set_option("overlap", overlap)
         assert r.get_option("overlap") == overlap
         xd = [torch.from_numpy(x[k * B:(k + 1) * B].copy()).cuda() for k in range(nb)]
@@ -319,6 +321,7 @@ def test_overlap_mode_is_bit_identical(fmt, C, S, T):
         r.release()
         # one output buffer for every block, copied out on the caller's stream right behind each call
         r = rt.Runtime(fmt, prog)
+        r.set_option("fir_impl", fir_impl)
         r.set_option("overlap", overlap)
         y1 = torch.zeros((B, C), dtype=xd[0].dtype, device="cuda")
         outs = []
@@ -329,4 +332,5 @@ def test_overlap_mode_is_bit_identical(fmt, C, S, T):
         got = np.concatenate([y.cpu().numpy() for y in outs])
         assert (words(got) == words(want)).all(), f"overlap={overlap}, one output buffer"
         r.set_option("overlap", 0)
+        r.set_option("fir_impl", 1)
         r.release()
