@@ -1001,7 +1001,17 @@ __global__ __launch_bounds__(kBlock, 2) void fir_tile(const FirTileArgs a)
     }
     const int unit = blk * 4 + wv;
     const int slot = unit / G::WPC, F0 = (unit % G::WPC) * G::FW;
-    if (slot >= a.ngroup || F0 >= B) return;                /* from here on a wave is on its own: no barrier below */
+    /* R = 4: the workgroup's four waves are four chains over the same frames, and their tiles leave together (one barrier, at
+     * the very end); a wave without a unit only attends that barrier */
+    [[maybe_unused]] int *xchg = reinterpret_cast<int *>(lds + (size_t)4 * G::LDS_DOUBLES);      /* [wave]: out_io of its chain, or -1 */
+    if (slot >= a.ngroup || F0 >= B) {
+        if constexpr (R == 4) {
+            if (lane == 0) xchg[wv] = -1;
+            __syncthreads();
+        }
+        return;
+    }
+    /* from here on a wave is on its own: no barrier in the tap loop */
     [[maybe_unused]] const int stamp_row = wv;
     FIR_STAMP(0); FIR_REALTIME(29);
 #ifdef AVDSP_FIR_STAMPS
@@ -1142,17 +1152,63 @@ __global__ __launch_bounds__(kBlock, 2) void fir_tile(const FirTileArgs a)
     }
     FIR_STAMP(23);
     /* C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg */
+    if constexpr (R == 4) {
+        /* The tile leaves as 16-byte pieces.  A wave's 1024 results are one CHANNEL: stored by itself it writes 4 bytes into each
+         * of 1024 different 128-byte lines, and with every wave of the chip doing that the L2's request rate is what the epilogue
+         * waits for (~13 000 cycles per wave, tools/fir_timeline.py).  The four waves of the workgroup hold four neighbouring
+         * channels of the same frames: each parks its words in its own (now idle) LDS region, [frame / 64][65] so that neither
+         * side has bank conflicts, and after one barrier every thread sends four frames x four channels.  Only when the four
+         * chains store once each to four consecutive, 16-byte aligned output columns; anything else goes the plain way. */
+        unsigned *mine = reinterpret_cast<unsigned *>(hs);
+        unsigned w16[16];
 #pragma unroll
-    for (int r = 0; r < R; r++)
+        for (int r = 0; r < R; r++)
 #pragma unroll
-        for (int v = 0; v < 4; v++) {
-            const int n = F0 + NR * i16 + 16 * r + 4 * v + k;
-            if (n < B) {
+            for (int v = 0; v < 4; v++) {
                 unsigned word = store_stage<FMT>(acc[r][v], c.sat, a.io.store_mask);
                 if constexpr (FMT == 6) word = ftz_bits(word);      /* default MODE here: flush the float by hand */
-                emit_out(a.io, c, n, word);
+                w16[4 * r + v] = word;
+                mine[65 * i16 + 16 * r + 4 * v + k] = word;
             }
+        if (lane == 0) xchg[wv] = c.n_out == 1 ? c.out_io[0] : -1;
+        __syncthreads();
+        const int o0 = xchg[0];
+        const bool together = o0 >= 0 && xchg[1] == o0 + 1 && xchg[2] == o0 + 2 && xchg[3] == o0 + 3 && ((o0 - a.io.out_base) & 3) == 0 &&
+                              (a.io.out_stride & 3) == 0 && (reinterpret_cast<size_t>(a.io.out) & 15) == 0;
+        if (together) {
+            const unsigned *r0 = reinterpret_cast<const unsigned *>(lds), *r1 = reinterpret_cast<const unsigned *>(lds + G::LDS_DOUBLES),
+                           *r2 = reinterpret_cast<const unsigned *>(lds + 2 * G::LDS_DOUBLES), *r3 = reinterpret_cast<const unsigned *>(lds + 3 * G::LDS_DOUBLES);
+#pragma unroll
+            for (int qf = 0; qf < 4; qf++) {
+                const int f = (int)threadIdx.x + 256 * qf;
+                if (f < B) {
+                    const int at = 65 * (f >> 6) + (f & 63);
+                    const uint4 o = make_uint4(r0[at], r1[at], r2[at], r3[at]);
+                    *reinterpret_cast<uint4 *>(a.io.out + (size_t)f * a.io.out_stride + (o0 - a.io.out_base)) = o;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; r++)
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    const int n = F0 + NR * i16 + 16 * r + 4 * v + k;
+                    if (n < B) emit_out(a.io, c, n, w16[4 * r + v]);
+                }
         }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const int n = F0 + NR * i16 + 16 * r + 4 * v + k;
+                if (n < B) {
+                    unsigned word = store_stage<FMT>(acc[r][v], c.sat, a.io.store_mask);
+                    if constexpr (FMT == 6) word = ftz_bits(word);      /* default MODE here: flush the float by hand */
+                    emit_out(a.io, c, n, word);
+                }
+            }
+    }
     FIR_STAMP(30); FIR_REALTIME(28);
 }
 
@@ -1825,7 +1881,7 @@ int launch_fir_tile(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, Block
     a.ring = plan_ring(pl); a.io = io; a.taps64 = pl.d_taps64; a.pitch64 = pl.pitch64;
     const int nwg = (n * TileGeom<R>::WPC + 3) / 4;
     a.per_xcd = (nwg + 7) / 8;
-    const size_t lds = (size_t)4 * TileGeom<R>::LDS_DOUBLES * sizeof(double);
+    const size_t lds = (size_t)4 * TileGeom<R>::LDS_DOUBLES * sizeof(double) + 64;      /* + the four words the waves exchange at the end */
 #ifdef AVDSP_FIR_STAMPS
     static unsigned long long *d_stamps = nullptr;
     if (!d_stamps) { HIP_TRY(hipMalloc((void **)&d_stamps, (size_t)8192 * 4 * 32 * 8)); }
@@ -2128,7 +2184,7 @@ int avdsp_hip_prog_add_plan(avdsp_hip_prog *prog, const avdsp_plan_desc *d)
             const void *tiles[3] = { d->format == 4 ? (const void *)fir_tile<4, 1> : (const void *)fir_tile<6, 1>,
                                      d->format == 4 ? (const void *)fir_tile<4, 2> : (const void *)fir_tile<6, 2>,
                                      d->format == 4 ? (const void *)fir_tile<4, 4> : (const void *)fir_tile<6, 4> };
-            const int tlds[3] = { 4 * TileGeom<1>::LDS_DOUBLES * 8, 4 * TileGeom<2>::LDS_DOUBLES * 8, 4 * TileGeom<4>::LDS_DOUBLES * 8 };
+            const int tlds[3] = { 4 * TileGeom<1>::LDS_DOUBLES * 8 + 64, 4 * TileGeom<2>::LDS_DOUBLES * 8 + 64, 4 * TileGeom<4>::LDS_DOUBLES * 8 + 64 };
             for (int v = 0; v < 3; v++) {
                 hipError_t e2 = hipFuncSetAttribute(tiles[v], hipFuncAttributeMaxDynamicSharedMemorySize, tlds[v]);
                 if (e2 != hipSuccess) { free_plan(pl); return set_err("hipFuncSetAttribute(fir_tile LDS %d): %s", tlds[v], hipGetErrorString(e2)); }
