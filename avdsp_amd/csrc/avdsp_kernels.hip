@@ -1005,7 +1005,7 @@ __global__ __launch_bounds__(kBlock, 2) void fir_tile(const FirTileArgs a)
      * the very end); a wave without a unit only attends that barrier */
     [[maybe_unused]] int *xchg = reinterpret_cast<int *>(lds + (size_t)4 * G::LDS_DOUBLES);      /* [wave]: out_io of its chain, or -1 */
     if (slot >= a.ngroup || F0 >= B) {
-        if constexpr (R == 4) {
+        if constexpr (R >= 2) {
             if (lane == 0) xchg[wv] = -1;
             __syncthreads();
         }
@@ -1152,15 +1152,17 @@ __global__ __launch_bounds__(kBlock, 2) void fir_tile(const FirTileArgs a)
     }
     FIR_STAMP(23);
     /* C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg */
-    if constexpr (R == 4) {
-        /* The tile leaves as 16-byte pieces.  A wave's 1024 results are one CHANNEL: stored by itself it writes 4 bytes into each
-         * of 1024 different 128-byte lines, and with every wave of the chip doing that the L2's request rate is what the epilogue
-         * waits for (~13 000 cycles per wave, tools/fir_timeline.py).  The four waves of the workgroup hold four neighbouring
-         * channels of the same frames: each parks its words in its own (now idle) LDS region, [frame / 64][65] so that neither
-         * side has bank conflicts, and after one barrier every thread sends four frames x four channels.  Only when the four
-         * chains store once each to four consecutive, 16-byte aligned output columns; anything else goes the plain way. */
+    if constexpr (R >= 2) {
+        /* The tiles leave as 16-byte (R = 4) or 8-byte (R = 2) pieces.  A wave's results are one CHANNEL: stored by itself it
+         * writes 4 bytes into each of 256 R different 128-byte lines, and with every wave of the chip doing that the L2's request
+         * rate is what the epilogue waits for (~13 000 cycles per wave at R = 4, tools/fir_timeline.py).  The workgroup holds R
+         * neighbouring channels over the same 1024 frames (4 / R tiles each): every wave parks its words in its own (now idle)
+         * LDS region, [frame / NR][NR + 1] so that neither side has bank conflicts, and after one barrier every thread sends
+         * four frames x R channels.  Only when the chains store once each to R consecutive, aligned output columns; anything else
+         * goes the plain way. */
+        constexpr int CH = R, WPC = G::WPC;                  /* channels per workgroup, waves (tiles) per channel */
         unsigned *mine = reinterpret_cast<unsigned *>(hs);
-        unsigned w16[16];
+        unsigned w16[4 * R];
 #pragma unroll
         for (int r = 0; r < R; r++)
 #pragma unroll
@@ -1168,23 +1170,29 @@ __global__ __launch_bounds__(kBlock, 2) void fir_tile(const FirTileArgs a)
                 unsigned word = store_stage<FMT>(acc[r][v], c.sat, a.io.store_mask);
                 if constexpr (FMT == 6) word = ftz_bits(word);      /* default MODE here: flush the float by hand */
                 w16[4 * r + v] = word;
-                mine[65 * i16 + 16 * r + 4 * v + k] = word;
+                mine[(NR + 1) * i16 + 16 * r + 4 * v + k] = word;
             }
         if (lane == 0) xchg[wv] = c.n_out == 1 ? c.out_io[0] : -1;
         __syncthreads();
         const int o0 = xchg[0];
-        const bool together = o0 >= 0 && xchg[1] == o0 + 1 && xchg[2] == o0 + 2 && xchg[3] == o0 + 3 && ((o0 - a.io.out_base) & 3) == 0 &&
-                              (a.io.out_stride & 3) == 0 && (reinterpret_cast<size_t>(a.io.out) & 15) == 0;
+        bool together = o0 >= 0 && ((o0 - a.io.out_base) & (CH - 1)) == 0 && (a.io.out_stride & (CH - 1)) == 0 &&
+                        (reinterpret_cast<size_t>(a.io.out) & (4 * CH - 1)) == 0;
+#pragma unroll
+        for (int w = 1; w < 4; w++) together = together && xchg[w] == o0 + w / WPC;       /* wave w: channel w / WPC, tile w % WPC */
         if (together) {
-            const unsigned *r0 = reinterpret_cast<const unsigned *>(lds), *r1 = reinterpret_cast<const unsigned *>(lds + G::LDS_DOUBLES),
-                           *r2 = reinterpret_cast<const unsigned *>(lds + 2 * G::LDS_DOUBLES), *r3 = reinterpret_cast<const unsigned *>(lds + 3 * G::LDS_DOUBLES);
+            const unsigned *reg = reinterpret_cast<const unsigned *>(lds);
 #pragma unroll
             for (int qf = 0; qf < 4; qf++) {
                 const int f = (int)threadIdx.x + 256 * qf;
                 if (f < B) {
-                    const int at = 65 * (f >> 6) + (f & 63);
-                    const uint4 o = make_uint4(r0[at], r1[at], r2[at], r3[at]);
-                    *reinterpret_cast<uint4 *>(a.io.out + (size_t)f * a.io.out_stride + (o0 - a.io.out_base)) = o;
+                    const int ti = f / G::FW, fl = f - ti * G::FW;
+                    const int at = (NR + 1) * (fl / NR) + fl % NR;
+                    unsigned o[CH];
+#pragma unroll
+                    for (int j = 0; j < CH; j++) o[j] = reg[(size_t)(j * WPC + ti) * (2 * G::LDS_DOUBLES) + at];
+                    unsigned *dst = a.io.out + (size_t)f * a.io.out_stride + (o0 - a.io.out_base);
+                    if constexpr (CH == 4) *reinterpret_cast<uint4 *>(dst) = make_uint4(o[0], o[1], o[2], o[3]);
+                    else *reinterpret_cast<uint2 *>(dst) = make_uint2(o[0], o[1]);
                 }
             }
         } else {
