@@ -97,3 +97,47 @@ def test_nan_inf_and_subnormal_samples_in_the_window():
     for rows in ROWS:
         for impl in IMPLS:
             run_vs_oracle(6, prog, x, C, [1024, 1024], rows, impl)
+
+
+def _program_with_out_map(C, T, out_of):
+    """FIR-only chains like synth_program's, but chain c stores to IO out_of(c)"""
+    pw = pb.ProgramWriter(6, pb.F48000, pb.F48000, capacity=64 + C * (T + 64))
+    taps = pb.lcg_taps_all(C, T)
+    pw.core()
+    for c in range(C):
+        pw.param()
+        imp = pw.fir_impulses([taps[c]])
+        pw.load_gain_fixed(C + c, 1.0)
+        pw.fir(imp, T)
+        pw.sat0db()
+        pw.store(out_of(c))
+    return pw.end_of_code()
+
+
+@pytest.mark.parametrize("layout", ["reversed", "shifted_window", "aligned"])
+def test_four_row_tiles_store_together_only_when_the_columns_allow(layout):
+    """fir_tile at four row tiles sends the workgroup's four channels as 16-byte stores when their output columns are consecutive
+    and aligned; chains stored in reverse order, or an output window that starts one IO off a multiple of four, take the plain way"""
+    C, T, B = 2052, 40, 1024
+    out_of = (lambda c: C - 1 - c) if layout == "reversed" else (lambda c: c)
+    prog = _program_with_out_map(C, T, out_of)
+    x = pb.lcg_input(B, C, True, seed=17)
+    o = po.OracleProgram(6, prog)
+    r = rt.Runtime(6, prog)
+    r.set_option("fir_rows", 4)
+    if layout == "shifted_window":
+        # the caller's output window starts at IO -1 ... i.e. one spare column in front: column of chain 0 is misaligned
+        want = o.run_block(x, C, C)
+        out = np.zeros((B, C + 1), dtype=x.dtype)
+        f = getattr(r.L, "dspRuntimeBlock_6")
+        # window [frames][C + 1] laid over IOs 0 .. C: base pointer one word in, stride C + 1
+        view = out.reshape(-1)[1:]
+        rc = f(r.cores[0], r.rundata, x.ctypes.data, C, C, view.ctypes.data, C + 1, 0, B)
+        assert rc >= 0, r.last_error()
+        got = np.lib.stride_tricks.as_strided(view, shape=(B, C), strides=((C + 1) * 4, 4))
+        assert (words(np.ascontiguousarray(got)) == words(want)).all()
+    else:
+        want = o.run_block(x, C, C)
+        got = r.run_block(x, C, C)
+        assert (words(got) == words(want)).all()
+    assert (r.sync_state() == o.state).all()
