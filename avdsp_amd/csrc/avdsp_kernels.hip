@@ -1327,8 +1327,13 @@ __global__ __launch_bounds__(kStreamBlock, 1) void fir_stream(const FirTileArgs 
         d.ring8 = reinterpret_cast<const char *>(a.ring.wide + (size_t)d.cid * a.ring.R);
         return d;
     };
+    /* (bounded: the partner wave is resident in the same workgroup and always gets there; should that ever not hold, the grid
+     * still drains after ~1 s of polling -- with wrong samples, which the parity tests would show -- instead of hanging the GPU) */
     auto flag_wait = [&](int *flag, int need) {
-        while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < need) __builtin_amdgcn_s_sleep(4);
+        for (int polls = 0; polls < (1 << 23); polls++) {
+            if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) >= need) break;
+            __builtin_amdgcn_s_sleep(4);
+        }
     };
     auto flag_set = [&](int *flag, int v) {
         if (lane == 0) __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
