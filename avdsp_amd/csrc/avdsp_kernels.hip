@@ -2007,8 +2007,9 @@ static int overlap_ready(avdsp_hip_prog *prog)
     if (prog->s_bq) return 0;
     HIP_TRY(hipStreamCreateWithFlags(&prog->s_bq, hipStreamNonBlocking));
     for (int i = 0; i < 2; i++) {
-        HIP_TRY(hipEventCreateWithFlags(&prog->ev_bq[i], hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&prog->ev_fir[i], hipEventDisableTiming));
+        /* they order kernels of this device among themselves: no system-scope fence (tools/stream_handover_bench.hip: 8.1 instead of 10.6 us) */
+        HIP_TRY(hipEventCreateWithFlags(&prog->ev_bq[i], hipEventDisableTiming | hipEventDisableSystemFence));
+        HIP_TRY(hipEventCreateWithFlags(&prog->ev_fir[i], hipEventDisableTiming | hipEventDisableSystemFence));
     }
     return 0;
 }

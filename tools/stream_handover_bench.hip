@@ -26,6 +26,7 @@ int main()
 {
     hipStream_t s1, s2; CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
     hipEvent_t ev; CK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipEvent_t evd; CK(hipEventCreateWithFlags(&evd, hipEventDisableTiming | hipEventDisableSystemFence));
     unsigned long long *t; CK(hipMalloc(&t, 16));
     unsigned *flag = nullptr;
     int can = 0; CK(hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, 0));
@@ -35,7 +36,7 @@ int main()
     else CK(hipMemset(flag, 0, 8));
     const int nblk = 128, spin = 4000;       /* 40 us */
     unsigned count = 0;
-    for (int mode = 0; mode < 3; mode++) {
+    for (int mode = 0; mode < 4; mode++) {
         if (mode == 1 && !flag) continue;
         std::vector<double> gaps;
         for (int it = 0; it < 60; it++) {
@@ -51,16 +52,20 @@ int main()
                 hipLaunchKernelGGL(producer, dim3(nblk), dim3(256), 0, s1, t, flag, spin);
                 CK(hipStreamWaitValue32(s2, flag, count, hipStreamWaitValueGte, 0xFFFFFFFFu));
                 hipLaunchKernelGGL(consumer, dim3(nblk), dim3(256), 0, s2, t + 1);
-            } else {
+            } else if (mode == 2) {
                 hipLaunchKernelGGL(producer, dim3(nblk), dim3(256), 0, s1, t, (unsigned *)nullptr, spin);
                 hipLaunchKernelGGL(consumer, dim3(nblk), dim3(256), 0, s1, t + 1);
+            } else {
+                hipLaunchKernelGGL(producer, dim3(nblk), dim3(256), 0, s1, t, (unsigned *)nullptr, spin);
+                CK(hipEventRecord(evd, s1)); CK(hipStreamWaitEvent(s2, evd, 0));
+                hipLaunchKernelGGL(consumer, dim3(nblk), dim3(256), 0, s2, t + 1);
             }
             CK(hipDeviceSynchronize());
             unsigned long long out[2]; CK(hipMemcpy(out, t, 16, hipMemcpyDeviceToHost));
             gaps.push_back(((double)out[1] - (double)out[0]) / 100.0);
         }
         std::sort(gaps.begin(), gaps.end());
-        printf("%-48s: gap median %.1f us (p10 %.1f, p90 %.1f)\n", mode == 0 ? "event record + stream wait event" : mode == 1 ? "kernel bumps a counter + hipStreamWaitValue32" : "same stream",
+        printf("%-48s: gap median %.1f us (p10 %.1f, p90 %.1f)\n", mode == 0 ? "event record + stream wait event" : mode == 1 ? "kernel bumps a counter + hipStreamWaitValue32" : mode == 2 ? "same stream" : "event with hipEventDisableSystemFence",
                gaps[gaps.size() / 2], gaps[gaps.size() / 10], gaps[gaps.size() * 9 / 10]);
     }
     return 0;
