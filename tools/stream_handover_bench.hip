@@ -3,6 +3,7 @@
 // (c) both kernels on one stream.  Gap = s_memrealtime at the consumer's first wave minus at the producer's last (100 MHz ticks).
 //   hipcc -O2 --offload-arch=gfx950 tools/stream_handover_bench.hip -o /tmp/handover && /tmp/handover
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <algorithm>
 #include <cstdio>
 #include <vector>
@@ -36,7 +37,8 @@ int main()
     else CK(hipMemset(flag, 0, 8));
     const int nblk = 128, spin = 4000;       /* 40 us */
     unsigned count = 0;
-    for (int mode = 0; mode < 4; mode++) {
+    hipEvent_t evk; CK(hipEventCreateWithFlags(&evk, hipEventDisableTiming | hipEventDisableSystemFence));
+    for (int mode = 0; mode < 5; mode++) {
         if (mode == 1 && !flag) continue;
         std::vector<double> gaps;
         for (int it = 0; it < 60; it++) {
@@ -55,9 +57,15 @@ int main()
             } else if (mode == 2) {
                 hipLaunchKernelGGL(producer, dim3(nblk), dim3(256), 0, s1, t, (unsigned *)nullptr, spin);
                 hipLaunchKernelGGL(consumer, dim3(nblk), dim3(256), 0, s1, t + 1);
-            } else {
+            } else if (mode == 3) {
                 hipLaunchKernelGGL(producer, dim3(nblk), dim3(256), 0, s1, t, (unsigned *)nullptr, spin);
                 CK(hipEventRecord(evd, s1)); CK(hipStreamWaitEvent(s2, evd, 0));
+                hipLaunchKernelGGL(consumer, dim3(nblk), dim3(256), 0, s2, t + 1);
+            } else {
+                unsigned long long *ta = t; unsigned *fnull = nullptr; int sp = spin;
+                void *kargs[] = {&ta, &fnull, &sp};
+                CK(hipExtLaunchKernel((const void *)producer, dim3(nblk), dim3(256), kargs, 0, s1, nullptr, evk, 0));
+                CK(hipStreamWaitEvent(s2, evk, 0));
                 hipLaunchKernelGGL(consumer, dim3(nblk), dim3(256), 0, s2, t + 1);
             }
             CK(hipDeviceSynchronize());
@@ -65,7 +73,7 @@ int main()
             gaps.push_back(((double)out[1] - (double)out[0]) / 100.0);
         }
         std::sort(gaps.begin(), gaps.end());
-        printf("%-48s: gap median %.1f us (p10 %.1f, p90 %.1f)\n", mode == 0 ? "event record + stream wait event" : mode == 1 ? "kernel bumps a counter + hipStreamWaitValue32" : mode == 2 ? "same stream" : "event with hipEventDisableSystemFence",
+        printf("%-48s: gap median %.1f us (p10 %.1f, p90 %.1f)\n", mode == 0 ? "event record + stream wait event" : mode == 1 ? "kernel bumps a counter + hipStreamWaitValue32" : mode == 2 ? "same stream" : mode == 3 ? "event with hipEventDisableSystemFence" : "the kernel's own stop event (hipExtLaunchKernel)",
                gaps[gaps.size() / 2], gaps[gaps.size() / 10], gaps[gaps.size() * 9 / 10]);
     }
     return 0;
