@@ -107,7 +107,6 @@ static int        g_nctx;
 static avdsp_ctx *g_cur = &g_template;
 #define G (*g_cur)
 static int        g_rate_static;     /* the reference's dspNumSamplingFreq static: what the latest dspRuntimeReset of the PROCESS left behind */
-static int        g_active_device = -1;
 
 static char g_err[512];
 static int  g_err_code;
@@ -143,17 +142,38 @@ static void ctx_make_current(avdsp_ctx *c)
     dspHeaderPtr = (dspHeader_t *)c->code;
     dspBiquadFreqSkip = c->biquad_freq_skip;
     dspMantissa = c->mantissa;
-    if (c->device_selected && c->device_ordinal >= 0 && c->device_ordinal != g_active_device && !avdsp_hip_set_device(c->device_ordinal))
-        g_active_device = c->device_ordinal;
+}
+
+/* The HIP current device is per thread and anybody's to change (torch in the tests and in bench.py calls hipSetDevice
+ * itself): every entry point that may reach the device names the current program's GPU again instead of trusting a
+ * remembered one.  The library as a whole is single-threaded, like the reference (statics, no locks): one thread at a
+ * time may be inside it. */
+static void device_current(void)
+{
+    if (G.device_selected && G.device_ordinal >= 0) (void)avdsp_hip_set_device(G.device_ordinal);
+}
+
+/* words [code, code + total_words) belong to a program (half open: two programs may lie back to back in one array) */
+static int ctx_holds(const avdsp_ctx *c, const opcode_t *q)
+{
+    return c->code && q >= c->code && q < c->code + (c->total_words > 0 ? c->total_words : 1);
 }
 
 /* the program a pointer belongs to (its code or its data area); the current one stays if none does */
 static avdsp_ctx *ctx_of(const void *ptr)
 {
     const opcode_t *q = (const opcode_t *)ptr;
-    if (g_cur != &g_template && g_cur->code && q >= g_cur->code && q <= g_cur->code + g_cur->total_words) return g_cur;
-    for (int i = 0; i < g_nctx; i++)
-        if (g_ctx[i]->code && q >= g_ctx[i]->code && q <= g_ctx[i]->code + g_ctx[i]->total_words) { ctx_make_current(g_ctx[i]); return g_cur; }
+    avdsp_ctx *hit = 0;
+    if (g_cur != &g_template && ctx_holds(g_cur, q)) hit = g_cur;
+    for (int i = 0; i < g_nctx && !hit; i++)
+        if (ctx_holds(g_ctx[i], q)) hit = g_ctx[i];
+    /* one past the last word: the rundata pointer of a program without a data area (checked last: it may also be the
+     * first word of the next program in the same array) */
+    if (!hit && g_cur != &g_template && g_cur->code && q == g_cur->code + g_cur->total_words) hit = g_cur;
+    for (int i = 0; i < g_nctx && !hit; i++)
+        if (g_ctx[i]->code && q == g_ctx[i]->code + g_ctx[i]->total_words) hit = g_ctx[i];
+    if (hit) ctx_make_current(hit);
+    device_current();
     return g_cur;
 }
 
@@ -191,7 +211,7 @@ int dspRuntimeSelect(const void *ptr_into_program)
 {
     avdsp_ctx *c = ctx_of(ptr_into_program);
     const opcode_t *q = (const opcode_t *)ptr_into_program;
-    if (c == &g_template || !c->code || q < c->code || q > c->code + c->total_words)
+    if (c == &g_template || !c->code || !(ctx_holds(c, q) || q == c->code + c->total_words))
         return fail(-1, "dspRuntimeSelect: the pointer is inside no loaded program");
     return 0;
 }
@@ -199,6 +219,7 @@ int dspRuntimeSelect(const void *ptr_into_program)
 /* a tunable that changes how cores are lowered: forget the plans, keep the device copy (state, TPDF globals) */
 static int replan(void)
 {
+    device_current();
     if (G.dev && avdsp_hip_prog_clear_plans(G.dev)) return fail(-10, "%s", avdsp_hip_last_error());
     G.nplans = 0;
     for (int i_ = 0; i_ < MAX_ARRANGEMENTS; i_++) G.arr[i_].valid = 0;
@@ -207,6 +228,7 @@ static int replan(void)
 
 static int set_option_here(const char *key, int value)
 {
+    device_current();
     if (!strcmp(key, "fir_impl"))    { G.opt_fir_impl = value; return 0; }
     if (!strcmp(key, "biquad_impl")) { G.opt_biquad_impl = value; return 0; }
     if (!strcmp(key, "device"))      { G.opt_device = value; G.device_selected = 0; return 0; }
@@ -337,6 +359,7 @@ opcode_t *dspFindCoreBegin(opcode_t *p)
 int dspRuntimeReset(const int fs, int random, int defaultDither)
 {
     if (!dspHeaderPtr) return fail(-1, "dspRuntimeReset before dspRuntimeInit");
+    device_current();
     int idx = dspConvertFrequencyToIndex(fs);
     if (idx >= FMAXpos) return fail(-1, "sampling frequency %d not supported", fs);
     int mn = dspHeaderPtr->freqMin, mx = dspHeaderPtr->freqMax;
@@ -371,16 +394,17 @@ int dspRuntimeInit(opcode_t *codePtr, int maxSize, const int fs, int random, int
 {
     /* the program's context: the one this buffer already has (loaded again: it starts clean), or a new one with the
      * options in force now */
-    avdsp_ctx *c = 0;
+    avdsp_ctx *c = 0, *prev = g_cur;
     for (int i = 0; i < g_nctx; i++) if (g_ctx[i]->code == codePtr) c = g_ctx[i];
     /* a program that overlaps this buffer can only be one whose buffer the caller has freed since: forget it */
     if (codePtr->op.opcode == DSP_HEADER) {
         const dspHeader_t *h = (const dspHeader_t *)codePtr;
         const opcode_t *lo = codePtr, *hi = codePtr + (long long)h->totalLength + (h->dataSize > 0 ? h->dataSize : 0);
         for (int i = 0; i < g_nctx; )
-            if (g_ctx[i] != c && g_ctx[i]->code < hi && lo <= g_ctx[i]->code + g_ctx[i]->total_words) ctx_destroy(g_ctx[i]);
+            if (g_ctx[i] != c && g_ctx[i]->code < hi && lo < g_ctx[i]->code + (g_ctx[i]->total_words > 0 ? g_ctx[i]->total_words : 1)) ctx_destroy(g_ctx[i]);
             else i++;
     }
+    int fresh = 0;
     if (!c) {
         if (g_nctx == MAX_PROGRAMS) return fail(-9, "%d programs are loaded already: dspRuntimeReleaseProgram() the ones no longer used", MAX_PROGRAMS);
         c = (avdsp_ctx *)calloc(1, sizeof *c);
@@ -393,6 +417,7 @@ int dspRuntimeInit(opcode_t *codePtr, int maxSize, const int fs, int random, int
         c->mantissa = DSP_MANT; c->device_ordinal = -1;
         c->code = codePtr;
         g_ctx[g_nctx++] = c;
+        fresh = 1;
     }
     ctx_make_current(c);
     drop_device();
@@ -400,16 +425,19 @@ int dspRuntimeInit(opcode_t *codePtr, int maxSize, const int fs, int random, int
     dspHeaderPtr = (dspHeader_t *)codePtr;
     G.code = codePtr;
     G.total_words = 0;
-    if (codePtr->op.opcode != DSP_HEADER) return fail(-1, "no dsp header in this program");
+    /* a buffer that holds no loadable program leaves no context behind (a host probing files would otherwise fill the table) */
+#define INIT_FAIL(...) do { const int r_ = fail(__VA_ARGS__); if (fresh) { ctx_destroy(c); for (int i_ = 0; i_ < g_nctx; i_++) if (g_ctx[i_] == prev) ctx_make_current(prev); } return r_; } while (0)
+    if (codePtr->op.opcode != DSP_HEADER) INIT_FAIL(-1, "no dsp header in this program");
     int length = dspHeaderPtr->totalLength, size = dspHeaderPtr->dataSize;
     if (size + length > maxSize)
-        return fail(-6, "program+data = %d words exceeds the buffer (%d)", size + length, maxSize);
+        INIT_FAIL(-6, "program+data = %d words exceeds the buffer (%d)", size + length, maxSize);
     unsigned sum; int cores;
     avdspChecksumWalk(codePtr, (unsigned)length, &sum, &cores);
-    if (cores < 1) return fail(-3, "no cores defined in the program");
-    if (sum != dspHeaderPtr->checkSum) return fail(-4, "checksum problem with the program");
+    if (cores < 1) INIT_FAIL(-3, "no cores defined in the program");
+    if (sum != dspHeaderPtr->checkSum) INIT_FAIL(-4, "checksum problem with the program");
     if (dspHeaderPtr->maxOpcode >= DSP_MAX_OPCODE)
-        return fail(-5, "program uses opcodes newer than this runtime");
+        INIT_FAIL(-5, "program uses opcodes newer than this runtime");
+#undef INIT_FAIL
     dspMantissa = DSP_MANT;
     /* dsp_runtime.c:181-190 converts the parameters to the runtime's encoding right here.  This library serves every
      * DSP_FORMAT, so which encoding is wanted is only known when the first entry point is called: the conversion runs
@@ -1125,11 +1153,8 @@ static int scan_generic(int format, opcode_t *core, int end_word, avdsp_generic_
 
 static int select_device(void)
 {
-    if (G.device_selected) {
-        if (G.device_ordinal != g_active_device) {      /* another program's GPU was active */
-            if (avdsp_hip_set_device(G.device_ordinal)) return fail(-10, "%s", avdsp_hip_last_error());
-            g_active_device = G.device_ordinal;
-        }
+    if (G.device_selected) {                            /* (another program's GPU, or somebody else's, may be the thread's current one) */
+        if (avdsp_hip_set_device(G.device_ordinal)) return fail(-10, "%s", avdsp_hip_last_error());
         return 0;
     }
     int n = avdsp_hip_device_count();
@@ -1141,7 +1166,7 @@ static int select_device(void)
     }
     if (avdsp_hip_set_device(want)) return fail(-10, "%s", avdsp_hip_last_error());
     G.device_selected = 1;
-    G.device_ordinal = want; g_active_device = want;
+    G.device_ordinal = want;
     return 0;
 }
 
@@ -1249,6 +1274,7 @@ int dspRuntimeKernelTime(int kind, double *total_ms, int *launches)
     if (total_ms) *total_ms = 0.0;
     if (launches) *launches = 0;
     if (!G.dev) return 0;
+    device_current();
     if (avdsp_hip_profile_read(G.dev, kind, total_ms, launches)) return fail(-10, "%s", avdsp_hip_last_error());
     return 0;
 }
@@ -1402,6 +1428,7 @@ int dspRuntimeBlockSubmit(int format, opcode_t *core, int *rundata, const void *
 int dspRuntimeBlockWait(int max_in_flight)
 {
     if (!G.dev) return 0;
+    device_current();
     const int rc = avdsp_hip_wait_block_host(G.dev, max_in_flight);
     if (rc < 0) return fail(-10, "%s", avdsp_hip_last_error());
     return rc;
@@ -1716,6 +1743,7 @@ int dspRuntimeBlockPcm(int format, opcode_t *core, int *rundata, int pcm, const 
 int dspRuntimeTagOutputDevice(void *d_out, int out_stride, int column, int nframes, void *stream)
 {
     if (!G.dev) return fail(-1, "no device program yet: run a block first");
+    device_current();
     if (column < 0 || column >= out_stride) return fail(-1, "tag column %d outside the output window of %d", column, out_stride);
     if (avdsp_hip_tag_output(G.dev, (int *)d_out + column, out_stride, nframes, 0, 0, stream)) return fail(-10, "%s", avdsp_hip_last_error());
     return 0;
@@ -1724,6 +1752,7 @@ int dspRuntimeTagOutputDevice(void *d_out, int out_stride, int column, int nfram
 int dspRuntimeTagOutputReset(int previoussample)
 {
     if (!G.dev) return fail(-1, "no device program yet: run a block first");
+    device_current();
     if (avdsp_hip_tag_output(G.dev, 0, 0, 0, 1, previoussample, 0)) return fail(-10, "%s", avdsp_hip_last_error());
     return 0;
 }
@@ -1731,6 +1760,7 @@ int dspRuntimeTagOutputReset(int previoussample)
 int dspRuntimeTagOutput(int *out, int out_stride, int column, int nframes)
 {
     if (!G.dev) return fail(-1, "no device program yet: run a block first");
+    device_current();
     if (column < 0 || column >= out_stride) return fail(-1, "tag column %d outside the output window of %d", column, out_stride);
     if (nframes <= 0) return 0;
     /* one column through the device: the carried value lives there */
@@ -1747,6 +1777,7 @@ int dspRuntimeTagOutput(int *out, int out_stride, int column, int nframes)
 int dspRuntimeUnpackPcmDevice(int pcm, const void *d_src, int *d_dst, long long nsamples, void *stream)
 {
     if (!G.dev) return fail(-1, "no device program yet: run a block first");
+    device_current();
     if (avdsp_hip_unpack_pcm(G.dev, pcm, d_src, d_dst, (size_t)nsamples, stream)) return fail(-10, "%s", avdsp_hip_last_error());
     return 0;
 }
@@ -1788,6 +1819,7 @@ int dspRuntimeUploadParams(void)
 {
     if (!dspHeaderPtr) return fail(-1, "no program loaded");
     if (!G.dev) return 0;                                     /* nothing on the device yet: the next block uploads everything */
+    device_current();
     const int first = (int)(sizeof(dspHeader_t) / sizeof(int));
     if (avdsp_hip_prog_clear_plans(G.dev) ||
         avdsp_hip_upload_words(G.dev, (const int32_t *)G.code, first, dspHeaderPtr->totalLength - first))

@@ -273,8 +273,14 @@ __device__ __forceinline__ void emit_out(const BlockIO &io, const avdsp_chain &c
  *           (row_ror:1); after NB steps the NB results sit in NB different lanes, which convert
  *           (SAT0DB/STORE) and store them together.
  * ---------------------------------------------------------------------------------------- */
+/* what biquad_row needs of a chain and of a section, one record per row slot / per lane of a launch group; made with the plan */
+struct RowRec { int cid, in_io, out_io, flags; unsigned gain_bits; int pad[3]; };      /* flags: load_mode | sat << 8 | to_ring << 9 | n_out << 16 */
+struct LaneRec { int coef_word, state_word; };                                          /* -1: the lane holds no section */
+
 struct BiquadArgs {
     int            *buf;            /* device mirror of the caller's buffer */
+    const RowRec   *rows;           /* biquad_row: [ngroup] */
+    const LaneRec  *lanes;          /* biquad_row: [ngroup][16], sections right-aligned in the row */
     const avdsp_chain *chains;
     const int      *sec_coef, *sec_state;
     const int      *group;          /* chain ids handled by this launch (all with `nsec` sections) */
@@ -712,6 +718,289 @@ __global__ __launch_bounds__(kBlock) void biquad_pipe(const BiquadArgs a)
             const avdsp_chain c2 = a2.chains[cid];
             cascade_in_reference_order<FMT>(a2, cid, c2);
         }
+    }
+    BQ_STAMP(29);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * biquad_row<FMT>: the section-pipelined cascade with fewer instructions per step (round 3; formats 4 and 6, cascades of up to
+ * 16 sections, one 16-lane row per chain).  Same arithmetic as biquad_pipe, lane = (chain, section), exact for the same reason.
+ *
+ * What bounds the cascade is one wave's instruction issue: ~4.4 cycles per instruction whatever it is (tools/cascade_lab.hip: DP,
+ * SP, dpp, dependent or not), one wave per SIMD, ~1050 dependent steps per block.  biquad_pipe's step is 13 instructions + 1.8 of
+ * batch overhead; here it is 10 + 0.6:
+ *   - Rows are RIGHT-aligned: a chain's last section sits in lane 15 of its row whatever the section count, section 0 in lane
+ *     16 - nsec.  The result of a step then reaches the lane that will store it with ONE dpp (row_newbcast:15 into one bank of four
+ *     lanes of one of four registers; three selects per 16 steps sort them out) instead of a rotating register + a select per step.
+ *   - The 16 input samples of a batch go global -> LDS -> 16 registers of every lane; the hand-off is v_cndmask_b32_dpp
+ *     (previous lane's result, row_shr:1; a section-0 lane takes the staged sample instead, by a lane mask in vcc): no rotating
+ *     input register.
+ *   - A lane keeps {acc, P, x1, x2, y1, y2 (doubles), hy (its latest result, float bits)} with the first product of its NEXT
+ *     compute (P * c0: the operand was fetched a step ago) already added to acc, as biquad_pipe's hand-scheduled step does:
+ *         step u:  t = hand-off;  lanes computing frame u-1-2s:  acc += x1 c1 + x2 c2 + y1 c3 + y2 c4 (one fma each, in order);
+ *                  hy = (float)acc;  x2 = x1; x1 = P; y2 = y1; y1 = widen(hy);   lanes computing next step:  P = widen(t); acc += P c0
+ *     Steady batches run that as four-step asm statements in which the x and y registers rotate roles instead of being moved;
+ *     the steps of the block's fill and drain run the same instructions under EXEC masks with the moves spelled out.
+ * Measured (tools/cascade_lab.hip, 4096 chains x 16 sections x 1024 frames): 54 cycles per steady step against 95.
+ * ---------------------------------------------------------------------------------------- */
+template <int FMT>
+__global__ __launch_bounds__(kBlock) void biquad_row(const BiquadArgs a)
+{
+    static_assert(FMT == 4 || FMT == 6, "double-accumulator models");
+    flush_f32_subnormals_like_the_reference();
+    BQ_STAMP(0);
+    __shared__ __attribute__((aligned(16))) unsigned lin[4][2][4][16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, row = lane >> 4, rp = lane & 15;
+    const int blk = xcd_remap(blockIdx.x, a.per_xcd);
+    const int slot = blk * 16 + wv * 4 + row;
+    const Ring ring_l = a.ring;
+    const BlockIO io_l = a.io;
+    const int B = io_l.nframes, L = a.nsec - 1;
+    const bool have_chain = slot < a.ngroup;
+    /* one load level to the records, a second to coefficients, state and the first samples (biquad_pipe: four) */
+    const RowRec rr = a.rows[have_chain ? slot : 0];
+    const LaneRec lr = a.lanes[(size_t)(have_chain ? slot : 0) * 16 + rp];
+    const int sec = rp - (15 - L);                      /* this lane's section (negative: none) */
+    const bool lane_on = have_chain && sec >= 0;
+    const int cid = rr.cid;
+    const int c_load_mode = rr.flags & 0xFF; const unsigned c_gain_bits = rr.gain_bits;
+    const bool c_sat = (rr.flags >> 8 & 1) != 0, to_ring = (rr.flags >> 9 & 1) != 0;
+    const unsigned long long firstmask = 0x0001000100010001ull << (15 - L);       /* the section-0 lanes */
+
+    /* sample input: lane (row, i) fetches frame 16 b + i of its row's chain, three batches ahead.  Byte offsets from the block's
+     * first word, 32 bits (a block is at most 1024 frames x 65536 IOs), clamped to the block's last frame. */
+    const char *in_bytes = reinterpret_cast<const char *>(io_l.in);
+    const unsigned in_col = (unsigned)(rr.in_io - io_l.in_base) * 4u, in_frame = (unsigned)io_l.in_stride * 4u;
+    const unsigned in_max = (unsigned)(B - 1) * in_frame + in_col, in_step = 16u * in_frame;
+    unsigned in_off = min((unsigned)rp * in_frame + in_col, in_max);
+    auto fetch_next = [&]() __attribute__((always_inline)) -> unsigned {       /* (every lane loads, section or not: see biquad_pipe) */
+        const unsigned v = *reinterpret_cast<const unsigned *>(in_bytes + in_off);
+        in_off = min(in_off + in_step, in_max);
+        return v;
+    };
+    unsigned r0 = fetch_next(), r1 = fetch_next(), r2 = fetch_next(), r3 = fetch_next();     /* raw words of batches 0, 1, 2, 3 */
+
+    double cd[5] = {0, 0, 0, 0, 0}, acc = 0, dx1 = 0, dx2 = 0, dy1 = 0, dy2 = 0, P = 0;
+    unsigned hy = 0;
+    if (lane_on) {
+        const int *st = a.buf + lr.state_word;
+        const unsigned long long raw = ((unsigned long long)(unsigned)st[1] << 32) | (unsigned)st[0];
+        acc = __longlong_as_double((long long)raw);
+        for (int k = 0; k < 5; k++) cd[k] = mulop(__int_as_float(a.buf[lr.coef_word + k]));
+        dx1 = mulop(__int_as_float(st[2])); dx2 = mulop(__int_as_float(st[3]));
+        hy = (unsigned)st[4];
+        dy1 = mulop(__int_as_float(st[4])); dy2 = mulop(__int_as_float(st[5]));
+    }
+
+    unsigned *mylin = &lin[wv][0][row][0];
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    auto stage = [&](int buf, unsigned raw) __attribute__((always_inline)) { mylin[buf * 64 + rp] = hand_from_sample<FMT>(raw, c_load_mode, c_gain_bits).y; };
+    auto take = [&](int buf, unsigned (&x)[16]) __attribute__((always_inline)) {
+        const u4 *p = reinterpret_cast<const u4 *>(mylin + buf * 64);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const u4 v = p[q];
+            x[4 * q] = v[0]; x[4 * q + 1] = v[1]; x[4 * q + 2] = v[2]; x[4 * q + 3] = v[3];
+        }
+    };
+    unsigned xa[16], xb[16];
+    stage(0, r0);
+    take(0, xa);
+
+    /* results: lane (row, i) stores frame u0 + i - 1 - 2 L of its row's chain after the batch that starts at step u0.  d_j lane 4 q + i
+     * = the result of step 4 q + j (row_newbcast of the last section's lane into bank q of d_j). */
+    const bool q1 = (rp & 1) != 0, q2 = (rp & 2) != 0;
+    auto pick = [&](unsigned d0, unsigned d1, unsigned d2, unsigned d3) __attribute__((always_inline)) -> unsigned {
+        const unsigned lo = q1 ? d1 : d0, hi = q1 ? d3 : d2;
+        return q2 ? hi : lo;
+    };
+    /* any batch, any chain: the general way */
+    auto flush = [&](int u0, unsigned w) __attribute__((always_inline)) {
+        const int n = u0 + rp - (1 + 2 * L);
+        if (have_chain && n >= 0 && n < B) {
+            if (to_ring) ring_put(ring_l, cid, n, w);
+            else {
+                const avdsp_chain oc = a.chains[cid];
+                emit_out(io_l, oc, n, c_sat ? __float_as_uint(saturate_f32_0db(__uint_as_float(w))) : w);
+            }
+        }
+    };
+    /* steady batches of chains that store once (or feed a FIR ring without the operand copy): a running 32-bit byte offset from a
+     * per-lane base -- the ring row, wrapping, or the output column, advancing by 16 frames -- one store, nothing to decide */
+    const bool lean = __ballot(have_chain && (rr.flags >> 16 & 0xFF) != 1 && !to_ring) == 0 && ring_l.wide == nullptr;
+    char *obase = to_ring ? reinterpret_cast<char *>(ring_l.base + (size_t)cid * ring_l.R)
+                          : reinterpret_cast<char *>(io_l.out + (rr.out_io - io_l.out_base));
+    const unsigned oinc = to_ring ? 64u : 64u * (unsigned)io_l.out_stride;
+    const unsigned owrap = to_ring ? (unsigned)ring_l.R * 4u - 1u : 0xFFFFFFFFu;
+    const bool dosat = FMT == 6 && c_sat && !to_ring;
+    unsigned ooff = 0;
+    auto store_lean = [&](unsigned w) __attribute__((always_inline)) {
+        const unsigned v = dosat ? __float_as_uint(__builtin_amdgcn_fmed3f(__uint_as_float(w), -1.0f, 1.0f)) : w;     /* = saturate_f32_0db for every value but a NaN (the replay's business) */
+        if (have_chain) *reinterpret_cast<unsigned *>(obase + ooff) = v;
+        ooff = (ooff + oinc) & owrap;
+    };
+
+#define AVDSP_ROW_DPP " row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+#define AVDSP_ROW_BCAST(D, O, BM) "v_mov_b32_dpp %[" D "], %[" O "] row_newbcast:15 row_mask:0xf bank_mask:" BM "\n\t"
+    /* one step, every lane busy: the hand-off, the four remaining products, the new operand, the rounding, the first product of the
+     * next step, the widening of the result, its broadcast.  Nothing directly behind an instruction whose result it needs except
+     * fma -> fma; every dpp reads a register written at least two instructions earlier.  X2 / YB: the registers whose contents die
+     * in this step take the new operand and the new y1. */
+#define AVDSP_ROW_STEP(X1, X2, YA, YB, XK, HY, O, D, BM) \
+        "v_cndmask_b32_dpp %[t" XK "], %[" HY "], %[" XK "], vcc" AVDSP_ROW_DPP \
+        "v_fma_f64 %[an], %[" X1 "], %[c1], %[an]\n\t" \
+        "v_fma_f64 %[an], %[" X2 "], %[c2], %[an]\n\t" \
+        "v_fma_f64 %[an], %[" YA "], %[c3], %[an]\n\t" \
+        "v_fma_f64 %[an], %[" YB "], %[c4], %[an]\n\t" \
+        "v_cvt_f64_f32 %[" X2 "], %[t" XK "]\n\t" \
+        "v_cvt_f32_f64 %[" O "], %[an]\n\t" \
+        "v_fma_f64 %[an], %[" X2 "], %[c0], %[an]\n\t" \
+        "v_cvt_f64_f32 %[" YB "], %[" O "]\n\t" \
+        AVDSP_ROW_BCAST(D, O, BM)
+    /* four steps: (P, x1, x2) enter in (xa, xb, xc) and leave in (xc, xa, xb); y1 / y2 swap twice */
+#define AVDSP_ROW_BLOCK4(BM) \
+        asm volatile( \
+            "s_mov_b64 vcc, %[m0]\n\t" \
+            AVDSP_ROW_STEP("xb", "xc", "ya", "yb", "x0", "hy", "o0", "d0", BM) \
+            AVDSP_ROW_STEP("xa", "xb", "yb", "ya", "x1", "o0", "o1", "d1", BM) \
+            AVDSP_ROW_STEP("xc", "xa", "ya", "yb", "x2", "o1", "o2", "d2", BM) \
+            AVDSP_ROW_STEP("xb", "xc", "yb", "ya", "x3", "o2", "o3", "d3", BM) \
+            : [an] "+v"(acc), [xa] "+v"(P), [xb] "+v"(dx1), [xc] "+v"(dx2), [ya] "+v"(dy1), [yb] "+v"(dy2), \
+              [tx0] "=&v"(t0), [tx1] "=&v"(t1), [tx2] "=&v"(t2), [tx3] "=&v"(t3), \
+              [o0] "=&v"(o0), [o1] "=&v"(o1), [o2] "=&v"(o2), [o3] "=&v"(o3), \
+              [d0] "+v"(d0), [d1] "+v"(d1), [d2] "+v"(d2), [d3] "+v"(d3) \
+            : [hy] "v"(hy), [c0] "v"(cd[0]), [c1] "v"(cd[1]), [c2] "v"(cd[2]), [c3] "v"(cd[3]), [c4] "v"(cd[4]), \
+              [x0] "v"(x[k]), [x1] "v"(x[k + 1]), [x2] "v"(x[k + 2]), [x3] "v"(x[k + 3]), [m0] "s"(firstmask) \
+            : "vcc")
+    auto steady_steps = [&](const unsigned (&x)[16]) __attribute__((always_inline)) -> unsigned {
+        unsigned d0, d1, d2, d3;                          /* every lane of them is written by one of the four blocks: no initial value */
+        asm volatile("; d0..d3 start undefined" : "=v"(d0), "=v"(d1), "=v"(d2), "=v"(d3));
+#pragma unroll
+        for (int k = 0; k < 16; k += 4) {
+            unsigned t0, t1, t2, t3, o0, o1, o2, o3;
+            if (k == 0) AVDSP_ROW_BLOCK4("0x1"); else if (k == 4) AVDSP_ROW_BLOCK4("0x2"); else if (k == 8) AVDSP_ROW_BLOCK4("0x4"); else AVDSP_ROW_BLOCK4("0x8");
+            { const double t = P; P = dx2; dx2 = dx1; dx1 = t; }
+            hy = o3;
+        }
+        return pick(d0, d1, d2, d3);
+    };
+    /* one step of the block's fill or drain: the same instructions under EXEC masks, the state moved instead of renamed.
+     * cm = the lanes that compute in this step, cn = those that compute in the next one (they take the new operand). */
+#define AVDSP_ROW_EDGE(D, BM) \
+        asm volatile( \
+            "s_mov_b64 %[sv], exec\n\t" \
+            "s_mov_b64 vcc, %[m0]\n\t" \
+            "v_cndmask_b32_dpp %[t], %[hy], %[xk], vcc" AVDSP_ROW_DPP \
+            "s_mov_b64 exec, %[cm]\n\t" \
+            "v_fma_f64 %[an], %[x1], %[c1], %[an]\n\t" \
+            "v_fma_f64 %[an], %[x2], %[c2], %[an]\n\t" \
+            "v_fma_f64 %[an], %[y1], %[c3], %[an]\n\t" \
+            "v_fma_f64 %[an], %[y2], %[c4], %[an]\n\t" \
+            "v_cvt_f32_f64 %[hy], %[an]\n\t" \
+            "v_mov_b64 %[x2], %[x1]\n\t" \
+            "v_mov_b64 %[x1], %[p]\n\t" \
+            "v_mov_b64 %[y2], %[y1]\n\t" \
+            "v_cvt_f64_f32 %[y1], %[hy]\n\t" \
+            "s_mov_b64 exec, %[cn]\n\t" \
+            "v_cvt_f64_f32 %[p], %[t]\n\t" \
+            "s_nop 0\n\t" \
+            "v_fma_f64 %[an], %[p], %[c0], %[an]\n\t" \
+            "s_mov_b64 exec, %[sv]\n\t" \
+            AVDSP_ROW_BCAST(D, "hy", BM) \
+            : [an] "+v"(acc), [p] "+v"(P), [x1] "+v"(dx1), [x2] "+v"(dx2), [y1] "+v"(dy1), [y2] "+v"(dy2), [hy] "+v"(hy), \
+              [t] "=&v"(t), [sv] "=&s"(sv), [d0] "+v"(d0), [d1] "+v"(d1), [d2] "+v"(d2), [d3] "+v"(d3) \
+            : [c0] "v"(cd[0]), [c1] "v"(cd[1]), [c2] "v"(cd[2]), [c3] "v"(cd[3]), [c4] "v"(cd[4]), \
+              [xk] "v"(x[k]), [m0] "s"(firstmask), [cm] "s"(cm), [cn] "s"(cn) \
+            : "vcc")
+    /* section s computes frame u - 1 - 2 s in step u: active while 0 <= u - ustart < B */
+    const unsigned ustart = lane_on ? (unsigned)(1 + 2 * sec) : 0x40000000u;
+    auto edge_steps = [&](int u0, const unsigned (&x)[16]) __attribute__((always_inline)) -> unsigned {
+        unsigned d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+        const unsigned ph = (unsigned)u0 - ustart;
+        unsigned long long cn = __ballot(ph < (unsigned)B);
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const unsigned long long cm = cn;
+            cn = __ballot(ph + (unsigned)(k + 1) < (unsigned)B);
+            unsigned t; unsigned long long sv;
+            if ((k & 3) == 0) { if (k == 0) AVDSP_ROW_EDGE("d0", "0x1"); else if (k == 4) AVDSP_ROW_EDGE("d0", "0x2"); else if (k == 8) AVDSP_ROW_EDGE("d0", "0x4"); else AVDSP_ROW_EDGE("d0", "0x8"); }
+            else if ((k & 3) == 1) { if (k == 1) AVDSP_ROW_EDGE("d1", "0x1"); else if (k == 5) AVDSP_ROW_EDGE("d1", "0x2"); else if (k == 9) AVDSP_ROW_EDGE("d1", "0x4"); else AVDSP_ROW_EDGE("d1", "0x8"); }
+            else if ((k & 3) == 2) { if (k == 2) AVDSP_ROW_EDGE("d2", "0x1"); else if (k == 6) AVDSP_ROW_EDGE("d2", "0x2"); else if (k == 10) AVDSP_ROW_EDGE("d2", "0x4"); else AVDSP_ROW_EDGE("d2", "0x8"); }
+            else { if (k == 3) AVDSP_ROW_EDGE("d3", "0x1"); else if (k == 7) AVDSP_ROW_EDGE("d3", "0x2"); else if (k == 11) AVDSP_ROW_EDGE("d3", "0x4"); else AVDSP_ROW_EDGE("d3", "0x8"); }
+        }
+        return pick(d0, d1, d2, d3);
+    };
+
+    const int U = B + 2 * L + 1;                        /* steps u = 0 .. U-1: section s computes frame u - 1 - 2 s */
+    const int nb = (U + 15) / 16;
+    /* a batch in canonical registers: inputs of batch b in xa, raw words of b+1, b+2, b+3 in r1, r2, r3 */
+    auto batch_canon = [&](int b) __attribute__((always_inline)) {
+        const int u0 = 16 * b;
+        stage((b + 1) & 1, r1);
+        const unsigned rn = fetch_next();
+        take((b + 1) & 1, xb);
+        unsigned w;
+        if (u0 >= 2 * L + 1 && u0 + 15 <= B - 1) w = steady_steps(xa);       /* every lane computes in all 16 steps and in the one after */
+        else w = edge_steps(u0, xa);
+        flush(u0, w);
+        r1 = r2; r2 = r3; r3 = rn;
+#pragma unroll
+        for (int k = 0; k < 16; k++) xa[k] = xb[k];
+    };
+    /* six steady batches with every queue slot and both register sets under names of their own (a queue that shifts moves
+     * registers that loads are still in flight to: see biquad_pipe) */
+    auto batch_named = [&](int b, const unsigned (&x)[16], unsigned (&xn)[16], unsigned &rslot, auto lean_c) __attribute__((always_inline)) {
+        if (b >= 12 && b < 36) BQ_STAMP(2 + b - 12);
+        stage((b + 1) & 1, rslot);                      /* the raw word of batch b+1 leaves its slot, the fetch of b+4 takes it */
+        rslot = fetch_next();
+        take((b + 1) & 1, xn);
+        const unsigned w = steady_steps(x);
+        if constexpr (decltype(lean_c)::value) store_lean(w); else flush(16 * b, w);
+    };
+    auto six = [&](int b, auto lean_c) __attribute__((always_inline)) {
+        batch_named(b, xa, xb, r1, lean_c);     batch_named(b + 1, xb, xa, r2, lean_c); batch_named(b + 2, xa, xb, r3, lean_c);
+        batch_named(b + 3, xb, xa, r1, lean_c); batch_named(b + 4, xa, xb, r2, lean_c); batch_named(b + 5, xb, xa, r3, lean_c);
+    };
+    const int first_steady = (2 * L + 1 + 15) / 16;     /* batches with 16 b >= 2 L + 1 ... */
+    const int end_steady = B >= 16 ? (B - 16) / 16 + 1 : 0;      /* ... and 16 b + 15 <= B - 1 */
+    int b = 0;
+    BQ_STAMP(1);
+    for (; b < nb && b < first_steady; b++) batch_canon(b);
+    BQ_STAMP(26);
+    if (b + 6 <= end_steady) {
+        if (lean) {
+            const int n0 = 16 * b + rp - (1 + 2 * L);   /* >= 0 from the first steady batch on */
+            ooff = to_ring ? ((unsigned)(ring_l.wpos + n0) & (unsigned)(ring_l.R - 1)) * 4u : (unsigned)n0 * (unsigned)io_l.out_stride * 4u;
+            for (; b + 6 <= end_steady; b += 6) six(b, std::true_type{});
+        } else
+            for (; b + 6 <= end_steady; b += 6) six(b, std::false_type{});
+    }
+    BQ_STAMP(27);
+    for (; b < nb; b++) batch_canon(b);
+    BQ_STAMP(28);
+#undef AVDSP_ROW_EDGE
+#undef AVDSP_ROW_BLOCK4
+#undef AVDSP_ROW_STEP
+#undef AVDSP_ROW_BCAST
+#undef AVDSP_ROW_DPP
+
+    /* Inf / NaN: as in biquad_pipe -- one look at the end of the block, the chain's first lane replays it in the reference's order
+     * from the untouched state (the widened x / y values carry an Inf or NaN as a non-finite double) */
+    auto nonfinite = [](double d) { return ((unsigned long long)__double_as_longlong(d) >> 52 & 0x7FF) == 0x7FF; };
+    const bool odd = lane_on && (nonfinite(acc) || nonfinite(dx1) || nonfinite(dx2) || nonfinite(dy1) || nonfinite(dy2));
+    const unsigned long long m = __ballot(odd);
+    const bool replay = (m & (0xFFFFull << (16 * row))) != 0;
+    if (lane_on && !replay) {
+        int *st = a.buf + lr.state_word;
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(acc);
+        st[0] = (int)(unsigned)bits; st[1] = (int)(unsigned)(bits >> 32);
+        st[2] = __float_as_int(narrow_f32(dx1)); st[3] = __float_as_int(narrow_f32(dx2));
+        st[4] = (int)hy; st[5] = __float_as_int(narrow_f32(dy2));
+    }
+    if (replay && have_chain && sec == 0) {
+        const BiquadArgs a2 = a;
+        const avdsp_chain c2 = a2.chains[cid];
+        cascade_in_reference_order<FMT>(a2, cid, c2);
     }
     BQ_STAMP(29);
 }
@@ -1687,7 +1976,8 @@ struct Plan {
     avdsp_chain *d_chains = nullptr;
     int *d_sec_coef = nullptr, *d_sec_state = nullptr;
     /* launch groups (device arrays of chain ids) */
-    struct Group { int P; int nsec; int n; int *d_ids; };
+    struct Group { int P; int nsec; int n; int *d_ids; bool all_fir;        /* all_fir: every chain of the group feeds a FIR (its cascade writes the ring) */
+                   RowRec *d_rows; LaneRec *d_lanes; };                     /* biquad_row's records (P == 16) */
     std::vector<Group> bq;            /* biquad chains grouped by section count (P = lanes per chain) */
     int *d_fir_ids = nullptr;  int n_fir = 0, max_taps = 0;
     int *d_pass_ids = nullptr; int n_pass = 0;
@@ -1739,7 +2029,7 @@ struct avdsp_hip_prog {
     hipEvent_t ev_bq[2] = {nullptr, nullptr}, ev_fir[2] = {nullptr, nullptr};
     int *d_tag_prev = nullptr;           /* tagoutput: the plugin's `previoussample` */
     /* host-pointer block calls: the caller's buffers pinned in place (cache), copies and kernels on three streams */
-    struct Pinned { const void *ptr; size_t bytes; bool ours; };
+    struct Pinned { const void *ptr; size_t bytes; bool ours; int refs; };   /* refs: queued blocks still copying from / into it */
     std::vector<Pinned> pinned;
     hipStream_t s_h2d = nullptr, s_run = nullptr, s_d2h = nullptr;
     std::vector<hipEvent_t> ev_host;
@@ -1747,11 +2037,13 @@ struct avdsp_hip_prog {
      * created WITHOUT hipStreamNonBlocking, so that everything else the library does on the null stream (state reads,
      * resets, the synchronous block calls) is ordered behind the blocks in flight */
     static constexpr int kHostQueue = 4;
-    struct HostSlot { unsigned *d_in = nullptr, *d_out = nullptr; size_t in_cap = 0, out_cap = 0; hipEvent_t h2d = nullptr, run = nullptr, d2h = nullptr; };
+    struct HostSlot { unsigned *d_in = nullptr, *d_out = nullptr; size_t in_cap = 0, out_cap = 0; hipEvent_t h2d = nullptr, run = nullptr, d2h = nullptr;
+                      const void *h_in = nullptr, *h_out = nullptr; };      /* the caller's buffers of the block in this slot (pin references) */
     HostSlot hq[kHostQueue];
     hipStream_t q_h2d = nullptr, q_run = nullptr, q_d2h = nullptr;
     unsigned long long hq_submitted = 0, hq_waited = 0;
-    hipEvent_t input_ready = nullptr;    /* set around a run_block whose input block is still being copied in by another stream: the overlap mode's cascade waits for it */
+    hipEvent_t input_ready = nullptr;    /* set around a run_block whose input block is still being written by another stream (a copy, pcm_unpack): the overlap mode's cascade waits for it */
+    hipEvent_t ev_unpack = nullptr;      /* ... recorded behind the library's own pcm_unpack */
     int host_split = 0;                  /* frames per piece of a host block (0 = one piece; pieces only pay with host_pin) */
     int host_pin = 0;                    /* pin the caller's buffers in place and remember them: only for a host that keeps them allocated */
     bool ev_fir_set[2] = {false, false};
@@ -1775,7 +2067,7 @@ int upload_vec(T **dst, const std::vector<T> &v)
 void free_plan(Plan &p)
 {
     (void)hipFree(p.d_chains); (void)hipFree(p.d_sec_coef); (void)hipFree(p.d_sec_state);
-    for (auto &g : p.bq) (void)hipFree(g.d_ids);
+    for (auto &g : p.bq) { (void)hipFree(g.d_ids); (void)hipFree(g.d_rows); (void)hipFree(g.d_lanes); }
     (void)hipFree(p.d_fir_ids); (void)hipFree(p.d_pass_ids); (void)hipFree(p.d_ring); (void)hipFree(p.d_ring64); (void)hipFree(p.d_own); (void)hipFree(p.d_taps64);
 }
 
@@ -1804,26 +2096,54 @@ hipEvent_t take_event(avdsp_hip_prog *prog)
     return e;
 }
 
-struct ProfileScope {                   /* records an event pair around the launches made inside its lifetime */
-    avdsp_hip_prog *prog; hipStream_t stream; int kind; hipEvent_t a = nullptr;
+/* Kernel timers (dspRuntimeKernelTime).  A launch that goes through hipExtLaunchKernel carries its own pair of events: they
+ * take the dispatch's own start and end stamps -- what rocprofv3's kernel trace reads -- and put nothing on the stream (ride()).
+ * Other launches are bracketed by two recorded events (begin() .. destructor), which costs the stream ~5 us per pair and reads
+ * that much more than the kernel took. */
+struct ProfileScope {
+    avdsp_hip_prog *prog; hipStream_t stream; int kind; bool on = false; hipEvent_t a = nullptr;
     ProfileScope(avdsp_hip_prog *p, hipStream_t s, int k) : prog(p), stream(s), kind(k)
     {
-        if ((prog->profile >> kind & 1u) && prog->profile_seen[kind & 7]++ % (unsigned)prog->profile_stride == 0 && (a = take_event(prog)))
-            (void)hipEventRecord(a, stream);
+        on = (prog->profile >> kind & 1u) && prog->profile_seen[kind & 7]++ % (unsigned)prog->profile_stride == 0;
     }
+    void keep(hipEvent_t s, hipEvent_t e)
+    {
+        if (prog->spans.size() >= 65536) {                 /* nobody reads the timers: forget the oldest half (their events go back to the pool) */
+            for (size_t i = 0; i < 32768; i++) { prog->free_events.push_back(prog->spans[i].a); prog->free_events.push_back(prog->spans[i].b); }
+            prog->spans.erase(prog->spans.begin(), prog->spans.begin() + 32768);
+        }
+        prog->spans.push_back({kind, s, e});
+    }
+    bool ride(hipEvent_t &s, hipEvent_t &e)                /* events for hipExtLaunchKernel's start / stop slots, if this launch is sampled */
+    {
+        if (!on) return false;
+        s = take_event(prog); e = take_event(prog);
+        if (!s || !e) { if (s) prog->free_events.push_back(s); if (e) prog->free_events.push_back(e); return false; }
+        keep(s, e);
+        return true;
+    }
+    void begin() { if (on && !a && (a = take_event(prog))) (void)hipEventRecord(a, stream); }
     ~ProfileScope()
     {
         if (!a) return;
         hipEvent_t b = take_event(prog);
         if (!b) { prog->free_events.push_back(a); return; }
         (void)hipEventRecord(b, stream);
-        if (prog->spans.size() >= 65536) {                 /* nobody reads the timers: forget the oldest half (their events go back to the pool) */
-            for (size_t i = 0; i < 32768; i++) { prog->free_events.push_back(prog->spans[i].a); prog->free_events.push_back(prog->spans[i].b); }
-            prog->spans.erase(prog->spans.begin(), prog->spans.begin() + 32768);
-        }
-        prog->spans.push_back({kind, a, b});
+        keep(a, b);
     }
 };
+
+/* a launch that is timed, when it is, by the dispatch's own stamps */
+template <typename Args>
+int launch_timed(ProfileScope &scope, const void *fn, dim3 grid, dim3 block, size_t lds, hipStream_t stream, Args &a, hipEvent_t stop = nullptr)
+{
+    void *kargs[] = {(void *)&a};
+    hipEvent_t s = nullptr, e = nullptr;
+    if (stop) { scope.begin(); HIP_TRY(hipExtLaunchKernel(fn, grid, block, kargs, lds, stream, nullptr, stop, 0)); return 0; }
+    if (scope.ride(s, e)) { HIP_TRY(hipExtLaunchKernel(fn, grid, block, kargs, lds, stream, s, e, 0)); return 0; }
+    HIP_TRY(hipLaunchKernel(fn, grid, block, kargs, lds, stream));
+    return 0;
+}
 
 #ifdef AVDSP_BQ_STAMPS
 static unsigned long long *g_bq_stamps = nullptr; static int g_bq_stamp_waves = 0;
@@ -1854,32 +2174,28 @@ int launch_biquad(avdsp_hip_prog *prog, Plan &pl, const Plan::Group &g, const in
     }
 #endif
     if (biquad_impl == 0 || g.P > 64) {
+        scope.begin();
         hipLaunchKernelGGL(biquad_simple<FMT>, dim3((n + 63) / 64), dim3(64), 0, stream, a);
         if (stop) HIP_TRY(hipEventRecord(stop, stream));
+    } else if (biquad_impl == 1 && g.P == 16 && g.d_rows && (FMT == 6 || (FMT == 4 && g.all_fir))) {
+        /* one 16-lane row per chain, double accumulators: biquad_row (format 4 only where the cascade feeds a FIR -- a format-4
+         * STORE needs all of the accumulator, biquad_row hands on its float) */
+        if constexpr (FMT != 2) {
+            const int nblk = (n + 15) / 16;
+            a.rows = g.d_rows; a.lanes = g.d_lanes;
+            a.per_xcd = (nblk + 7) / 8;
+            /* (under "overlap" `stop` rides on the kernel's own completion signal instead of a marker packet behind it: 7.1 instead of
+             * 8.3 us to the start of the kernel that waits for it on another stream, tools/stream_handover_bench.hip) */
+            if (launch_timed(scope, (const void *)biquad_row<FMT>, dim3(a.per_xcd * 8), dim3(kBlock), 0, stream, a, stop)) return -1;
+        }
     } else {
         const int cpb = kBlock / g.P;
         const int nblk = (n + cpb - 1) / cpb;
         a.per_xcd = (nblk + 7) / 8;
-        const dim3 grid(a.per_xcd * 8), block(kBlock);
-        if (stop) {
-            /* the event rides on the kernel's own completion signal instead of a marker packet behind it: 7.1 instead of 8.3 us from
-             * this kernel's end to the start of the kernel that waits for the event on another stream (tools/stream_handover_bench.hip) */
-            const void *fn = g.P == 1 ? (const void *)biquad_pipe<FMT, 1> : g.P == 2 ? (const void *)biquad_pipe<FMT, 2> : g.P == 4 ? (const void *)biquad_pipe<FMT, 4>
-                           : g.P == 8 ? (const void *)biquad_pipe<FMT, 8> : g.P == 16 ? (const void *)biquad_pipe<FMT, 16> : g.P == 32 ? (const void *)biquad_pipe<FMT, 32>
-                           : (const void *)biquad_pipe<FMT, 64>;
-            void *kargs[] = {(void *)&a};
-            HIP_TRY(hipExtLaunchKernel(fn, grid, block, kargs, 0, stream, nullptr, stop, 0));
-            return 0;
-        }
-        switch (g.P) {
-        case 1:  hipLaunchKernelGGL((biquad_pipe<FMT, 1>),  grid, block, 0, stream, a); break;
-        case 2:  hipLaunchKernelGGL((biquad_pipe<FMT, 2>),  grid, block, 0, stream, a); break;
-        case 4:  hipLaunchKernelGGL((biquad_pipe<FMT, 4>),  grid, block, 0, stream, a); break;
-        case 8:  hipLaunchKernelGGL((biquad_pipe<FMT, 8>),  grid, block, 0, stream, a); break;
-        case 16: hipLaunchKernelGGL((biquad_pipe<FMT, 16>), grid, block, 0, stream, a); break;
-        case 32: hipLaunchKernelGGL((biquad_pipe<FMT, 32>), grid, block, 0, stream, a); break;
-        default: hipLaunchKernelGGL((biquad_pipe<FMT, 64>), grid, block, 0, stream, a); break;
-        }
+        const void *fn = g.P == 1 ? (const void *)biquad_pipe<FMT, 1> : g.P == 2 ? (const void *)biquad_pipe<FMT, 2> : g.P == 4 ? (const void *)biquad_pipe<FMT, 4>
+                       : g.P == 8 ? (const void *)biquad_pipe<FMT, 8> : g.P == 16 ? (const void *)biquad_pipe<FMT, 16> : g.P == 32 ? (const void *)biquad_pipe<FMT, 32>
+                       : (const void *)biquad_pipe<FMT, 64>;
+        if (launch_timed(scope, fn, dim3(a.per_xcd * 8), dim3(kBlock), 0, stream, a, stop)) return -1;
     }
     HIP_TRY(hipGetLastError());
     return 0;
@@ -1898,7 +2214,7 @@ extern "C" int avdsp_hip_debug_fir_stamps(unsigned long long *host_out, int max_
 #endif
 
 template <int FMT, int R>
-int launch_fir_tile(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, BlockIO io, hipStream_t stream)
+int launch_fir_tile(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, BlockIO io, hipStream_t stream, ProfileScope &scope)
 {
     (void)prog;
     FirTileArgs a{};
@@ -1914,9 +2230,7 @@ int launch_fir_tile(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, Block
     a.stamps = d_stamps;
     g_fir_stamps = d_stamps; g_fir_stamp_waves = a.per_xcd * 8 * 4;
 #endif
-    hipLaunchKernelGGL((fir_tile<FMT, R>), dim3(a.per_xcd * 8), dim3(kBlock), lds, stream, a);
-    HIP_TRY(hipGetLastError());
-    return 0;
+    return launch_timed(scope, (const void *)fir_tile<FMT, R>, dim3(a.per_xcd * 8), dim3(kBlock), lds, stream, a);
 }
 
 
@@ -1963,6 +2277,7 @@ int launch_fir(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, BlockIO io
     if constexpr (FMT == 2) { (void)prog; (void)pl; (void)ids; (void)n; (void)io; (void)fir_impl; (void)stream; return 0; }
     else {
         ProfileScope scope(prog, stream, AVDSP_KERNEL_FIR);
+        if (fir_impl != 1) scope.begin();
         if (fir_impl == 3) {
             /* row tiles per wave: as many as leave every SIMD a wave (1024) */
             int rows = prog->fir_rows;
@@ -1978,9 +2293,9 @@ int launch_fir(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, BlockIO io
             int rows = prog->fir_rows;
             if (rows != 1 && rows != 2 && rows != 4) rows = n >= 2048 ? 4 : n >= 1024 ? 2 : 1;
             while (rows > 1 && 128 * rows >= io.nframes) rows >>= 1;       /* a tile twice the block would multiply zeros */
-            return rows == 4 ? launch_fir_tile<FMT, 4>(prog, pl, ids, n, io, stream)
-                 : rows == 2 ? launch_fir_tile<FMT, 2>(prog, pl, ids, n, io, stream)
-                             : launch_fir_tile<FMT, 1>(prog, pl, ids, n, io, stream);
+            return rows == 4 ? launch_fir_tile<FMT, 4>(prog, pl, ids, n, io, stream, scope)
+                 : rows == 2 ? launch_fir_tile<FMT, 2>(prog, pl, ids, n, io, stream, scope)
+                             : launch_fir_tile<FMT, 1>(prog, pl, ids, n, io, stream, scope);
         }
         FirArgs a{};
         a.buf = prog->d_buf; a.chains = pl.d_chains; a.group = ids; a.ngroup = n;
@@ -2050,7 +2365,7 @@ int launch_all(avdsp_hip_prog *prog, Plan &pl, BlockIO io, int fir_impl, int biq
         if (pl.n_fir && launch_fir<FMT>(prog, pl, pl.d_fir_ids, pl.n_fir, io, fir_impl, stream)) return -1;
     }
     if (pl.n_pass) {
-        ProfileScope scope(prog, stream, AVDSP_KERNEL_PASS);
+        ProfileScope scope(prog, stream, AVDSP_KERNEL_PASS); scope.begin();
         PassArgs a{pl.d_chains, pl.d_pass_ids, pl.n_pass, io};
         const long long total = (long long)pl.n_pass * io.nframes;
         const int grid = (int)std::min<long long>((total + kBlock - 1) / kBlock, 2048);
@@ -2116,6 +2431,7 @@ void avdsp_hip_prog_destroy(avdsp_hip_prog *p)
         for (auto e : {sl.h2d, sl.run, sl.d2h}) if (e) (void)hipEventDestroy(e);
     }
     if (p->s_bq) (void)hipStreamDestroy(p->s_bq);
+    if (p->ev_unpack) (void)hipEventDestroy(p->ev_unpack);
     for (int i = 0; i < 2; i++) { if (p->ev_bq[i]) (void)hipEventDestroy(p->ev_bq[i]); if (p->ev_fir[i]) (void)hipEventDestroy(p->ev_fir[i]); }
     (void)hipFree(p->d_buf); (void)hipFree(p->d_in); (void)hipFree(p->d_out); (void)hipFree(p->d_tpdf); (void)hipFree(p->d_frame);
     (void)hipFree(p->d_tpdf_seq);
@@ -2172,8 +2488,21 @@ int avdsp_hip_prog_add_plan(avdsp_hip_prog *prog, const avdsp_plan_desc *d)
          * 8-section cascades 85 -> 62 us) and idle lanes cost nothing there */
         int P = e.first > 64 ? 128 : pow2ceil(e.first);
         if (P < 16 && (long long)e.second.size() * 16 <= 65536) P = 16;
-        Plan::Group g{P, e.first, (int)e.second.size(), nullptr};
+        bool all_fir = true;
+        for (int id : e.second) all_fir = all_fir && chains[id].fir_taps != 0;
+        Plan::Group g{P, e.first, (int)e.second.size(), nullptr, all_fir, nullptr, nullptr};
         if (upload_vec(&g.d_ids, e.second)) { free_plan(pl); return -1; }
+        if (P == 16 && d->format != 2) {                 /* what biquad_row loads instead of walking group -> chain -> section tables */
+            std::vector<RowRec> rows(e.second.size());
+            std::vector<LaneRec> lanes(e.second.size() * 16, LaneRec{-1, -1});
+            for (size_t i = 0; i < e.second.size(); i++) {
+                const avdsp_chain &c = chains[e.second[i]];
+                rows[i] = RowRec{e.second[i], c.in_io, c.out_io[0], (c.load_mode & 0xFF) | (c.sat ? 1 << 8 : 0) | (c.fir_taps ? 1 << 9 : 0) | (c.n_out << 16),
+                                 c.gain_bits, {0, 0, 0}};
+                for (int k = 0; k < c.nsec; k++) lanes[i * 16 + (16 - c.nsec) + k] = LaneRec{coef[c.sec_base + k], state[c.sec_base + k]};
+            }
+            if (upload_vec(&g.d_rows, rows) || upload_vec(&g.d_lanes, lanes)) { (void)hipFree(g.d_ids); (void)hipFree(g.d_rows); free_plan(pl); return -1; }
+        }
         pl.bq.push_back(g);
     }
     pl.n_fir = (int)fir.size(); pl.n_pass = (int)pass.size();
@@ -2399,7 +2728,7 @@ static int launch_generic(avdsp_hip_prog *prog, Plan &pl, BlockIO io, hipStream_
     if (tpdf_seq_for(prog, a, io.nframes)) return -1;
     const dim3 grid(1), block(64);
     if (wave_plan_fits(prog, pl, io, a)) {
-        ProfileScope scope(prog, stream, AVDSP_KERNEL_GENERIC_WAVE);
+        ProfileScope scope(prog, stream, AVDSP_KERNEL_GENERIC_WAVE); scope.begin();
         const size_t lds = ((size_t)a.batch_lds + 128 + (size_t)a.nvm * 128 + a.seq_words) * 4;
         switch (pl.format) {
         case 2:  hipLaunchKernelGGL((interp_wave<2>), grid, block, lds, stream, a); break;
@@ -2411,7 +2740,7 @@ static int launch_generic(avdsp_hip_prog *prog, Plan &pl, BlockIO io, hipStream_
         HIP_TRY(hipGetLastError());
         return 0;
     }
-    ProfileScope scope(prog, stream, AVDSP_KERNEL_GENERIC);
+    ProfileScope scope(prog, stream, AVDSP_KERNEL_GENERIC); scope.begin();
 #define AVDSP_LAUNCH_INTERP(F) \
     if (pl.ga_staged) hipLaunchKernelGGL((interp_core<F, true>), grid, block, pl.ga_lds, stream, a); \
     else              hipLaunchKernelGGL((interp_core<F, false>), grid, block, pl.ga_lds, stream, a)
@@ -2523,7 +2852,7 @@ int avdsp_hip_run_block(avdsp_hip_prog *prog, int plan, const void *d_in, int in
         return launch_generic(prog, pl, io, (hipStream_t)stream);
     }
     if (pl.lane_mode) {
-        ProfileScope scope(prog, (hipStream_t)stream, AVDSP_KERNEL_BIQUAD);
+        ProfileScope scope(prog, (hipStream_t)stream, AVDSP_KERNEL_BIQUAD); scope.begin();
         LaneArgs a{};
         a.buf = prog->d_buf; a.chains = pl.d_chains; a.sec_coef = pl.d_sec_coef; a.sec_state = pl.d_sec_state; a.nchains = pl.nchains;
         a.io.in = (const unsigned *)d_in;  a.io.in_stride = in_stride;   a.io.in_base = in_io_base;
@@ -2556,11 +2885,13 @@ int avdsp_hip_run_block(avdsp_hip_prog *prog, int plan, const void *d_in, int in
 /* "host_pin": pin the caller's buffer where it lies (a host hands over the same buffers block after block): copies from and
  * to pinned memory are true DMA and run beside kernels.  Registrations are remembered, which is only sound while the caller
  * keeps those buffers allocated -- a registration outlives free(), and a new allocation at the same address would then
- * receive DMA into the OLD pages.  Hence opt-in; without it the copies go through the driver's own staging.      */
-static void pin_in_place(avdsp_hip_prog *prog, const void *ptr, size_t bytes)
+ * receive DMA into the OLD pages.  Hence opt-in; without it the synchronous calls copy through the driver's own staging and
+ * the queued calls (avdsp_hip_submit_block_host) register a block's buffers for the time the block is in flight only --
+ * avdsp_hip_wait_block_host releases them as it lets the block through, so a buffer may be freed once its block is back.   */
+static void pin_in_place(avdsp_hip_prog *prog, const void *ptr, size_t bytes, bool hold = false)
 {
     for (auto &pn : prog->pinned)
-        if (pn.ptr == ptr && pn.bytes >= bytes) return;
+        if (pn.ptr == ptr && pn.bytes >= bytes) { pn.refs += hold; return; }
     if (prog->pinned.size() >= 16) {
         (void)avdsp_hip_wait_block_host(prog, 0);           /* (queued blocks may be copying from the buffers about to be released) */
         for (auto &pn : prog->pinned) if (pn.ours) (void)hipHostUnregister(const_cast<void *>(pn.ptr));
@@ -2568,7 +2899,22 @@ static void pin_in_place(avdsp_hip_prog *prog, const void *ptr, size_t bytes)
     }
     const hipError_t e = hipHostRegister(const_cast<void *>(ptr), bytes, hipHostRegisterDefault);
     (void)hipGetLastError();
-    prog->pinned.push_back({ptr, bytes, e == hipSuccess});
+    prog->pinned.push_back({ptr, bytes, e == hipSuccess, hold ? 1 : 0});
+}
+
+/* a queued block has gone back: without "host_pin" its buffers' registrations end with it (the caller may free them now) */
+static void unpin_block(avdsp_hip_prog *prog, const void *ptr)
+{
+    for (size_t i = 0; i < prog->pinned.size(); i++) {
+        auto &pn = prog->pinned[i];
+        if (pn.ptr != ptr) continue;
+        if (pn.refs > 0) pn.refs--;
+        if (pn.refs == 0 && !prog->host_pin) {
+            if (pn.ours) (void)hipHostUnregister(const_cast<void *>(pn.ptr));
+            prog->pinned.erase(prog->pinned.begin() + (long)i);
+        }
+        return;
+    }
 }
 
 int avdsp_hip_run_block_host(avdsp_hip_prog *prog, int plan, const void *h_in, int in_stride, int in_io_base,
@@ -2617,7 +2963,10 @@ int avdsp_hip_run_block_host(avdsp_hip_prog *prog, int plan, const void *h_in, i
             HIP_TRY(hipMemcpyAsync(di, hi, (size_t)nf * in_stride * 4, hipMemcpyHostToDevice, prog->s_h2d));
             HIP_TRY(hipEventRecord(prog->ev_host[2 * k], prog->s_h2d));
             HIP_TRY(hipStreamWaitEvent(prog->s_run, prog->ev_host[2 * k], 0));
-            if (avdsp_hip_run_block(prog, plan, di, in_stride, in_io_base, dout, out_stride, out_io_base, nf, fir_impl, biquad_impl, prog->s_run)) return -1;
+            prog->input_ready = prog->ev_host[2 * k];       /* "overlap": the cascade runs on a stream of its own and must wait for this piece's copy too */
+            const int rc = avdsp_hip_run_block(prog, plan, di, in_stride, in_io_base, dout, out_stride, out_io_base, nf, fir_impl, biquad_impl, prog->s_run);
+            prog->input_ready = nullptr;
+            if (rc) return -1;
             HIP_TRY(hipEventRecord(prog->ev_host[2 * k + 1], prog->s_run));
             HIP_TRY(hipStreamWaitEvent(prog->s_d2h, prog->ev_host[2 * k + 1], 0));
             HIP_TRY(hipMemcpyAsync((unsigned *)h_out + (size_t)f0 * out_stride, dout, (size_t)nf * out_stride * 4, hipMemcpyDeviceToHost, prog->s_d2h));
@@ -2647,6 +2996,8 @@ int avdsp_hip_wait_block_host(avdsp_hip_prog *prog, int max_in_flight)
     while ((long long)(prog->hq_submitted - prog->hq_waited) > max_in_flight) {
         auto &sl = prog->hq[prog->hq_waited % avdsp_hip_prog::kHostQueue];
         HIP_TRY(hipEventSynchronize(sl.d2h));
+        if (sl.h_in)  { unpin_block(prog, sl.h_in);  sl.h_in = nullptr; }
+        if (sl.h_out) { unpin_block(prog, sl.h_out); sl.h_out = nullptr; }
         prog->hq_waited++;
     }
     return (int)(prog->hq_submitted - prog->hq_waited);
@@ -2679,8 +3030,8 @@ int avdsp_hip_submit_block_host(avdsp_hip_prog *prog, int plan, const void *h_in
         (void)hipFree(sl.d_out); sl.d_out = nullptr; sl.out_cap = 0;
         HIP_TRY(hipMalloc((void **)&sl.d_out, out_words * 4)); sl.out_cap = out_words;
     }
-    pin_in_place(prog, h_in, in_words * 4);
-    pin_in_place(prog, h_out, out_words * 4);
+    pin_in_place(prog, h_in, in_words * 4, true);   sl.h_in = h_in;
+    pin_in_place(prog, h_out, out_words * 4, true); sl.h_out = h_out;
     const bool whole = pl.stores_whole_window && out_io_base == pl.io_out_min && out_stride == pl.io_out_max - pl.io_out_min + 1;
     if (!whole) HIP_TRY(hipMemcpyAsync(sl.d_out, h_out, out_words * 4, hipMemcpyHostToDevice, prog->q_h2d));   /* unstored slots keep their content */
     HIP_TRY(hipMemcpyAsync(sl.d_in, h_in, in_words * 4, hipMemcpyHostToDevice, prog->q_h2d));
@@ -2689,7 +3040,11 @@ int avdsp_hip_submit_block_host(avdsp_hip_prog *prog, int plan, const void *h_in
     prog->input_ready = sl.h2d;
     const int rc = avdsp_hip_run_block(prog, plan, sl.d_in, in_stride, in_io_base, sl.d_out, out_stride, out_io_base, nframes, fir_impl, biquad_impl, prog->q_run);
     prog->input_ready = nullptr;
-    if (rc) return -1;
+    if (rc) {
+        (void)hipStreamSynchronize(prog->q_h2d);
+        unpin_block(prog, sl.h_in); unpin_block(prog, sl.h_out); sl.h_in = sl.h_out = nullptr;
+        return -1;
+    }
     HIP_TRY(hipEventRecord(sl.run, prog->q_run));
     HIP_TRY(hipStreamWaitEvent(prog->q_d2h, sl.run, 0));
     HIP_TRY(hipMemcpyAsync(h_out, sl.d_out, out_words * 4, hipMemcpyDeviceToHost, prog->q_d2h));
@@ -2764,7 +3119,7 @@ int avdsp_hip_run_levels(avdsp_hip_prog *prog, const int *plans, const int *leve
             if (grid_ok) {
                 HIP_TRY(hipMemcpyAsync(d_slot, table, (size_t)n * sizeof(GenericArgs), hipMemcpyHostToDevice, main));
                 {
-                    ProfileScope scope(prog, main, AVDSP_KERNEL_GENERIC_WAVE);
+                    ProfileScope scope(prog, main, AVDSP_KERNEL_GENERIC_WAVE); scope.begin();
                     const dim3 grid(n), block(64);
                     switch (prog->plans[plans[at]].format) {
                     case 2:  hipLaunchKernelGGL((interp_wave_grid<2>), grid, block, lds, main, d_slot); break;
@@ -2837,12 +3192,22 @@ int avdsp_hip_unpack_pcm(avdsp_hip_prog *prog, int pcm, const void *d_src, void 
     if (pcm != AVDSP_PCM_S24_3LE && pcm != AVDSP_PCM_S16) return set_err("unpack: PCM kind %d needs no conversion or is unknown", pcm);
     if (reinterpret_cast<size_t>(d_dst) & 15) return set_err("unpack: destination must be 16-byte aligned");
     if (!nsamples) return 0;
-    ProfileScope scope(prog, (hipStream_t)stream, AVDSP_KERNEL_UNPACK);
+    ProfileScope scope(prog, (hipStream_t)stream, AVDSP_KERNEL_UNPACK); scope.begin();
     UnpackArgs a{(const unsigned char *)d_src, (unsigned *)d_dst, nsamples};
     const int grid = (int)std::min<size_t>((nsamples / 4 + kBlock - 1) / kBlock + 1, 8192);
     if (pcm == AVDSP_PCM_S24_3LE) hipLaunchKernelGGL(pcm_unpack<AVDSP_PCM_S24_3LE>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a);
     else                          hipLaunchKernelGGL(pcm_unpack<AVDSP_PCM_S16>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+/* the block that follows reads what pcm_unpack (null stream) is still writing: the overlap mode's cascade, on its own
+ * non-blocking stream, waits for this event (launch_all) */
+static int unpack_done(avdsp_hip_prog *prog)
+{
+    if (!prog->ev_unpack) HIP_TRY(hipEventCreateWithFlags(&prog->ev_unpack, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(prog->ev_unpack, nullptr));
+    prog->input_ready = prog->ev_unpack;
     return 0;
 }
 
@@ -2871,9 +3236,11 @@ int avdsp_hip_run_block_pcm_host(avdsp_hip_prog *prog, int plan, int pcm, const 
     unsigned *d_raw = prog->d_in + unpacked;
     HIP_TRY(hipMemcpy(d_raw, h_src, raw_bytes, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(prog->d_out, h_out, out_words * 4, hipMemcpyHostToDevice));
-    if (avdsp_hip_unpack_pcm(prog, pcm, d_raw, prog->d_in, nsamples, nullptr)) return -1;
-    if (avdsp_hip_run_block(prog, plan, prog->d_in, in_stride, in_io_base, prog->d_out, out_stride, out_io_base,
-                            nframes, fir_impl, biquad_impl, nullptr)) return -1;
+    if (avdsp_hip_unpack_pcm(prog, pcm, d_raw, prog->d_in, nsamples, nullptr) || unpack_done(prog)) return -1;
+    const int rc = avdsp_hip_run_block(prog, plan, prog->d_in, in_stride, in_io_base, prog->d_out, out_stride, out_io_base,
+                                       nframes, fir_impl, biquad_impl, nullptr);
+    prog->input_ready = nullptr;
+    if (rc) return -1;
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(h_out, prog->d_out, out_words * 4, hipMemcpyDeviceToHost));
     return 0;
@@ -2909,9 +3276,11 @@ int avdsp_hip_run_levels_pcm_host(avdsp_hip_prog *prog, const int *plans, const 
     unsigned *d_raw = prog->d_in + unpacked;
     HIP_TRY(hipMemcpy(d_raw, h_src, raw_bytes, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(prog->d_out, h_out, out_words * 4, hipMemcpyHostToDevice));
-    if (avdsp_hip_unpack_pcm(prog, pcm, d_raw, prog->d_in, nsamples, nullptr)) return -1;
-    if (avdsp_hip_run_levels(prog, plans, level_size, nlevels, prog->d_in, in_stride, in_io_base, prog->d_out, out_stride,
-                             out_io_base, nframes, fir_impl, biquad_impl, nullptr)) return -1;
+    if (avdsp_hip_unpack_pcm(prog, pcm, d_raw, prog->d_in, nsamples, nullptr) || unpack_done(prog)) return -1;
+    const int rc = avdsp_hip_run_levels(prog, plans, level_size, nlevels, prog->d_in, in_stride, in_io_base, prog->d_out, out_stride,
+                                        out_io_base, nframes, fir_impl, biquad_impl, nullptr);
+    prog->input_ready = nullptr;
+    if (rc) return -1;
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(h_out, prog->d_out, out_words * 4, hipMemcpyDeviceToHost));
     return 0;
@@ -2953,7 +3322,11 @@ int avdsp_hip_prog_set_option(avdsp_hip_prog *prog, int key, int value)
     case AVDSP_OPT_PROFILE_STRIDE: if (value < 1) return set_err("profile_stride: every n-th launch, n >= 1"); prog->profile_stride = value; return 0;
     case AVDSP_OPT_HOST_SPLIT: if (value < 0) return set_err("host_split: frames per piece, 0 = whole block"); prog->host_split = value; return 0;
     case AVDSP_OPT_HOST_PIN: prog->host_pin = value != 0;
-                             if (!value) { for (auto &pn : prog->pinned) if (pn.ours) (void)hipHostUnregister(const_cast<void *>(pn.ptr)); prog->pinned.clear(); }
+                             if (!value) {           /* (nothing is in flight: set_option synchronised above; queued blocks keep their references until waited for) */
+                                 (void)avdsp_hip_wait_block_host(prog, 0);
+                                 for (auto &pn : prog->pinned) if (pn.ours) (void)hipHostUnregister(const_cast<void *>(pn.ptr));
+                                 prog->pinned.clear();
+                             }
                              return 0;
     }
     return set_err("unknown device option %d", key);

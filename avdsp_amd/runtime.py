@@ -248,14 +248,19 @@ class Runtime:
         return out
 
     def submit_block(self, x: np.ndarray, out: np.ndarray, in_io_base: int, out_io_base: int = 0) -> int:
-        """dspRuntimeBlockSubmit for every core: the block is queued (copies and kernels of up to four blocks overlap);
-        x and out (C-contiguous, the runtime's sample type) belong to the library until wait_blocks lets the block through.
+        """dspRuntimeBlockSubmit: the block is queued (copies and kernels of up to four blocks overlap); x and out
+        (C-contiguous, the runtime's sample type) belong to the library until wait_blocks lets the block through -- keep
+        them alive until then.  With set_option("host_pin", 1) their registrations are kept for reuse and the arrays must
+        stay alive until host_pin goes back to 0 (or release()).  A program with several cores queues them one after the
+        other: the cores share the output window, so core k+1 is submitted when core k's block is back.
         Returns the number of blocks in flight."""
         dt = sample_dtype(self.fmt)
         if x.dtype != dt or out.dtype != dt or not x.flags.c_contiguous or not out.flags.c_contiguous:
             raise ValueError("submit_block takes C-contiguous arrays of the runtime's sample type (they are used in place)")
         rc = 0
-        for core in self.cores:
+        for k, core in enumerate(self.cores):
+            if k:
+                self._check(min(self.L.dspRuntimeBlockWait(0), 0))
             rc = self.L.dspRuntimeBlockSubmit(self.fmt, core, self.rundata, x.ctypes.data, x.shape[1], in_io_base,
                                               out.ctypes.data, out.shape[1], out_io_base, x.shape[0])
             self._check(min(rc, 0))

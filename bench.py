@@ -52,6 +52,7 @@ WORKLOADS = {
 # quoted in SURVEY.md 8(d) / BASELINE.md 3 for FP64 (vector and matrix alike): 78.6 TFLOP/s.
 PEAK_F64_TFLOPS = 78.6
 PEAK_HBM_GBS = 8000.0
+PEAK_F32_TFMAS = 157.3 / 2.0          # FP32 vector FMAs per second (157.3 TFLOP/s); 32x32-bit integer multiply-adds run at a quarter of it
 
 
 def pmc_traffic(workload, kernel):
@@ -175,6 +176,59 @@ def cpu_baseline(fmt, S, T, B, budget_s=10.0):
                        f"cores = what this job may use (affinity mask and cgroup quota) of the host's {n_all} CPUs")
 
 
+# BASELINE workloads whose every channel is pinned against the compiled reference (tests/golden/make_headline_goldens.py)
+HEADLINE_CASE = {"north": "north_f6", "cfg3": "cfg3_f6", "cfg3i": "cfg3_f2", "cfg4": "cfg4_f6", "cfg5": "cfg5_f6"}
+
+
+def verify_against_reference_pins(args, make_runtime, workload, shard_rank, shard_world, torch):
+    """Before anything is timed: the benchmarked workload's HEADLINE input (seed 20260104, several blocks so that FIR histories
+    fill) through a fresh runtime on the same dspRuntimeBlockDevice path with the same options, this rank's columns against the
+    reference's pins -- per-channel sums of the output words of every block of the case, and (whole program on one rank) the
+    SHA-256 of every block and of the final state.  Returns a description for the JSON line; raises SystemExit on a mismatch."""
+    import hashlib
+    from avdsp_amd import progbuilder as pb
+    name = HEADLINE_CASE.get(workload)
+    gdir = os.path.join(ROOT, "tests", "golden")
+    if name is None or not os.path.exists(os.path.join(gdir, f"headline_{name}.npz")):
+        return None
+    with open(os.path.join(gdir, "headline_manifest.json")) as f:
+        case = json.load(f)["cases"][name]
+    g = np.load(os.path.join(gdir, f"headline_{name}.npz"))
+    fmt, C, B, frames = case["fmt"], case["channels"], case["block"], case["frames"]
+    x = pb.lcg_input(frames, C, fmt in (5, 6), seed=case["seed"])
+    r = make_runtime()
+    r.set_shard(shard_rank, shard_world)
+    info = r.shard_info()
+    Cl, in_base, out_base = info["nchains"], info["in_io_min"], info["out_io_min"]
+    if Cl < 1:
+        r.release()
+        return f"{name}: shard {shard_rank}/{shard_world} holds no chains"
+    xs = torch.from_numpy(np.ascontiguousarray(x[:, in_base - C:in_base - C + Cl])).cuda()
+    ys = torch.zeros((frames, Cl), dtype=xs.dtype, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    for k in range(frames // B):
+        r.run_block_device(xs[k * B:].data_ptr(), Cl, in_base, ys[k * B:].data_ptr(), Cl, out_base, B, stream)
+    torch.cuda.synchronize()
+    out = ys.cpu().numpy()
+    w = np.ascontiguousarray(out).view(np.uint32)
+    col = w.sum(axis=0, dtype=np.uint64).astype(np.uint32)
+    want = g["col_sum"][out_base:out_base + Cl]
+    bad = np.nonzero(col != want)[0]
+    if bad.size:
+        sys.exit(f"bench.py: VERIFICATION FAILED on shard {shard_rank}/{shard_world}: {bad.size} of {Cl} channels differ from the "
+                 f"reference's pins of {name} (first: channel {out_base + int(bad[0])})")
+    what = f"{name}: blocks 0..{frames // B - 1}, channels {out_base}..{out_base + Cl - 1}: per-channel word sums vs reference pins"
+    if shard_world == 1:
+        for k, sha_want in enumerate(case["block_sha"]):
+            if hashlib.sha256(np.ascontiguousarray(out[k * B:(k + 1) * B]).tobytes()).hexdigest() != sha_want:
+                sys.exit(f"bench.py: VERIFICATION FAILED: block {k} of {name} differs from the reference (SHA-256)")
+        if hashlib.sha256(np.ascontiguousarray(r.sync_state()).tobytes()).hexdigest() != case["state_sha"]:
+            sys.exit(f"bench.py: VERIFICATION FAILED: final state of {name} differs from the reference (SHA-256)")
+        what += " + SHA-256 of every block and of the final state"
+    r.release()
+    return what
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -192,6 +246,9 @@ def main():
     ap.add_argument("--settle", type=float, default=0.5, help="seconds of untimed steps in front of the warm-up: the chip raises its clock over the first ~0.1 s of load "
                     "(tools/fir_timeline.py: 2.15 GHz in-kernel after 6 blocks, 2.36 GHz after 200) and a short run would be timed on the ramp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the pre-timing check of this rank's columns against the reference's pins")
+    ap.add_argument("--gather", action="store_true", help="N > 1: also time an RCCL all_gather of the ranks' [B][C/N] output blocks and an all_reduce of "
+                    "their checksums (SURVEY.md 8e: block-boundary collectives), reported BESIDE value, never inside it")
     args = ap.parse_args()
 
     import torch                      # first: its bundled HIP runtime must be the process's only one
@@ -227,19 +284,27 @@ def main():
     shard_rank, shard_world = rank, world
     if args.shard:
         shard_rank, shard_world = (int(v) for v in args.shard.split("/"))
-    r = rt.Runtime(fmt, pb.synth_program(fmt, C, S, T))
-    if r.rc < 0:
-        sys.exit(f"dspRuntimeInit failed: {r.rc} {r.last_error()}")
-    r.set_option("device", device_index)
-    r.set_option("fir_impl", args.fir_impl)
-    r.set_option("biquad_impl", args.biquad_impl)
-    r.set_option("overlap", args.overlap)
-    if args.fir_rows >= 0:
-        r.set_option("fir_rows", args.fir_rows)
-    if args.host_split >= 0:
-        r.set_option("host_split", args.host_split)
-    if args.host_pin >= 0:
-        r.set_option("host_pin", args.host_pin)
+    prog_words = pb.synth_program(fmt, C, S, T)
+
+    def make_runtime():
+        rr = rt.Runtime(fmt, prog_words)
+        if rr.rc < 0:
+            sys.exit(f"dspRuntimeInit failed: {rr.rc} {rr.last_error()}")
+        rr.set_option("device", device_index)
+        rr.set_option("fir_impl", args.fir_impl)
+        rr.set_option("biquad_impl", args.biquad_impl)
+        rr.set_option("overlap", args.overlap)
+        if args.fir_rows >= 0:
+            rr.set_option("fir_rows", args.fir_rows)
+        if args.host_split >= 0:
+            rr.set_option("host_split", args.host_split)
+        if args.host_pin >= 0:
+            rr.set_option("host_pin", args.host_pin)
+        return rr
+
+    # What is about to be timed is checked first, on every rank: the same path, the same options, the reference's own bits
+    verified = None if args.no_verify else verify_against_reference_pins(args, make_runtime, args.workload, shard_rank, shard_world, torch)
+    r = make_runtime()
     r.set_option("profile", 1)
     r.set_shard(shard_rank, shard_world)
     info = r.shard_info()
@@ -288,7 +353,9 @@ def main():
             step()
         torch.cuda.synchronize()
         r.kernel_time(1)
-    r.set_option("profile_stride", 4)                      # every fourth launch: a pair costs the stream ~5 us, 4 % of a 512-chain step
+    # every timed launch of a short run carries its event pair (>= 16 samples); longer runs sample every n-th (a pair costs the stream ~5 us)
+    stride = 1 if args.steps <= 50 else max(1, args.steps // 32)
+    r.set_option("profile_stride", stride)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -299,15 +366,47 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    rank_ms = [elapsed / args.steps * 1e3]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dev = "cuda" if backend == "nccl" else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        every = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(every, t)
+        rank_ms = [float(v.item()) / args.steps * 1e3 for v in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # block-boundary collectives (opt-in, beside the metric): every rank's [B][C/N] output gathered on every rank, checksums summed
+    gather = None
+    if args.gather and world > 1:
+        # (shards differ by at most one chain: every rank hands over max(C/N) columns, the last one of a smaller shard unused)
+        cmax = -(-C // world)
+        ypad = y if Cl == cmax else torch.nn.functional.pad(y, (0, cmax - Cl))
+        dev_y = ypad.contiguous() if backend == "nccl" else ypad.cpu().contiguous()
+        parts = [torch.empty_like(dev_y) for _ in range(world)]
+        csum = dev_y.view(torch.int32).to(torch.int64).sum().reshape(1)
+        for _ in range(3):
+            dist.all_gather(parts, dev_y); dist.all_reduce(csum.clone())
+        torch.cuda.synchronize(); dist.barrier()
+        tg = time.perf_counter()
+        n_g = 20
+        for _ in range(n_g):
+            dist.all_gather(parts, dev_y)
+        torch.cuda.synchronize()
+        t_gather = (time.perf_counter() - tg) / n_g
+        tg = time.perf_counter()
+        for _ in range(n_g):
+            c2 = csum.clone(); dist.all_reduce(c2)
+        torch.cuda.synchronize()
+        t_reduce = (time.perf_counter() - tg) / n_g
+        gather = {"all_gather_ms": t_gather * 1e3, "bytes_per_rank": int(dev_y.numel() * 4), "checksum_all_reduce_ms": t_reduce * 1e3,
+                  "backend": backend}
 
     bq_ms, bq_n = r.kernel_time(0) if bq_side is None else bq_side
     fir_ms, fir_n = r.kernel_time(1)
-    # What an event pair measures with NOTHING between its two records (4.6 us on MI355X): part of every bracketed launch, not of
-    # the kernel -- rocprofv3's kernel trace, which stamps the kernel itself, reads that much less.  Taken off per launch below.
+    # The timed kernels (fir_tile, biquad_row / biquad_pipe) carry their events in hipExtLaunchKernel's start / stop slots: the
+    # dispatch's own start and end stamps, what rocprofv3's kernel trace reads, nothing on the stream -- no correction applies.
+    # (Kernels launched the plain way are bracketed by two recorded events, which read ~5 us more than the kernel took:
+    # kernels_ms.event_pair says how much on this box.)
     pairs = []
     for _ in range(60):
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
@@ -315,10 +414,8 @@ def main():
         pairs.append((e0, e1))
     torch.cuda.synchronize()
     pair_ms = float(np.median([a.elapsed_time(b) for a, b in pairs[10:]]))
+    rides = args.fir_impl == 1 and args.biquad_impl != 0
     fir_raw, bq_raw = fir_ms / max(fir_n, 1), bq_ms / max(bq_n, 1)
-    fir_ms, bq_ms = max(fir_ms - pair_ms * fir_n, 0.0), max(bq_ms - pair_ms * bq_n, 0.0)
-    if fir_alone is not None:
-        fir_alone = (max(fir_alone[0] - pair_ms * fir_alone[1], 0.0), fir_alone[1])
     checksum = float(y.double().abs().sum().item()) if fmt == 6 else float(y.to(torch.float64).abs().sum().item())
     if not np.isfinite(checksum) or checksum == 0.0:
         sys.exit("bench.py: output block is empty or not finite")
@@ -337,6 +434,7 @@ def main():
         host_rate = Cl * B * n / (time.perf_counter() - th) / 1e6
         # ... and as a queue (dspRuntimeBlockSubmit / Wait): four blocks in flight, the host cycles through six buffer pairs
         ring = [(xs.copy(), np.zeros((B, Cl), dtype=xs.dtype)) for _ in range(6)]
+        r.set_option("host_pin", 1)       # six buffer pairs, reused: keep their registrations (they outlive this leg)
         for k in range(30):
             r.submit_block(*ring[k % 6], in_base, out_base); r.wait_blocks(3)
         r.wait_blocks(0)
@@ -361,7 +459,9 @@ def main():
         # several ranks: rank 0's shard, if that shard was profiled alone (profiles/traffic.json has north and cfg5 in 8)
         traffic_key = f"{args.workload} shard {args.shard}" if args.shard else (args.workload if world == 1 else f"{args.workload} shard 0/{world}")
         if T and fir_n:
-            per_launch = fir_ms / fir_n * 1e-3
+            # `frac` from the kernel's own start / end stamps of every timed launch (rocprofv3's kernel average of the same command
+            # agrees, profiles/)
+            per_launch = fir_raw * 1e-3
             # 2*T flop per sample; the Cl*B samples of a step are spread over fir_n/steps launches
             launches_per_step = (B + 1023) // 1024           # blocks longer than 1024 frames are cut into 1024-frame launches
             flops = 2.0 * T * B * Cl / launches_per_step
@@ -370,6 +470,7 @@ def main():
             fir_bytes = (4.0 * Cl * B + 4.0 * (T - 1 + B) * Cl + 4.0 * T * Cl) / launches_per_step   # out, window, taps
             roof = dict(bound="mfma", kernel=kname, achieved=ach,
                         peak=PEAK_F64_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_F64_TFLOPS,
+                        timing="dispatch start/end stamps (hipExtLaunchKernel events), every timed launch" if rides else "event pairs recorded around the launch (read ~event_pair more)",
                         traffic=pmc_traffic(traffic_key, kname), traffic_source="profiles/traffic.json (committed rocprofv3 --pmc passes of this command, not this run)",
                         hbm_frac=fir_bytes / per_launch / 1e9 / PEAK_HBM_GBS,
                         launch_ms=per_launch * 1e3, launches=fir_n)
@@ -378,13 +479,24 @@ def main():
                 roof["launch_ms_alone"] = fir_alone[0] / fir_alone[1]
                 roof["frac_alone"] = flops / (roof["launch_ms_alone"] * 1e-3) / 1e12 / PEAK_F64_TFLOPS
         elif bq_n:
-            per_launch = bq_ms / bq_n * 1e-3
+            # The cascade is a recurrence: what binds it is vector-instruction issue, not memory.  Both ceilings, the binding one first
+            # (SURVEY.md 8d): double models 10 flop per section and sample against the FP64 vector peak; int64 5 32x32->64 MADs per
+            # section and sample against a quarter of the FP32 FMA rate (v_mad_i64_i32); HBM: algorithmic bytes against 8 TB/s.
+            per_launch = bq_raw * 1e-3
             nbytes = 8.0 * Cl * B + 48.0 * S * Cl + 20.0 * S * Cl   # samples in+out, state r+w, coefficients
-            ach = nbytes / per_launch / 1e9
-            kname = "biquad_pipe" if args.biquad_impl else "biquad_simple"
-            roof = dict(bound="hbm", kernel=kname, achieved=ach,
-                        peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS,
-                        traffic=pmc_traffic(traffic_key, kname), traffic_source="profiles/traffic.json (committed rocprofv3 --pmc passes of this command, not this run)",
+            hbm_ach = nbytes / per_launch / 1e9
+            kname = "biquad_simple" if not args.biquad_impl else ("biquad_pipe" if args.biquad_impl == 2 or fmt == 2 else "biquad_row")
+            if fmt == 2:
+                ops, peak, unit = 5.0 * S * Cl * B, PEAK_F32_TFMAS / 4.0, "T MAD/s (v_mad_i64_i32; quarter of the FP32 FMA rate)"
+            else:
+                ops, peak, unit = 10.0 * S * Cl * B, PEAK_F64_TFLOPS, "TFLOP/s"
+            ach = ops / per_launch / 1e12
+            roof = dict(bound="valu", kernel=kname, achieved=ach, peak=peak, unit=unit, frac=ach / peak,
+                        timing="dispatch start/end stamps (hipExtLaunchKernel events), every timed launch" if rides else "event pairs recorded around the launch (read ~event_pair more)",
+                        hbm=dict(achieved=hbm_ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=hbm_ach / PEAK_HBM_GBS),
+                        hbm_frac=hbm_ach / PEAK_HBM_GBS,
+                        traffic=pmc_traffic(traffic_key, kname) or pmc_traffic(traffic_key, "biquad_pipe"),
+                        traffic_source="profiles/traffic.json (committed rocprofv3 --pmc passes of this command, not this run)",
                         launch_ms=per_launch * 1e3, launches=bq_n)
         else:
             roof = None
@@ -398,12 +510,17 @@ def main():
             "config": {"workload": f"{args.workload}: {C} ch x ({S} biquads + {T}-tap FIR), block {B} frames, "
                                    f"DSP_FORMAT {fmt}; {shard_txt}, no data-path collective",
                        "channels": C, "channels_per_gpu": Cl, "sections": S, "taps": T, "block": B, "format": fmt,
-                       "overlap": r.get_option("overlap"), "settle_s": args.settle},
+                       "overlap": r.get_option("overlap"), "settle_s": args.settle, "profile_stride": stride},
             "roofline": roof,
             "hbm_frac_step": step_bytes / step_s / 1e9 / PEAK_HBM_GBS,
-            "kernels_ms": {"biquad": bq_ms / max(bq_n, 1), "fir": fir_ms / max(fir_n, 1), "biquad_raw": bq_raw, "fir_raw": fir_raw,
-                           "event_pair": pair_ms},
+            "kernels_ms": {"biquad": bq_raw, "fir": fir_raw, "event_pair": pair_ms},
         }
+        line["verified"] = verified
+        if world > 1:
+            line["ranks"] = world
+            line["rank_ms_per_step"] = rank_ms
+        if gather is not None:
+            line["gather"] = gather
         if host_rate is not None:
             line["host_buffers_msamples_s"] = host_rate
             line["host_queue_msamples_s"] = host_queue_rate

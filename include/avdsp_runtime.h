@@ -100,10 +100,15 @@ int dspRuntimeBlock_6(opcode_t *core, int *rundata, const float *in, int in_stri
  * (a hipStream_t passed as void*, NULL = default stream).  Asynchronous: returns after enqueue. */
 /* dspRuntimeBlock_N as a queue: submit returns once the block's copies and kernels are enqueued (its value: blocks in
  * flight, < 0 on error); up to four blocks are in flight, the copies of one under the kernels of another.  `in` and `out`
- * are pinned in place on first use and stay the library's -- allocated, unread, unwritten -- until dspRuntimeBlockWait
- * has let the block through.  dspRuntimeBlockWait(m) returns when at most m submitted blocks are unfinished (oldest
- * first; m = 0: all done) with the number that still are.  Results are those of the same dspRuntimeBlock_N calls in
- * the same order; every other entry point waits for the queue by itself.                                         */
+ * are pinned in place (hipHostRegister) and stay the library's -- allocated, unread, unwritten -- until
+ * dspRuntimeBlockWait has let the block through; the registration ends there too, so a buffer may be freed as soon as
+ * its block is back.  A host that cycles through the same few buffers sets dspRuntimeSetOption("host_pin", 1): the
+ * registrations are then kept (registering 16 MB costs about as much as copying it) and the buffers must stay
+ * allocated until "host_pin" is set back to 0, the program is released, or dspRuntimeRelease().
+ * dspRuntimeBlockWait(m) returns when at most m submitted blocks are unfinished (oldest first; m = 0: all done) with
+ * the number that still are.  Results are those of the same dspRuntimeBlock_N calls in the same order; every other
+ * entry point waits for the queue by itself.  One core per block in flight: a program with several chain cores
+ * submits core k+1 after dspRuntimeBlockWait(0) for core k (they share the output window), or uses dspRuntimeBlockAll. */
 int dspRuntimeBlockSubmit(int format, opcode_t *core, int *rundata, const void *in, int in_stride, int in_io_base,
                           void *out, int out_stride, int out_io_base, int nframes);
 int dspRuntimeBlockWait(int max_in_flight);
@@ -175,7 +180,7 @@ int dspRuntimeShardInfo(int format, opcode_t *core, int *total_chains, int *firs
                         int *in_io_min, int *in_io_max, int *out_io_min, int *out_io_max);
 
 /* Tunables: "fir_impl" 0 = plain tap loop, 1 = MFMA (default); "biquad_impl" 0 = lane per channel,
- * 1 = section-pipelined (default); "interp_impl" 0 = interpreter always frame by frame, 1 = frame-parallel
+ * 1 = section-pipelined (default: biquad_row where it applies, else biquad_pipe), 2 = round 2's biquad_pipe throughout; "interp_impl" 0 = interpreter always frame by frame, 1 = frame-parallel
  * where the core allows it (default); "strand_split" 0 = dspRuntimeBlockAll keeps cores whole; "generic" 1 = every core through the interpreter;
  * "device" = HIP device ordinal (before the first block).                                        */
 int dspRuntimeSetOption(const char *key, int value);

@@ -190,3 +190,39 @@ def test_programs_are_contexts_keyed_by_their_buffer():
     finally:
         L.dspRuntimeSetShard(0, 1)
         L.dspRuntimeRelease()
+
+
+def test_two_programs_back_to_back_in_one_array():
+    """rows of one array, the second program starting where the first one's data area ends: both stay loaded and a
+    pointer to the second program's first word names the second program (half-open word ranges)"""
+    L = rt.lib()
+    pa, pb_ = pb.with_data_area(pb.synth_program(2, 3, 2)), pb.with_data_area(pb.synth_program(6, 2, 1, 5))
+    arr = np.concatenate([pa, pb_]).astype(np.uint32)
+    a_ptr, b_ptr = arr.ctypes.data, arr.ctypes.data + 4 * len(pa)
+    ra = L.dspRuntimeInit(a_ptr, len(pa), 48000, 0, 31)
+    rb = L.dspRuntimeInit(b_ptr, len(pb_), 48000, 0, 31)
+    assert ra == int(pa[1]) and rb == int(pb_[1])
+    hdr = C.c_void_p.in_dll(L, "dspHeaderPtr")
+    assert hdr.value == b_ptr
+    assert L.dspRuntimeSelect(a_ptr) == 0 and C.c_void_p.in_dll(L, "dspHeaderPtr").value == a_ptr      # A survived B's load
+    assert L.dspRuntimeSelect(b_ptr) == 0 and C.c_void_p.in_dll(L, "dspHeaderPtr").value == b_ptr      # ... and B's first word is B's
+    assert L.dspRuntimeSelect(a_ptr + 4 * (len(pa) - 1)) == 0 and C.c_void_p.in_dll(L, "dspHeaderPtr").value == a_ptr
+    assert L.dspFindCore(b_ptr, 1) and L.dspFindCore(a_ptr, 1)
+    assert L.dspRuntimeReleaseProgram(a_ptr) == 0 and L.dspRuntimeReleaseProgram(b_ptr) == 0
+
+
+def test_failed_loads_leave_no_context_behind():
+    """a host probing buffers that hold no program must not fill the table of loaded programs (64)"""
+    L = rt.lib()
+    junk = [np.full(64, 0x12345678 + i, dtype=np.uint32) for i in range(70)]
+    for j in junk:
+        assert L.dspRuntimeInit(j.ctypes.data, len(j), 48000, 0, 31) == -1
+    bad = pb.with_data_area(pb.synth_program(2, 2, 2))
+    bad[3] ^= 1                                              # header.checkSum
+    for _ in range(70):
+        assert L.dspRuntimeInit(bad.ctypes.data, len(bad), 48000, 0, 31) == -4
+    good = rt.Runtime(2, pb.synth_program(2, 2, 2))
+    assert good.rc > 0
+    # a failed load does not take the current program away from calls that name none
+    assert L.dspRuntimeInit(junk[0].ctypes.data, 64, 48000, 0, 31) == -1
+    assert C.c_void_p.in_dll(L, "dspHeaderPtr").value == good.buf.ctypes.data

@@ -16,6 +16,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("workload", nargs="?", default="cfg3")
 ap.add_argument("--shard", default=None)
 ap.add_argument("--blocks", type=int, default=300)
+ap.add_argument("--biquad-impl", type=int, default=1)
 args = ap.parse_args()
 lib = "/tmp/libavdsp_bqstamps.so"
 src = os.path.join(ROOT, "avdsp_amd", "csrc")
@@ -31,6 +32,7 @@ import bench                                                       # noqa: E402
 
 fmt, Cn, S, T, B = bench.WORKLOADS[args.workload]
 r = rt.Runtime(fmt, pb.synth_program(fmt, Cn, S, T))
+r.set_option("biquad_impl", args.biquad_impl)
 if args.shard:
     a, b = (int(v) for v in args.shard.split("/"))
     r.set_shard(a, b)
@@ -54,5 +56,7 @@ print(f"  start -> batch loop (coefficients, state, first samples): {med(st[:, 1
 per = np.diff(st[:, 2:26], axis=1)
 print(f"  one batch of 16 steps, batches 12..34: median {med(per):.0f} cycles (p10 {np.percentile(per, 10):.0f}, p90 {np.percentile(per, 90):.0f}) = {med(per) / 16:.1f} per step")
 print(f"  batch loop in all: {med(st[:, 28] - st[:, 1]):.0f} cycles;  behind the loop (state write-back, Inf/NaN look): {med(st[:, 29] - st[:, 28]):.0f} cycles")
+if (st[:, 26] != 0).any():          # biquad_row: the fill batches, the loop of steady batches, the rest (steady leftovers + drain)
+    print(f"  fill batches {med(st[:, 26] - st[:, 1]):.0f} cycles, steady loop {med(st[:, 27] - st[:, 26]):.0f}, leftover + drain batches {med(st[:, 28] - st[:, 27]):.0f}")
 print(f"  wave life {med(st[:, 29] - st[:, 0]):.0f} cycles")
 r.release()
