@@ -2026,7 +2026,8 @@ struct avdsp_hip_prog {
     int overlap = 0;
     int fir_rows = 0;                    /* fir_tile: row tiles per wave (1, 2, 4), 0 = by the number of chains */
     hipStream_t s_bq = nullptr;
-    hipEvent_t ev_bq[2] = {nullptr, nullptr}, ev_fir[2] = {nullptr, nullptr};
+    static constexpr int kAhead = 3;     /* cascade k waits for FIR k - kAhead: it may run under FIR k - 2 and be done before FIR k - 1 ends */
+    hipEvent_t ev_bq[kAhead] = {nullptr, nullptr, nullptr}, ev_fir[kAhead] = {nullptr, nullptr, nullptr};
     int *d_tag_prev = nullptr;           /* tagoutput: the plugin's `previoussample` */
     /* host-pointer block calls: the caller's buffers pinned in place (cache), copies and kernels on three streams */
     struct Pinned { const void *ptr; size_t bytes; bool ours; int refs; };   /* refs: queued blocks still copying from / into it */
@@ -2046,7 +2047,7 @@ struct avdsp_hip_prog {
     hipEvent_t ev_unpack = nullptr;      /* ... recorded behind the library's own pcm_unpack */
     int host_split = 0;                  /* frames per piece of a host block (0 = one piece; pieces only pay with host_pin) */
     int host_pin = 0;                    /* pin the caller's buffers in place and remember them: only for a host that keeps them allocated */
-    bool ev_fir_set[2] = {false, false};
+    bool ev_fir_set[kAhead] = {false, false, false};
     unsigned long long blk = 0;
 };
 
@@ -2322,7 +2323,11 @@ int launch_fir(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, BlockIO io
  * others not at all, and the step shortens by 5 % (4096 channels on one GPU) to 8 % (a 512-channel shard).  (Round 2
  * first tried cascade workgroups of 1024 threads that claimed a CU's LDS to keep FIR waves off their CU: sixteen cascade
  * waves on four SIMDs slow each other 2.5x, and the step got LONGER, 123 -> 147 us on the 512-channel shard.)  Ordering:
- *     cascade k   waits for FIR k-2 (the ring positions it appends are free once that FIR has read its window),
+ *     cascade k   waits for FIR k-3 (the rings hold three launches of frames beside the longest history: the positions it appends
+ *                 are free once that FIR has read its window).  Not k-2: a cascade wave that shares its SIMD with the FIR's MFMA
+ *                 stream is served every few hundred cycles and ends about when that FIR does; the FIR that needs its output
+ *                 would wait for it and for the hand-over between the two queues (7-11 us).  One block further ahead the
+ *                 cascade runs under FIR k-2 and is long done when FIR k-1 ends: FIR k follows FIR k-1 in stream order.
  *                 NOT for the caller's stream -- the mode's contract is that the input block is complete in memory
  *                 when the call is made (stream order would put it behind FIR k-1, which is the very thing to avoid);
  *     FIR k       on the caller's stream, after cascade k: outputs are ordered on that stream as always, and so is
@@ -2333,7 +2338,7 @@ static int overlap_ready(avdsp_hip_prog *prog)
 {
     if (prog->s_bq) return 0;
     HIP_TRY(hipStreamCreateWithFlags(&prog->s_bq, hipStreamNonBlocking));
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < avdsp_hip_prog::kAhead; i++) {
         /* they order kernels of this device among themselves: no system-scope fence (tools/stream_handover_bench.hip: 8.1 instead of 10.6 us) */
         HIP_TRY(hipEventCreateWithFlags(&prog->ev_bq[i], hipEventDisableTiming | hipEventDisableSystemFence));
         HIP_TRY(hipEventCreateWithFlags(&prog->ev_fir[i], hipEventDisableTiming | hipEventDisableSystemFence));
@@ -2347,8 +2352,8 @@ int launch_all(avdsp_hip_prog *prog, Plan &pl, BlockIO io, int fir_impl, int biq
     const bool under = prog->overlap && pl.overlap_ok && biquad_impl && fir_impl;
     if (under) {
         if (overlap_ready(prog)) return -1;
-        const int slot = (int)(prog->blk & 1);
-        if (prog->ev_fir_set[slot]) HIP_TRY(hipStreamWaitEvent(prog->s_bq, prog->ev_fir[slot], 0));   /* FIR k-2 */
+        const int slot = (int)(prog->blk % avdsp_hip_prog::kAhead);
+        if (prog->ev_fir_set[slot]) HIP_TRY(hipStreamWaitEvent(prog->s_bq, prog->ev_fir[slot], 0));   /* FIR k-3 */
         if (prog->input_ready) HIP_TRY(hipStreamWaitEvent(prog->s_bq, prog->input_ready, 0));           /* (queued host blocks: the copy of this block) */
         for (size_t gi = 0; gi < pl.bq.size(); gi++) {        /* (the last group's kernel carries the event: the stream is in order) */
             auto &g = pl.bq[gi];
@@ -2432,7 +2437,7 @@ void avdsp_hip_prog_destroy(avdsp_hip_prog *p)
     }
     if (p->s_bq) (void)hipStreamDestroy(p->s_bq);
     if (p->ev_unpack) (void)hipEventDestroy(p->ev_unpack);
-    for (int i = 0; i < 2; i++) { if (p->ev_bq[i]) (void)hipEventDestroy(p->ev_bq[i]); if (p->ev_fir[i]) (void)hipEventDestroy(p->ev_fir[i]); }
+    for (int i = 0; i < avdsp_hip_prog::kAhead; i++) { if (p->ev_bq[i]) (void)hipEventDestroy(p->ev_bq[i]); if (p->ev_fir[i]) (void)hipEventDestroy(p->ev_fir[i]); }
     (void)hipFree(p->d_buf); (void)hipFree(p->d_in); (void)hipFree(p->d_out); (void)hipFree(p->d_tpdf); (void)hipFree(p->d_frame);
     (void)hipFree(p->d_tpdf_seq);
     delete p;
@@ -2520,7 +2525,7 @@ int avdsp_hip_prog_add_plan(avdsp_hip_prog *prog, const avdsp_plan_desc *d)
             }
         }
         /* + one more launch of frames: under "overlap" the cascade appends block k+1 while the FIR still reads block k's window */
-        pl.ring_R = pow2ceil(pl.max_taps + 2 * kFirChunk + 16 * pl.fir_gpc + 16 * (kNG + 4) + 64);
+        pl.ring_R = pow2ceil(pl.max_taps + avdsp_hip_prog::kAhead * kFirChunk + 16 * pl.fir_gpc + 16 * (kNG + 4) + 64);
         static_assert(kFirChunk == kFirPad, "one FIR launch covers exactly the frames the window image is laid out for");
         hipError_t e = hipMalloc((void **)&pl.d_ring, (size_t)d->nchains * pl.ring_R * sizeof(float));
         if (e != hipSuccess) { free_plan(pl); return set_err("hipMalloc(FIR rings, %d x %d): %s", d->nchains, pl.ring_R, hipGetErrorString(e)); }
@@ -3316,7 +3321,7 @@ int avdsp_hip_prog_set_option(avdsp_hip_prog *prog, int key, int value)
 {
     HIP_TRY(hipDeviceSynchronize());                    /* nothing in flight when the launch arrangement changes */
     switch (key) {
-    case AVDSP_OPT_OVERLAP:  prog->overlap = value != 0; prog->ev_fir_set[0] = prog->ev_fir_set[1] = false; return 0;
+    case AVDSP_OPT_OVERLAP:  prog->overlap = value != 0; for (bool &f : prog->ev_fir_set) f = false; return 0;
     case AVDSP_OPT_FIR_ROWS: if (value != 0 && value != 1 && value != 2 && value != 4) return set_err("fir_tile row tiles: 0 (auto), 1, 2 or 4");
                              prog->fir_rows = value; return 0;
     case AVDSP_OPT_PROFILE_STRIDE: if (value < 1) return set_err("profile_stride: every n-th launch, n >= 1"); prog->profile_stride = value; return 0;
