@@ -1005,6 +1005,268 @@ __global__ __launch_bounds__(kBlock) void biquad_row(const BiquadArgs a)
     BQ_STAMP(29);
 }
 
+/* biquad_row_i64: the same arrangement for the int64 model (dsp_biquadSTD.h:34-77).  A lane keeps {acc (with P * c0 of its next compute
+ * already added), P, x1, x2, y1 = hy, y2} as 32-bit words; a step is 5 v_mad_i64_i32, the hand-off dpp (straight into the register of
+ * the x2 that has just died), the saturation look (hi + 2^27 - 2 against 2^28 - 3, unsigned: one add, one compare, and a branch over
+ * the clamp that almost never runs), y = acc >> 28, the word that leaves (acc >> 28 behind SAT0DB, else acc's low word: one
+ * v_alignbit with a per-lane shift) and its broadcast: 11 vector + 2 scalar instructions (biquad_pipe<2>: ~20).  The accumulator lives
+ * in v[2:3] inside the asm statements (its halves are named there). */
+__global__ __launch_bounds__(kBlock) void biquad_row_i64(const BiquadArgs a)
+{
+    BQ_STAMP(0);
+    __shared__ __attribute__((aligned(16))) unsigned lin[4][2][4][16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, row = lane >> 4, rp = lane & 15;
+    const int blk = xcd_remap(blockIdx.x, a.per_xcd);
+    const int slot = blk * 16 + wv * 4 + row;
+    const BlockIO io_l = a.io;
+    const int B = io_l.nframes, L = a.nsec - 1;
+    const bool have_chain = slot < a.ngroup;
+    const RowRec rr = a.rows[have_chain ? slot : 0];
+    const LaneRec lr = a.lanes[(size_t)(have_chain ? slot : 0) * 16 + rp];
+    const int sec = rp - (15 - L);
+    const bool lane_on = have_chain && sec >= 0;
+    const int cid = rr.cid;
+    const int c_load_mode = rr.flags & 0xFF; const unsigned c_gain_bits = rr.gain_bits;
+    const unsigned sh = (rr.flags >> 8 & 1) ? 28u : 0u;          /* SAT0DB: the stored word is acc >> 28 (saturate64_031 of an accumulator the cascade has clamped already), else acc's low word */
+    const unsigned long long firstmask = 0x0001000100010001ull << (15 - L);
+
+    const char *in_bytes = reinterpret_cast<const char *>(io_l.in);
+    const unsigned in_col = (unsigned)(rr.in_io - io_l.in_base) * 4u, in_frame = (unsigned)io_l.in_stride * 4u;
+    const unsigned in_max = (unsigned)(B - 1) * in_frame + in_col, in_step = 16u * in_frame;
+    unsigned in_off = min((unsigned)rp * in_frame + in_col, in_max);
+    auto fetch_next = [&]() __attribute__((always_inline)) -> unsigned {
+        const unsigned v = *reinterpret_cast<const unsigned *>(in_bytes + in_off);
+        in_off = min(in_off + in_step, in_max);
+        return v;
+    };
+    unsigned r0 = fetch_next(), r1 = fetch_next(), r2 = fetch_next(), r3 = fetch_next();
+
+    int ci[5] = {0, 0, 0, 0, 0};
+    long long acc = 0;
+    unsigned P = 0, x1 = 0, x2 = 0, hy = 0, yp = 0;
+    if (lane_on) {
+        const int *st = a.buf + lr.state_word;
+        acc = (long long)(((unsigned long long)(unsigned)st[1] << 32) | (unsigned)st[0]);
+        for (int k = 0; k < 5; k++) ci[k] = a.buf[lr.coef_word + k];
+        x1 = (unsigned)st[2]; x2 = (unsigned)st[3]; hy = (unsigned)st[4]; yp = (unsigned)st[5];
+    }
+    unsigned *mylin = &lin[wv][0][row][0];
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    auto stage = [&](int buf, unsigned raw) __attribute__((always_inline)) { mylin[buf * 64 + rp] = hand_from_sample<2>(raw, c_load_mode, c_gain_bits).y; };
+    auto take = [&](int buf, unsigned (&x)[16]) __attribute__((always_inline)) {
+        const u4 *p = reinterpret_cast<const u4 *>(mylin + buf * 64);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const u4 v = p[q];
+            x[4 * q] = v[0]; x[4 * q + 1] = v[1]; x[4 * q + 2] = v[2]; x[4 * q + 3] = v[3];
+        }
+    };
+    unsigned xa[16], xb[16];
+    stage(0, r0);
+    take(0, xa);
+
+    const bool q1 = (rp & 1) != 0, q2 = (rp & 2) != 0;
+    auto pick = [&](unsigned d0, unsigned d1, unsigned d2, unsigned d3) __attribute__((always_inline)) -> unsigned {
+        const unsigned lo = q1 ? d1 : d0, hi = q1 ? d3 : d2;
+        return (q2 ? hi : lo) & (unsigned)io_l.store_mask;
+    };
+    auto flush = [&](int u0, unsigned w) __attribute__((always_inline)) {
+        const int n = u0 + rp - (1 + 2 * L);
+        if (have_chain && n >= 0 && n < B) {
+            const avdsp_chain oc = a.chains[cid];
+            emit_out(io_l, oc, n, w);
+        }
+    };
+    const bool lean = __ballot(have_chain && (rr.flags >> 16 & 0xFF) != 1) == 0;
+    char *obase = reinterpret_cast<char *>(io_l.out + (rr.out_io - io_l.out_base));
+    const unsigned oinc = 64u * (unsigned)io_l.out_stride;
+    unsigned ooff = 0;
+    auto store_lean = [&](unsigned w) __attribute__((always_inline)) {
+        if (have_chain) *reinterpret_cast<unsigned *>(obase + ooff) = w;
+        ooff += oinc;
+    };
+
+    const unsigned k_in_range = 0x0FFFFFFDu;          /* hi + (2^27 - 2), unsigned, above this: the accumulator left (-2^59 + 2^33, 2^59) -- checkbiquadsat, dsp_biquadSTD.h:25-32 */
+#define AVDSP_ROW_DPP " row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+#define AVDSP_ROW_BCAST(D, O, BM) "v_mov_b32_dpp %[" D "], %[" O "] row_newbcast:15 row_mask:0xf bank_mask:" BM "\n\t"
+    /* the clamp, for the lanes in SQ: hi >= 2^27 -> 2^59 - 1, hi <= 1 - 2^27 -> -2^59 */
+#define AVDSP_ROW_SAT(SQ, LBL) \
+        "v_add_u32 %[ta], 0x07fffffe, v3\n\t" \
+        "v_cmp_lt_u32 " SQ ", %[kr], %[ta]\n\t" \
+        "s_cmp_lg_u64 " SQ ", 0\n\t" \
+        "s_cbranch_scc1 .Lbqi_fix" LBL "_%=\n\t" \
+        ".Lbqi_ok" LBL "_%=:\n\t"
+    /* ... out of line, behind the statement's last instruction: the common path falls through its branch */
+#define AVDSP_ROW_FIX(SQ, LBL) \
+        ".Lbqi_fix" LBL "_%=:\n\t" \
+        "v_ashrrev_i32 %[ta], 31, v3\n\t" \
+        "v_xor_b32 %[tb], 0x07ffffff, %[ta]\n\t" \
+        "v_not_b32 %[ta], %[ta]\n\t" \
+        "v_cndmask_b32 v3, v3, %[tb], " SQ "\n\t" \
+        "v_cndmask_b32 v2, v2, %[ta], " SQ "\n\t" \
+        "s_branch .Lbqi_ok" LBL "_%=\n\t"
+#define AVDSP_ROWI_STEP(X1, X2, Y1, Y2, XK, O, W, D, BM, LBL) \
+        "v_mad_i64_i32 v[2:3], %[sj], %[" X1 "], %[c1], v[2:3]\n\t" \
+        "v_mad_i64_i32 v[2:3], %[sj], %[" X2 "], %[c2], v[2:3]\n\t" \
+        "v_cndmask_b32_dpp %[" X2 "], %[" Y1 "], %[" XK "], vcc" AVDSP_ROW_DPP \
+        "v_mad_i64_i32 v[2:3], %[sj], %[" Y1 "], %[c3], v[2:3]\n\t" \
+        "v_mad_i64_i32 v[2:3], %[sj], %[" Y2 "], %[c4], v[2:3]\n\t" \
+        "v_add_u32 %[ta], 0x07fffffe, v3\n\t" \
+        "v_max_u32 %[fl], %[fl], %[ta]\n\t" \
+        "v_alignbit_b32 %[" W "], v3, v2, %[sh]\n\t" \
+        "v_alignbit_b32 %[" O "], v3, v2, 28\n\t" \
+        "v_mad_i64_i32 v[2:3], %[sj], %[" X2 "], %[c0], v[2:3]\n\t" \
+        AVDSP_ROW_BCAST(D, W, BM)
+    /* four steps: (P, x1, x2) enter in (xa, xb, xc) and leave in (xc, xa, xb); (y1, y2) = the results of the last two steps */
+#define AVDSP_ROWI_BLOCK4(BM) \
+        asm volatile( \
+            "s_mov_b64 vcc, %[m0]\n\t" \
+            AVDSP_ROWI_STEP("xb", "xc", "hy", "yp", "x0", "o0", "w0", "d0", BM, "0") \
+            AVDSP_ROWI_STEP("xa", "xb", "o0", "hy", "x1", "o1", "w1", "d1", BM, "1") \
+            AVDSP_ROWI_STEP("xc", "xa", "o1", "o0", "x2", "o2", "w2", "d2", BM, "2") \
+            AVDSP_ROWI_STEP("xb", "xc", "o2", "o1", "x3", "o3", "w3", "d3", BM, "3") \
+            : "={v[2:3]}"(acc), [xa] "+v"(P), [xb] "+v"(x1), [xc] "+v"(x2), \
+              [o0] "=&v"(o0), [o1] "=&v"(o1), [o2] "=&v"(o2), [o3] "=&v"(o3), \
+              [w0] "=&v"(w0), [w1] "=&v"(w1), [w2] "=&v"(w2), [w3] "=&v"(w3), [ta] "=&v"(ta), [fl] "+v"(fl), \
+              [d0] "+v"(d0), [d1] "+v"(d1), [d2] "+v"(d2), [d3] "+v"(d3), [sj] "=&s"(sj) \
+            : "0"(acc), [hy] "v"(hy), [yp] "v"(yp), [c0] "v"(ci[0]), [c1] "v"(ci[1]), [c2] "v"(ci[2]), [c3] "v"(ci[3]), [c4] "v"(ci[4]), \
+              [x0] "v"(x[k]), [x1] "v"(x[k + 1]), [x2] "v"(x[k + 2]), [x3] "v"(x[k + 3]), [m0] "s"(firstmask), [sh] "v"(sh) \
+            : "vcc")
+    /* 16 steps, every lane busy, WITHOUT the clamp: every step only notes how far its accumulator's high word went (a running
+     * maximum of hi + 2^27 - 2, unsigned).  The caller looks at the note after the batch and, if an accumulator left the range,
+     * runs the batch again from the state it started with, through the masked steps, which clamp (saturating audio is rare). */
+    auto steady_steps = [&](const unsigned (&x)[16], unsigned &fl) __attribute__((always_inline)) -> unsigned {
+        unsigned d0, d1, d2, d3;
+        asm volatile("; d0..d3 start undefined" : "=v"(d0), "=v"(d1), "=v"(d2), "=v"(d3));
+#pragma unroll
+        for (int k = 0; k < 16; k += 4) {
+            unsigned o0, o1, o2, o3, w0, w1, w2, w3, ta;
+            unsigned long long sj;
+            if (k == 0) AVDSP_ROWI_BLOCK4("0x1"); else if (k == 4) AVDSP_ROWI_BLOCK4("0x2"); else if (k == 8) AVDSP_ROWI_BLOCK4("0x4"); else AVDSP_ROWI_BLOCK4("0x8");
+            { const unsigned t = P; P = x2; x2 = x1; x1 = t; }
+            hy = o3; yp = o2;
+        }
+        return pick(d0, d1, d2, d3);
+    };
+    /* one step of the fill or drain under EXEC masks (cm: the lanes that compute now, cn: those that compute in the next step) */
+#define AVDSP_ROWI_EDGE(D, BM) \
+        asm volatile( \
+            "s_mov_b64 %[sv], exec\n\t" \
+            "s_mov_b64 vcc, %[m0]\n\t" \
+            "v_cndmask_b32_dpp %[t], %[hy], %[xk], vcc" AVDSP_ROW_DPP \
+            "s_mov_b64 exec, %[cm]\n\t" \
+            "v_mad_i64_i32 v[2:3], %[sj], %[x1], %[c1], v[2:3]\n\t" \
+            "v_mad_i64_i32 v[2:3], %[sj], %[x2], %[c2], v[2:3]\n\t" \
+            "v_mad_i64_i32 v[2:3], %[sj], %[hy], %[c3], v[2:3]\n\t" \
+            "v_mad_i64_i32 v[2:3], %[sj], %[yp], %[c4], v[2:3]\n\t" \
+            AVDSP_ROW_SAT("%[sq]", "e") \
+            "v_mov_b32 %[yp], %[hy]\n\t" \
+            "v_alignbit_b32 %[hy], v3, v2, 28\n\t" \
+            "v_alignbit_b32 %[w], v3, v2, %[sh]\n\t" \
+            "v_mov_b32 %[x2], %[x1]\n\t" \
+            "v_mov_b32 %[x1], %[p]\n\t" \
+            "s_mov_b64 exec, %[cn]\n\t" \
+            "v_mov_b32 %[p], %[t]\n\t" \
+            "v_mad_i64_i32 v[2:3], %[sj], %[t], %[c0], v[2:3]\n\t" \
+            "s_mov_b64 exec, %[sv]\n\t" \
+            AVDSP_ROW_BCAST(D, "w", BM) \
+            "s_branch .Lbqi_end_%=\n\t" \
+            AVDSP_ROW_FIX("%[sq]", "e") \
+            ".Lbqi_end_%=:\n\t" \
+            : "={v[2:3]}"(acc), [p] "+v"(P), [x1] "+v"(x1), [x2] "+v"(x2), [hy] "+v"(hy), [yp] "+v"(yp), [w] "+v"(wlast), \
+              [t] "=&v"(t), [ta] "=&v"(ta), [tb] "=&v"(tb), [sv] "=&s"(sv), [sq] "=&s"(sq), [sj] "=&s"(sj), \
+              [d0] "+v"(d0), [d1] "+v"(d1), [d2] "+v"(d2), [d3] "+v"(d3) \
+            : "0"(acc), [c0] "v"(ci[0]), [c1] "v"(ci[1]), [c2] "v"(ci[2]), [c3] "v"(ci[3]), [c4] "v"(ci[4]), \
+              [xk] "v"(x[k]), [m0] "s"(firstmask), [cm] "s"(cm), [cn] "s"(cn), [kr] "s"(k_in_range), [sh] "v"(sh) \
+            : "vcc", "scc")
+    const unsigned ustart = lane_on ? (unsigned)(1 + 2 * sec) : 0x40000000u;
+    unsigned wlast = 0;
+    auto edge_steps = [&](int u0, const unsigned (&x)[16]) __attribute__((always_inline)) -> unsigned {
+        unsigned d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+        const unsigned ph = (unsigned)u0 - ustart;
+        unsigned long long cn = __ballot(ph < (unsigned)B);
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const unsigned long long cm = cn;
+            cn = __ballot(ph + (unsigned)(k + 1) < (unsigned)B);
+            unsigned t, ta, tb; unsigned long long sv, sq, sj;
+            if ((k & 3) == 0) { if (k == 0) AVDSP_ROWI_EDGE("d0", "0x1"); else if (k == 4) AVDSP_ROWI_EDGE("d0", "0x2"); else if (k == 8) AVDSP_ROWI_EDGE("d0", "0x4"); else AVDSP_ROWI_EDGE("d0", "0x8"); }
+            else if ((k & 3) == 1) { if (k == 1) AVDSP_ROWI_EDGE("d1", "0x1"); else if (k == 5) AVDSP_ROWI_EDGE("d1", "0x2"); else if (k == 9) AVDSP_ROWI_EDGE("d1", "0x4"); else AVDSP_ROWI_EDGE("d1", "0x8"); }
+            else if ((k & 3) == 2) { if (k == 2) AVDSP_ROWI_EDGE("d2", "0x1"); else if (k == 6) AVDSP_ROWI_EDGE("d2", "0x2"); else if (k == 10) AVDSP_ROWI_EDGE("d2", "0x4"); else AVDSP_ROWI_EDGE("d2", "0x8"); }
+            else { if (k == 3) AVDSP_ROWI_EDGE("d3", "0x1"); else if (k == 7) AVDSP_ROWI_EDGE("d3", "0x2"); else if (k == 11) AVDSP_ROWI_EDGE("d3", "0x4"); else AVDSP_ROWI_EDGE("d3", "0x8"); }
+        }
+        return pick(d0, d1, d2, d3);
+    };
+
+    auto steady_checked = [&](int u0, const unsigned (&x)[16]) __attribute__((always_inline)) -> unsigned {
+        const long long acc0 = acc; const unsigned P0 = P, x10 = x1, x20 = x2, hy0 = hy, yp0 = yp;
+        unsigned fl = 0;
+        unsigned w = steady_steps(x, fl);
+        if (__builtin_expect(__ballot(fl > k_in_range) != 0, 0)) {
+            acc = acc0; P = P0; x1 = x10; x2 = x20; hy = hy0; yp = yp0;
+            w = edge_steps(u0, x);
+        }
+        return w;
+    };
+    const int U = B + 2 * L + 1;
+    const int nb = (U + 15) / 16;
+    auto batch_canon = [&](int b) __attribute__((always_inline)) {
+        const int u0 = 16 * b;
+        stage((b + 1) & 1, r1);
+        const unsigned rn = fetch_next();
+        take((b + 1) & 1, xb);
+        unsigned w;
+        if (u0 >= 2 * L + 1 && u0 + 15 <= B - 1) w = steady_checked(u0, xa);
+        else w = edge_steps(u0, xa);
+        flush(u0, w);
+        r1 = r2; r2 = r3; r3 = rn;
+#pragma unroll
+        for (int k = 0; k < 16; k++) xa[k] = xb[k];
+    };
+    auto batch_named = [&](int b, const unsigned (&x)[16], unsigned (&xn)[16], unsigned &rslot, auto lean_c) __attribute__((always_inline)) {
+        if (b >= 12 && b < 36) BQ_STAMP(2 + b - 12);
+        stage((b + 1) & 1, rslot);
+        rslot = fetch_next();
+        take((b + 1) & 1, xn);
+        const unsigned w = steady_checked(16 * b, x);
+        if constexpr (decltype(lean_c)::value) store_lean(w); else flush(16 * b, w);
+    };
+    auto six = [&](int b, auto lean_c) __attribute__((always_inline)) {
+        batch_named(b, xa, xb, r1, lean_c);     batch_named(b + 1, xb, xa, r2, lean_c); batch_named(b + 2, xa, xb, r3, lean_c);
+        batch_named(b + 3, xb, xa, r1, lean_c); batch_named(b + 4, xa, xb, r2, lean_c); batch_named(b + 5, xb, xa, r3, lean_c);
+    };
+    const int first_steady = (2 * L + 1 + 15) / 16;
+    const int end_steady = B >= 16 ? (B - 16) / 16 + 1 : 0;
+    int b = 0;
+    BQ_STAMP(1);
+    for (; b < nb && b < first_steady; b++) batch_canon(b);
+    BQ_STAMP(26);
+    if (b + 6 <= end_steady) {
+        if (lean) {
+            const int n0 = 16 * b + rp - (1 + 2 * L);
+            ooff = (unsigned)n0 * (unsigned)io_l.out_stride * 4u;
+            for (; b + 6 <= end_steady; b += 6) six(b, std::true_type{});
+        } else
+            for (; b + 6 <= end_steady; b += 6) six(b, std::false_type{});
+    }
+    BQ_STAMP(27);
+    for (; b < nb; b++) batch_canon(b);
+    BQ_STAMP(28);
+#undef AVDSP_ROWI_EDGE
+#undef AVDSP_ROWI_BLOCK4
+#undef AVDSP_ROWI_STEP
+#undef AVDSP_ROW_SAT
+#undef AVDSP_ROW_FIX
+#undef AVDSP_ROW_BCAST
+#undef AVDSP_ROW_DPP
+    if (lane_on) {
+        int *st = a.buf + lr.state_word;
+        st[0] = (int)(unsigned)(unsigned long long)acc; st[1] = (int)(unsigned)((unsigned long long)acc >> 32);
+        st[2] = (int)x1; st[3] = (int)x2; st[4] = (int)hy; st[5] = (int)yp;
+    }
+    BQ_STAMP(29);
+}
+
 /* lane per chain, the reference's loop order: cross-check path, and cascades longer than 64 sections */
 template <int FMT>
 __global__ __launch_bounds__(64) void biquad_simple(const BiquadArgs a)
@@ -2178,10 +2440,15 @@ int launch_biquad(avdsp_hip_prog *prog, Plan &pl, const Plan::Group &g, const in
         scope.begin();
         hipLaunchKernelGGL(biquad_simple<FMT>, dim3((n + 63) / 64), dim3(64), 0, stream, a);
         if (stop) HIP_TRY(hipEventRecord(stop, stream));
-    } else if (biquad_impl == 1 && g.P == 16 && g.d_rows && (FMT == 6 || (FMT == 4 && g.all_fir))) {
-        /* one 16-lane row per chain, double accumulators: biquad_row (format 4 only where the cascade feeds a FIR -- a format-4
-         * STORE needs all of the accumulator, biquad_row hands on its float) */
-        if constexpr (FMT != 2) {
+    } else if (biquad_impl == 1 && g.P == 16 && g.d_rows && (FMT == 2 || FMT == 6 || (FMT == 4 && g.all_fir))) {
+        /* one 16-lane row per chain: biquad_row (format 4 only where the cascade feeds a FIR -- a format-4 STORE needs all of the
+         * accumulator, biquad_row hands on its float), biquad_row_i64 */
+        if constexpr (FMT == 2) {
+            const int nblk = (n + 15) / 16;
+            a.rows = g.d_rows; a.lanes = g.d_lanes;
+            a.per_xcd = (nblk + 7) / 8;
+            if (launch_timed(scope, (const void *)biquad_row_i64, dim3(a.per_xcd * 8), dim3(kBlock), 0, stream, a, stop)) return -1;
+        } else {
             const int nblk = (n + 15) / 16;
             a.rows = g.d_rows; a.lanes = g.d_lanes;
             a.per_xcd = (nblk + 7) / 8;
@@ -2497,7 +2764,7 @@ int avdsp_hip_prog_add_plan(avdsp_hip_prog *prog, const avdsp_plan_desc *d)
         for (int id : e.second) all_fir = all_fir && chains[id].fir_taps != 0;
         Plan::Group g{P, e.first, (int)e.second.size(), nullptr, all_fir, nullptr, nullptr};
         if (upload_vec(&g.d_ids, e.second)) { free_plan(pl); return -1; }
-        if (P == 16 && d->format != 2) {                 /* what biquad_row loads instead of walking group -> chain -> section tables */
+        if (P == 16) {                                   /* what biquad_row loads instead of walking group -> chain -> section tables */
             std::vector<RowRec> rows(e.second.size());
             std::vector<LaneRec> lanes(e.second.size() * 16, LaneRec{-1, -1});
             for (size_t i = 0; i < e.second.size(); i++) {

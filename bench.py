@@ -485,7 +485,7 @@ def main():
             per_launch = bq_raw * 1e-3
             nbytes = 8.0 * Cl * B + 48.0 * S * Cl + 20.0 * S * Cl   # samples in+out, state r+w, coefficients
             hbm_ach = nbytes / per_launch / 1e9
-            kname = "biquad_simple" if not args.biquad_impl else ("biquad_pipe" if args.biquad_impl == 2 or fmt == 2 else "biquad_row")
+            kname = "biquad_simple" if not args.biquad_impl else ("biquad_pipe" if args.biquad_impl == 2 else "biquad_row_i64" if fmt == 2 else "biquad_row")
             if fmt == 2:
                 ops, peak, unit = 5.0 * S * Cl * B, PEAK_F32_TFMAS / 4.0, "T MAD/s (v_mad_i64_i32; quarter of the FP32 FMA rate)"
             else:
