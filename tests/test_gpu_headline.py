@@ -334,3 +334,28 @@ def test_overlap_mode_is_bit_identical(fmt, C, S, T, fir_impl):
         r.set_option("overlap", 0)
         r.set_option("fir_impl", 1)
         r.release()
+
+
+def test_bench_verifies_every_rank_and_reports_the_gather_leg():
+    """bench.py as the driver launches it for N = 2 (torch.distributed.run, one process per rank; both ranks share this box's one
+    GPU, so the process group is gloo): before anything is timed every rank pushes the headline input through the same
+    dspRuntimeBlockDevice path and compares ITS columns with the reference's pins (a mismatch ends the run non-zero); the JSON
+    line says so, carries the per-rank step times, and -- on request -- the timed block-boundary collectives beside the metric."""
+    import json
+    import subprocess
+    import sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AVDSP_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+           "--settle", "0.05", "--workload", "cfg3", "--no-cpu-baseline", "--gather"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["ranks"] == 2 and len(line["rank_ms_per_step"]) == 2
+    assert line["verified"] and "cfg3_f6" in line["verified"] and "channels 0..2047" in line["verified"]
+    assert line["gather"]["all_gather_ms"] > 0 and line["gather"]["bytes_per_rank"] == 1024 * 2048 * 4
+    assert line["config"]["channels_per_gpu"] == 2048 and line["scaling"] == "strong"
