@@ -89,6 +89,9 @@ typedef struct avdsp_ctx {
     int             device_selected;
     int             last_levels, last_cores, last_pieces;  /* of the latest dspRuntimeBlockAll: dspRuntimeGetOption("levels" / "cores" / "pieces") */
     int             opt_strand_split, next_tpdf_role;
+    int             opt_strand_lanes;                      /* uniform strand runs of an interpreted core on lanes (strand_lower) */
+    const avdsp_strand_desc *next_strands;                 /* get_plan_range attaches this to the plan it makes */
+    int             last_strands;                          /* strands of the latest dspRuntimeBlockAll arrangement that run on lanes */
     int             shard_rank, shard_world;               /* dspRuntimeSetShard: this process's slice of every chain core */
     int             numfreq_at_init;                       /* dspChangeFormat's view of the rate count (see dspRuntimeInit) */
     int             opt_profile_stride;
@@ -99,7 +102,7 @@ typedef struct avdsp_ctx {
 } avdsp_ctx;
 
 /* no program loaded: options set now are the defaults every program starts from (and keeps following, see dspRuntimeSetOption) */
-static avdsp_ctx g_template = { .opt_fir_impl = 1, .opt_biquad_impl = 1, .opt_device = -1, .opt_interp_impl = 1, .opt_strand_split = 1, .shard_world = 1,
+static avdsp_ctx g_template = { .opt_fir_impl = 1, .opt_biquad_impl = 1, .opt_device = -1, .opt_interp_impl = 1, .opt_strand_split = 1, .opt_strand_lanes = 1, .shard_world = 1,
                                 .mantissa = DSP_MANT, .device_ordinal = -1 };
 #define MAX_PROGRAMS 64
 static avdsp_ctx *g_ctx[MAX_PROGRAMS];
@@ -235,6 +238,7 @@ static int set_option_here(const char *key, int value)
     if (!strcmp(key, "generic"))     { G.opt_generic = value; return replan(); }
     if (!strcmp(key, "interp_impl")) { G.opt_interp_impl = value; return replan(); }
     if (!strcmp(key, "strand_split")) { G.opt_strand_split = value; return replan(); }
+    if (!strcmp(key, "strand_lanes")) { G.opt_strand_lanes = value; return replan(); }
     if (!strcmp(key, "overlap") || !strcmp(key, "fir_rows") || !strcmp(key, "host_split")) {
         int *slot = key[0] == 'o' ? &G.opt_overlap : key[0] == 'f' ? &G.opt_fir_rows : &G.opt_host_split;
         const int dev_key = key[0] == 'o' ? AVDSP_OPT_OVERLAP : key[0] == 'f' ? AVDSP_OPT_FIR_ROWS : AVDSP_OPT_HOST_SPLIT;
@@ -290,6 +294,8 @@ int dspRuntimeGetOption(const char *key)
     if (!strcmp(key, "cores"))       return G.last_cores;
     if (!strcmp(key, "pieces"))      return G.last_pieces;
     if (!strcmp(key, "strand_split")) return G.opt_strand_split;
+    if (!strcmp(key, "strand_lanes")) return G.opt_strand_lanes;
+    if (!strcmp(key, "strands"))     return G.last_strands;
     if (!strcmp(key, "overlap"))     return G.opt_overlap;
     if (!strcmp(key, "fir_rows"))    return G.opt_fir_rows;
     if (!strcmp(key, "host_split"))  return G.opt_host_split;
@@ -411,7 +417,7 @@ int dspRuntimeInit(opcode_t *codePtr, int maxSize, const int fs, int random, int
         if (!c) return fail(-9, "out of memory");
         const avdsp_ctx *o = &g_template;
         c->opt_fir_impl = o->opt_fir_impl; c->opt_biquad_impl = o->opt_biquad_impl; c->opt_device = o->opt_device; c->opt_profile = o->opt_profile;
-        c->opt_generic = o->opt_generic; c->opt_interp_impl = o->opt_interp_impl; c->opt_strand_split = o->opt_strand_split;
+        c->opt_generic = o->opt_generic; c->opt_interp_impl = o->opt_interp_impl; c->opt_strand_split = o->opt_strand_split; c->opt_strand_lanes = o->opt_strand_lanes;
         c->opt_profile_stride = o->opt_profile_stride; c->opt_overlap = o->opt_overlap; c->opt_fir_rows = o->opt_fir_rows; c->opt_host_split = o->opt_host_split; c->opt_host_pin = o->opt_host_pin;
         c->shard_rank = o->shard_rank; c->shard_world = o->shard_world;
         c->mantissa = DSP_MANT; c->device_ordinal = -1;
@@ -975,6 +981,7 @@ static int scan_generic(int format, opcode_t *core, int end_word, avdsp_generic_
     d->biquad_freq_skip = dspBiquadFreqSkip; d->biquad_freq_offset = G.biquad_offset;
     d->delay_line_factor = (unsigned)(4294.967296 * (double)dspConvertFrequencyFromIndex(G.fs_index));   /* dsp_runtime.c:81-90 */
 
+    int nreal = 0;                               /* opcodes that do something */
     for (;;) {
         const int op = p->op.opcode;
         const unsigned skip = p->op.skip;
@@ -985,6 +992,7 @@ static int scan_generic(int format, opcode_t *core, int end_word, avdsp_generic_
         if ((long long)at + skip > S.prog_words) { free(smap); return fail(-8, "word %d: opcode longer than the program", at); }
         S.at = at; S.skip = skip;
         int rc = 0;
+        if (op != DSP_NOP && op != DSP_PARAM && op != DSP_PARAM_NUM && op != DSP_SERIAL) nreal++;
         switch (op) {
         case DSP_NOP: case DSP_PARAM: case DSP_PARAM_NUM: case DSP_SERIAL:
         case DSP_SWAPXY: case DSP_COPYXY: case DSP_COPYYX: case DSP_CLRXY:
@@ -1030,6 +1038,7 @@ static int scan_generic(int format, opcode_t *core, int end_word, avdsp_generic_
                 if (S.w.tpdf_calc_seen || S.w.tpdf_user_seen) S.w.ok = 0;
                 S.w.tpdf_calc_seen = 1;
                 ws_mem_write(&S, S.prog_words + a[1]);
+                d->dither_arg = a[0]; d->dither_result_word = S.prog_words + a[1];
             }
             break;
         case DSP_TPDF:
@@ -1129,6 +1138,7 @@ static int scan_generic(int format, opcode_t *core, int end_word, avdsp_generic_
         p += skip;
     }
     free(smap);
+    d->dither_only = nreal == 1 && S.w.tpdf_calc_seen;
     if (d->io_span == 0) d->io_span = 1;
     if (d->io_span > WAVE_IO_LIMIT) S.w.ok = S.w.complete = 0;
     if (S.w.ok) ws_finish(&S);
@@ -1260,8 +1270,13 @@ static core_plan *get_plan_range(int format, opcode_t *core, int end_word)
             if (L.chains[i].fir_taps > cp->max_taps) cp->max_taps = L.chains[i].fir_taps;
         }
         lowered_free(&L);
-    } else
+    } else {
         cp->plan_id = avdsp_hip_prog_add_generic(G.dev, &gd);
+        if (cp->plan_id >= 0 && G.next_strands && end_word && avdsp_hip_plan_add_strands(G.dev, cp->plan_id, G.next_strands)) {
+            fail(-10, "%s", avdsp_hip_last_error());
+            return 0;
+        }
+    }
     if (cp->plan_id < 0) { fail(-10, "%s", avdsp_hip_last_error()); return 0; }
     G.nplans++;
     return cp;
@@ -1574,6 +1589,266 @@ static int split_core(opcode_t *core, int *starts)
     return ng;
 }
 
+/* ---- strand runs on lanes (include/avdsp_hip.h, strand plans) ----
+ * A stretch [start, end) of an interpreted core is offered as a strand plan when it is N >= 2 repetitions of one opcode sequence
+ * -- every repetition opening at a legal cut (split_core's rule) with LOAD / LOAD_GAIN / LOAD_MEM, made of opcodes the strand
+ * kernel has, equal in every word that steers control (opcode, length, sections per bank) -- and the repetitions are strangers:
+ * no IO stored twice or stored by one and loaded by another (or by itself earlier in the frame), state areas disjoint, no memory
+ * word written by one that any of them reads.  scan_generic has bounds-checked every offset of the stretch before this runs.  */
+typedef struct { long long lo, hi; int kind; } s_interval;           /* kind 0: state (exclusive), 1: word read, 2: word written */
+typedef struct { avdsp_strand_op *ops; int32_t *args; avdsp_strand_desc d;
+                 s_interval *iv; int niv; int *stored, nst, *loaded, nld; } strand_plan;        /* (what the run touches: against a prefix piece) */
+static void strand_free(strand_plan *S) { free(S->ops); free(S->args); free(S->iv); free(S->stored); free(S->loaded); memset(S, 0, sizeof *S); }
+static int cmp_interval(const void *a, const void *b) { const s_interval *x = a, *y = b; return (x->lo > y->lo) - (x->lo < y->lo); }
+
+static int sop_of(int op)
+{
+    switch (op) {
+    case DSP_LOAD: return AVDSP_SOP_LOAD;               case DSP_LOAD_GAIN: return AVDSP_SOP_LOAD_GAIN;
+    case DSP_GAIN: return AVDSP_SOP_GAIN;               case DSP_COPYXY: return AVDSP_SOP_COPYXY;
+    case DSP_SWAPXY: return AVDSP_SOP_SWAPXY;           case DSP_COPYYX: return AVDSP_SOP_COPYYX;
+    case DSP_ADDXY: return AVDSP_SOP_ADDXY;             case DSP_ADDYX: return AVDSP_SOP_ADDYX;
+    case DSP_SUBXY: return AVDSP_SOP_SUBXY;             case DSP_SUBYX: return AVDSP_SOP_SUBYX;
+    case DSP_NEGX: return AVDSP_SOP_NEGX;               case DSP_SHIFT: return AVDSP_SOP_SHIFT;
+    case DSP_SAT0DB: return AVDSP_SOP_SAT0DB;           case DSP_SAT0DB_TPDF: return AVDSP_SOP_SAT0DB_TPDF;
+    case DSP_SAT0DB_GAIN: return AVDSP_SOP_SAT0DB_GAIN; case DSP_SAT0DB_TPDF_GAIN: return AVDSP_SOP_SAT0DB_TPDF_GAIN;
+    case DSP_STORE: return AVDSP_SOP_STORE;             case DSP_LOAD_MEM: return AVDSP_SOP_LOAD_MEM;
+    case DSP_STORE_MEM: return AVDSP_SOP_STORE_MEM;     case DSP_DELAY: return AVDSP_SOP_DELAY;
+    case DSP_DELAY_DP: return AVDSP_SOP_DELAY_DP;       case DSP_BIQUADS: return AVDSP_SOP_BIQUADS;
+    }
+    return 0;
+}
+
+/* 0 = the stretch is a strand run (S filled), -8 = it is not (no error text: the caller falls back), -9 = out of memory */
+static int strand_lower(int format, int start, int end, strand_plan *S)
+{
+    memset(S, 0, sizeof *S);
+    const int prog_words = dspHeaderPtr->totalLength, aw = (format == 3 || format == 5) ? 1 : 2;
+    enum { MAXOPS = 1 << 20 };
+    int nops_all = 0, cap = 4096;
+    int *at = (int *)malloc((size_t)cap * sizeof(int));
+    if (!at) return -9;
+    for (int w = start; w < end;) {
+        const opcode_t *p = G.code + w;
+        const int op = p->op.opcode; const unsigned skip = p->op.skip;
+        if (skip == 0 || op == DSP_CORE || op == DSP_END_OF_CODE) break;
+        if (op != DSP_NOP && op != DSP_PARAM && op != DSP_PARAM_NUM && op != DSP_SERIAL) {
+            if (!sop_of(op) || nops_all == MAXOPS) { free(at); return -8; }
+            if (nops_all == cap) { cap *= 2; int *q = (int *)realloc(at, (size_t)cap * sizeof(int)); if (!q) { free(at); return -9; } at = q; }
+            at[nops_all++] = w;
+        }
+        w += (int)skip;
+    }
+    if (nops_all < 4) { free(at); return -8; }
+#define OPC(i) (G.code[at[i]].op.opcode)
+    /* the first repetition: from the first opcode to the next legal cut whose opcode equals the first one's; then the stretch must
+     * be whole repetitions of that length */
+    const int op0 = OPC(0);
+    if (op0 != DSP_LOAD && op0 != DSP_LOAD_GAIN && op0 != DSP_LOAD_MEM) { free(at); return -8; }
+    int len = 0;
+    for (int i = 1; i < nops_all && !len; i++) {
+        if (OPC(i) != op0) continue;
+        int legal = 1;
+        for (int k = i + 1; k < nops_all; k++) {
+            if (reads_y(OPC(k))) { legal = 0; break; }
+            if (sets_y_from_x(OPC(k))) break;
+        }
+        if (!legal) continue;
+        /* a candidate period: the stretch must repeat with it */
+        if (nops_all % i) continue;
+        int same = 1;
+        for (int k = i; k < nops_all && same; k++)
+            same = OPC(k) == OPC(k - i) && G.code[at[k]].op.skip == G.code[at[k - i]].op.skip;
+        if (same) len = i;
+    }
+    if (!len) { free(at); return -8; }
+    const int N = nops_all / len;
+    if (N < 2) { free(at); return -8; }
+    /* every repetition opens at a legal cut */
+    for (int r = 1; r < N; r++) {
+        const int i = r * len;
+        for (int k = i + 1; k < nops_all; k++) {
+            if (reads_y(OPC(k))) { free(at); return -8; }
+            if (sets_y_from_x(OPC(k))) break;
+        }
+    }
+    S->ops = (avdsp_strand_op *)calloc((size_t)len, sizeof *S->ops);
+    if (!S->ops) { free(at); return -9; }
+    int nargs = 0;
+    for (int j = 0; j < len; j++) {
+        avdsp_strand_op *o = &S->ops[j];
+        o->op = sop_of(OPC(j));
+        switch (o->op) {
+        case AVDSP_SOP_LOAD: case AVDSP_SOP_GAIN: case AVDSP_SOP_SHIFT: case AVDSP_SOP_SAT0DB_GAIN: case AVDSP_SOP_SAT0DB_TPDF_GAIN:
+        case AVDSP_SOP_STORE: case AVDSP_SOP_LOAD_MEM: case AVDSP_SOP_STORE_MEM:
+            o->a0 = nargs++; break;
+        case AVDSP_SOP_LOAD_GAIN: case AVDSP_SOP_BIQUADS:
+            o->a0 = nargs++; o->a1 = nargs++; break;
+        case AVDSP_SOP_DELAY: case AVDSP_SOP_DELAY_DP:
+            o->a0 = nargs++; o->a1 = nargs++; o->a2 = nargs++; break;
+        default: break;
+        }
+    }
+    if (nargs == 0) nargs = 1;
+    S->args = (int32_t *)calloc((size_t)N * nargs, sizeof(int32_t));
+    s_interval *iv = (s_interval *)malloc(((size_t)N * len * 2 + 4) * sizeof *iv);
+    int *stored = (int *)malloc(((size_t)N * len + 1) * sizeof(int)), *loaded = (int *)malloc(((size_t)N * len + 1) * sizeof(int));
+    int rc = 0, niv = 0, nst = 0, nld = 0, io_max = 0;
+    if (!S->args || !iv || !stored || !loaded) rc = -9;
+    for (int r = 0; r < N && !rc; r++) {
+        int32_t *row = S->args + (size_t)r * nargs;
+        const int st0 = nst;                                 /* this strand's own stores so far */
+        for (int j = 0; j < len && !rc; j++) {
+            const opcode_t *p = G.code + at[r * len + j];
+            const int *w = (const int *)p + 1;
+            const int here = at[r * len + j];
+            const avdsp_strand_op *o = &S->ops[j];
+#define SL_WORD(off, n, kind_) do { const long long lo_ = (long long)here + (off); if (lo_ < 12 || lo_ + (n) > prog_words) rc = -8; \
+                                    else { iv[niv].lo = lo_; iv[niv].hi = lo_ + (n); iv[niv].kind = (kind_); niv++; } } while (0)
+            switch (o->op) {
+            case AVDSP_SOP_LOAD: case AVDSP_SOP_LOAD_GAIN:
+                if (w[0] < 0 || w[0] >= GENERIC_IO_LIMIT) { rc = -8; break; }
+                for (int k = st0; k < nst; k++) if (stored[k] == w[0]) rc = -8;      /* the frame's own value: a slot, not the block */
+                row[o->a0] = w[0]; loaded[nld++] = w[0];
+                if (o->op == AVDSP_SOP_LOAD_GAIN) { SL_WORD(w[1], 1, 1); row[o->a1] = here + w[1]; }
+                break;
+            case AVDSP_SOP_GAIN: case AVDSP_SOP_SAT0DB_GAIN: case AVDSP_SOP_SAT0DB_TPDF_GAIN:
+                SL_WORD(w[0], 1, 1); row[o->a0] = here + w[0];
+                break;
+            case AVDSP_SOP_SHIFT: row[o->a0] = w[0]; break;
+            case AVDSP_SOP_STORE:
+                if (w[0] < 0 || w[0] >= GENERIC_IO_LIMIT) { rc = -8; break; }
+                row[o->a0] = w[0]; stored[nst++] = w[0];
+                if (w[0] > io_max) io_max = w[0];
+                break;
+            case AVDSP_SOP_LOAD_MEM:  SL_WORD(w[0], aw, 1); row[o->a0] = here + w[0]; break;
+            case AVDSP_SOP_STORE_MEM: SL_WORD(w[0], aw, 2); row[o->a0] = here + w[0]; break;
+            case AVDSP_SOP_DELAY: case AVDSP_SOP_DELAY_DP: {
+                /* :769-790: with a parameter the first word is the line's size in samples, without it microseconds (scan_generic) */
+                const unsigned dfac = (unsigned)(4294.967296 * (double)dspConvertFrequencyFromIndex(G.fs_index));
+                const long long nline = w[2] ? (long long)w[0] : (long long)(((unsigned long long)(unsigned)w[0] * dfac) >> 32);
+                const long long words = 1 + nline * (o->op == AVDSP_SOP_DELAY_DP ? aw : 1);
+                if (w[0] < 0) { rc = -8; break; }
+                if (w[1] < 0 || w[1] + words > dspHeaderPtr->dataSize) { rc = -8; break; }
+                row[o->a0] = w[0]; row[o->a1] = prog_words + w[1];
+                row[o->a2] = 0;
+                if (w[2]) { SL_WORD(w[2], 1, 1); row[o->a2] = here + w[2]; }
+                iv[niv].lo = (long long)prog_words + w[1]; iv[niv].hi = iv[niv].lo + words; iv[niv].kind = 0; niv++;
+                break; }
+            case AVDSP_SOP_BIQUADS: {
+                const long long bw = (long long)here + w[1];
+                if (bw < 12 || bw + 2 > prog_words) { rc = -8; break; }
+                const int num = (short)G.code[bw].i32;
+                if (num < 1 || num > 64) { rc = -8; break; }
+                if (r == 0) S->ops[j].imm = num; else if (S->ops[j].imm != num) { rc = -8; break; }
+                if (w[0] < 0 || (long long)w[0] + 6ll * num > dspHeaderPtr->dataSize) { rc = -8; break; }
+                SL_WORD(w[1], G.biquad_offset + (num - 1) * dspBiquadFreqSkip + 5, 1);
+                row[o->a0] = prog_words + w[0]; row[o->a1] = (int)bw;
+                iv[niv].lo = (long long)prog_words + w[0]; iv[niv].hi = iv[niv].lo + 6ll * num; iv[niv].kind = 0; niv++;
+                break; }
+            default: break;
+            }
+#undef SL_WORD
+        }
+    }
+#undef OPC
+    if (!rc) {
+        /* no IO stored twice; none stored by one strand and loaded by any */
+        qsort(stored, (size_t)nst, sizeof(int), cmp_int);
+        for (int i = 1; i < nst && !rc; i++) if (stored[i] == stored[i - 1]) rc = -8;
+        for (int i = 0; i < nld && !rc; i++) if (bsearch(&loaded[i], stored, (size_t)nst, sizeof(int), cmp_int)) rc = -8;
+        /* state areas disjoint from everything; a written word disjoint from every word read or written */
+        qsort(iv, (size_t)niv, sizeof *iv, cmp_interval);
+        long long wr_reach = -1, st_reach = -1, rd_reach = -1;      /* furthest end seen per kind (sorted by start) */
+        for (int i = 0; i < niv && !rc; i++) {
+            const s_interval *v = &iv[i];
+            if (v->kind == 0) { if (v->lo < st_reach || v->lo < wr_reach || v->lo < rd_reach) rc = -8; if (v->hi > st_reach) st_reach = v->hi; }
+            else if (v->kind == 2) { if (v->lo < st_reach || v->lo < wr_reach || v->lo < rd_reach) rc = -8; if (v->hi > wr_reach) wr_reach = v->hi; }
+            else { if (v->lo < st_reach || v->lo < wr_reach) rc = -8; if (v->hi > rd_reach) rd_reach = v->hi; }
+        }
+    }
+    free(at);
+    S->iv = iv; S->niv = niv; S->stored = stored; S->nst = nst; S->loaded = loaded; S->nld = nld;
+    if (rc) { strand_free(S); return rc; }
+    int nres = 0;
+    for (int j = 0; j < len; j++) { S->ops[j].rcol = nres; nres += avdsp_strand_rcols(S->ops[j].op, S->ops[j].imm, aw); }
+    if (nres > 224 || len > 512) { strand_free(S); return -8; }   /* the kernel's table: 64 lanes x nres words of LDS (56 KB); its operation list: 512 */
+    S->d.nops = len; S->d.ops = S->ops; S->d.nstrands = N; S->d.nargs = nargs; S->d.args = S->args; S->d.stored_io_max = io_max; S->d.nres = nres;
+    return 0;
+}
+
+/* does the piece in front of a run (its deps from scan_generic) meet the run?  cores_meet_ex on what strand_lower collected (a run
+ * of thousands of strands does not fit a core_deps) */
+static int prefix_meets_run(const core_deps *d0, const strand_plan *S)
+{
+    if (!d0->complete) return 1;
+    for (int i = 0; i < S->nst; i++) {
+        const int io = S->stored[i];
+        if (io < 256 && ((d0->written_io[io >> 5] | d0->early_io[io >> 5]) >> (io & 31) & 1u)) return 1;
+    }
+    for (int i = 0; i < S->nld; i++) {
+        const int io = S->loaded[i];
+        if (io < 256 && (d0->written_io[io >> 5] >> (io & 31) & 1u)) return 1;
+    }
+    for (int i = 0; i < S->niv; i++) {
+        const s_interval *v = &S->iv[i];
+        for (int j = 0; j < d0->nwr; j++) if (d0->wr_word[j] + 2 > v->lo && d0->wr_word[j] < v->hi) return 1;
+        for (int j = 0; j < d0->nranges; j++) if (d0->range[j][1] > v->lo && d0->range[j][0] < v->hi) return 1;
+        if (v->kind != 1) for (int j = 0; j < d0->nrd; j++) if (d0->rd_word[j] + 2 > v->lo && d0->rd_word[j] < v->hi) return 1;
+        if (v->kind == 2) for (int j = 0; j < d0->nparams; j++) if (d0->param[j][1] > v->lo && d0->param[j][0] < v->hi) return 1;
+    }
+    return 0;
+}
+
+/* the first LOAD / LOAD_GAIN / LOAD_MEM of the core from which everything up to the core's end is one strand run; 0 = found */
+static int find_strand_run(int format, opcode_t *begin, int *run_word, int *end_word, strand_plan *S)
+{
+    const int total = dspHeaderPtr->totalLength;
+    int core_end = -1, tried = 0;
+    for (opcode_t *p = begin;;) {
+        const int w = (int)(p - G.code);
+        if (w < 0 || w >= total) return -8;
+        if (p->op.skip == 0 || p->op.opcode == DSP_CORE || p->op.opcode == DSP_END_OF_CODE) { core_end = w; break; }
+        if (p->op.opcode == DSP_TPDF) return -8;           /* switches the dither width for the rest of the frame: the core stays whole */
+        p += p->op.skip;
+    }
+    for (opcode_t *p = begin; tried < 12;) {
+        const int w = (int)(p - G.code);
+        if (w >= core_end) break;
+        const int o = p->op.opcode;
+        if (o == DSP_LOAD || o == DSP_LOAD_GAIN || o == DSP_LOAD_MEM) {
+            tried++;
+            const int rc = strand_lower(format, w, core_end, S);
+            if (rc == -9) return -9;
+            if (rc == 0) { *run_word = w; *end_word = core_end; return 0; }
+        }
+        p += p->op.skip;
+    }
+    return -8;
+}
+
+/* Host-only: would the core's tail run as a strand plan?  strands = 0: no.  (prefix_words: opcode words in front of the run that
+ * stay with the interpreter; ops: micro-operations per strand) */
+int dspRuntimeStrandInfo(int format, opcode_t *core, int *strands, int *ops, int *prefix_words)
+{
+    (void)ctx_of(core);
+    if (!dspHeaderPtr || !G.code) return fail(-1, "no program loaded");
+    if (!G.have_rate) return fail(-1, "dspRuntimeReset(fs) has not selected a sample rate yet");
+    if (format < 2 || format > 6) return fail(-1, "DSP_FORMAT %d is not one of 2..6", format);
+    if (core < G.code || core >= G.code + dspHeaderPtr->totalLength) return fail(-1, "core pointer outside the loaded program");
+    if (ensure_encoding(format)) return g_err_code;
+    opcode_t *begin = dspFindCoreBegin(core);
+    strand_plan S;
+    int w = 0, e = 0;
+    const int rc = find_strand_run(format, begin, &w, &e, &S);
+    if (rc == -9) return fail(-9, "out of memory");
+    if (strands) *strands = rc ? 0 : S.d.nstrands;
+    if (ops) *ops = rc ? 0 : S.d.nops;
+    if (prefix_words) *prefix_words = rc ? 0 : w - (int)(begin - G.code);
+    if (!rc) strand_free(&S);
+    return 0;
+}
+
 /* one core -> its pieces (or itself), appended to cp[] */
 static int expand_core(int format, opcode_t *c, core_plan **cp, int *pn)
 {
@@ -1583,6 +1858,45 @@ static int expand_core(int format, opcode_t *c, core_plan **cp, int *pn)
     static core_deps pd[MAX_GROUPS];
     core_plan *whole = get_plan(format, begin);           /* also tells whether the core is a chain core */
     if (!whole) return g_err_code;
+    /* [prefix] + a run of identical strands up to the core's end: the run goes to lanes (strand_lower), the prefix -- usually the
+     * TPDF_CALC -- stays a piece of the interpreter's, one level ahead */
+    if (G.opt_strand_split && G.opt_strand_lanes && whole->total_chains == 0) {
+        strand_plan S;
+        int w = 0, core_end = 0;
+        const int rc = find_strand_run(format, begin, &w, &core_end, &S);
+        if (rc == -9) return fail(-9, "out of memory");
+        if (rc == 0) {
+            avdsp_generic_desc gd;
+            static core_deps d0, d1;
+            int ok = !scan_generic(format, G.code + w, core_end, &gd, &d1);
+            const int has_prefix = G.code + w != begin;
+            if (ok && has_prefix) {
+                ok = !scan_generic(format, begin, w, &gd, &d0);
+                if (ok && prefix_meets_run(&d0, &S)) ok = 0;
+            }
+            if (ok && n + 2 <= MAX_CORE_PLANS && G.nplans + 2 <= MAX_CORE_PLANS) {
+                const int calc_first = has_prefix && d0.tpdf_calc;
+                if (has_prefix) {
+                    G.next_tpdf_role = calc_first ? 1 : 0;
+                    cp[n] = get_plan_range(format, begin, w);
+                    G.next_tpdf_role = 0;
+                    if (!cp[n]) { strand_free(&S); return g_err_code; }
+                    n++;
+                }
+                G.next_tpdf_role = calc_first ? 2 : 0;
+                G.next_strands = &S.d;
+                cp[n] = get_plan_range(format, G.code + w, core_end);
+                G.next_strands = 0; G.next_tpdf_role = 0;
+                strand_free(&S);
+                if (!cp[n]) return g_err_code;
+                n++;
+                *pn = n;
+                return 0;
+            }
+            strand_free(&S);
+        }
+        g_err[0] = 0;
+    }
     if (G.opt_strand_split && whole->total_chains == 0) ng = split_core(c, starts);
     if (ng > 1 && (G.nplans + ng + 8 > MAX_CORE_PLANS || n + ng + 8 > MAX_CORE_PLANS)) ng = 1;   /* plan table nearly full: whole */
     if (ng > 1) {
@@ -1688,6 +2002,8 @@ static int block_all(int format, int *rundata, const void *in, int in_stride, in
         A->nlevels = nlevels; A->n = n; A->ncores = ncores; A->format = format; A->only = only; A->valid = 1;
     }
     G.last_levels = A->nlevels; G.last_cores = A->ncores; G.last_pieces = A->n;
+    G.last_strands = 0;
+    for (int i = 0; i < A->n; i++) G.last_strands += avdsp_hip_plan_strands(G.dev, A->plans[i]);
     if (A->n == 0) return 0;                                     /* every core's shard is empty on this rank */
     const int *plans = A->plans, *size = A->size;
     const int nlevels = A->nlevels;

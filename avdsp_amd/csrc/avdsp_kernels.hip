@@ -37,6 +37,7 @@
 #include <cstdio>
 #include <cstring>
 #include <type_traits>
+#include <utility>
 #include <vector>
 #include <algorithm>
 
@@ -2181,6 +2182,7 @@ __global__ __launch_bounds__(kBlock) void tag_column(const TagArgs a)
     if (have_last) *a.prev = last;
 }
 
+static constexpr int kStrandMaxOps = 512;         /* operations per strand (strand_lanes keeps the list in LDS) */
 #include "avdsp_interp.inc"
 
 
@@ -2233,6 +2235,8 @@ struct Plan {
     bool generic = false;             /* general interpreter instead of chain kernels */
     GenericArgs ga{};                 /* launch template of the generic path (io filled per block) */
     int io_span = 0;                  /* highest IO number the core touches + 1 */
+    bool dither_only = false;         /* a DSP_TPDF_CALC and nothing else: tpdf_walk */
+    int dither_arg = 0, dither_word = 0;
     size_t ga_lds = 0; bool ga_staged = false;
     int format = 0, nchains = 0, store_mask = -1;
     avdsp_chain *d_chains = nullptr;
@@ -2253,6 +2257,9 @@ struct Plan {
     int *d_own = nullptr;                                /* owned mirror ranges (pairs), generic plans */
     double *d_taps64 = nullptr; int pitch64 = 0;         /* fir_tile: the taps as doubles, [chain][pitch64] */
     bool lane_mode = false;                              /* formats 3 and 5: chain_lane, one lane per chain, state in the mirror */
+    /* strand plan attached to a generic plan (include/avdsp_hip.h): the stretch as micro-operations, one argument row per strand */
+    avdsp_strand_op *d_sops = nullptr; int *d_sargs = nullptr; int s_nops = 0, s_nargs = 0, s_nstrands = 0, s_nres = 0;
+    std::vector<int> s_loaded, s_stored;                 /* the IOs the strands load / store: per call against the windows */
     bool stores_whole_window = false;                    /* every IO of [io_out_min, io_out_max] is stored by some chain */
     bool overlap_ok = false;                             /* every cascade of the plan feeds a FIR: its launches may run under the previous block's FIR */
 };
@@ -2331,6 +2338,7 @@ void free_plan(Plan &p)
 {
     (void)hipFree(p.d_chains); (void)hipFree(p.d_sec_coef); (void)hipFree(p.d_sec_state);
     for (auto &g : p.bq) { (void)hipFree(g.d_ids); (void)hipFree(g.d_rows); (void)hipFree(g.d_lanes); }
+    (void)hipFree(p.d_sops); (void)hipFree(p.d_sargs);
     (void)hipFree(p.d_fir_ids); (void)hipFree(p.d_pass_ids); (void)hipFree(p.d_ring); (void)hipFree(p.d_ring64); (void)hipFree(p.d_own); (void)hipFree(p.d_taps64);
 }
 
@@ -2893,6 +2901,8 @@ int avdsp_hip_prog_add_generic(avdsp_hip_prog *prog, const avdsp_generic_desc *d
     /* what the core owns (written back after a launch); unknown = everything, and the core then runs alone */
     a.nown = -1; a.own = nullptr; a.tpdf_owner = d->tpdf_calc != 0;
     a.tpdf_role = d->tpdf_role; a.tpdf_seq = nullptr;
+    pl.dither_only = d->dither_only != 0 && d->dither_result_word >= d->prog_words && d->dither_result_word + ((d->format == 3 || d->format == 5) ? 1 : 2) <= prog->total_words;
+    pl.dither_arg = d->dither_arg; pl.dither_word = d->dither_result_word;
     a.nrd_slot = a.nwr_slot = -1;
     if (d->nown >= 0 && d->io_span <= 256) {
         std::vector<int> own(d->own, d->own + 2 * (size_t)d->nown);
@@ -2937,6 +2947,78 @@ int avdsp_hip_prog_add_generic(avdsp_hip_prog *prog, const avdsp_generic_desc *d
     return (int)prog->plans.size() - 1;
 }
 
+int avdsp_hip_plan_add_strands(avdsp_hip_prog *prog, int plan, const avdsp_strand_desc *d)
+{
+    if (plan < 0 || plan >= (int)prog->plans.size() || !prog->plans[plan].generic) return set_err("strand plan: %d is not a generic plan", plan);
+    Plan &pl = prog->plans[plan];
+    if (d->nops < 1 || d->nstrands < 1 || d->nargs < 1) return set_err("strand plan: empty");
+    if (d->nops > kStrandMaxOps) return set_err("strand plan: %d operations per strand (the kernel's list holds %d)", d->nops, kStrandMaxOps);
+    std::vector<avdsp_strand_op> ops(d->ops, d->ops + d->nops);
+    std::vector<int> args(d->args, d->args + (size_t)d->nstrands * d->nargs);
+    /* every word index and IO number the kernel will follow lies inside the mirror / the frame (the host derived them from offsets
+     * scan_generic has checked; checked once more here, like the chain plans) */
+    for (auto &o : ops) {
+        const int cols[3] = {o.a0, o.a1, o.a2};
+        for (int c : cols) if (c < 0 || c >= d->nargs) return set_err("strand plan: argument column %d outside the row", c);
+        for (int r = 0; r < d->nstrands; r++) {
+            const int *row = args.data() + (size_t)r * d->nargs;
+            auto word_ok = [&](int w, int n) { return w >= 0 && (long long)w + n <= prog->total_words; };
+            bool ok = true;
+            switch (o.op) {
+            case AVDSP_SOP_LOAD: ok = row[o.a0] >= 0 && row[o.a0] < prog->frame_words; pl.s_loaded.push_back(row[o.a0]); break;
+            case AVDSP_SOP_LOAD_GAIN: ok = row[o.a0] >= 0 && row[o.a0] < prog->frame_words && word_ok(row[o.a1], 1); pl.s_loaded.push_back(row[o.a0]); break;
+            case AVDSP_SOP_STORE: ok = row[o.a0] >= 0 && row[o.a0] < prog->frame_words; pl.s_stored.push_back(row[o.a0]); break;
+            case AVDSP_SOP_GAIN: case AVDSP_SOP_SAT0DB_GAIN: case AVDSP_SOP_SAT0DB_TPDF_GAIN: ok = word_ok(row[o.a0], 1); break;
+            case AVDSP_SOP_LOAD_MEM: case AVDSP_SOP_STORE_MEM: ok = word_ok(row[o.a0], 2); break;
+            case AVDSP_SOP_DELAY: case AVDSP_SOP_DELAY_DP:
+                {   /* the line: the first word is its size in samples when a parameter word gives the delay, else microseconds */
+                    const long long nline = row[o.a2] ? (long long)row[o.a0] : (long long)(((unsigned long long)(unsigned)row[o.a0] * pl.ga.delay_factor) >> 32);
+                    ok = row[o.a0] >= 0 && word_ok(row[o.a1], 1) && (long long)row[o.a1] + 1 + nline * (o.op == AVDSP_SOP_DELAY_DP ? 2 : 1) <= prog->total_words &&
+                         (row[o.a2] == 0 || word_ok(row[o.a2], 1));
+                }
+                break;
+            case AVDSP_SOP_BIQUADS:
+                ok = o.imm >= 1 && word_ok(row[o.a0], 6 * o.imm) && word_ok(row[o.a1], pl.ga.biquad_offset + (o.imm - 1) * pl.ga.biquad_skip + 5);
+                break;
+            default: break;
+            }
+            if (!ok) { pl.s_loaded.clear(); pl.s_stored.clear(); return set_err("strand plan: strand %d addresses words or IOs outside the loaded buffer", r); }
+        }
+    }
+    if (upload_vec(&pl.d_sops, ops) || upload_vec(&pl.d_sargs, args)) return -1;
+    {
+        int nres = 0;
+        const int aw = (pl.format == 3 || pl.format == 5) ? 1 : 2;
+        for (auto &o : ops) { if (o.rcol != nres) return set_err("strand plan: resolved columns are not laid out in order"); nres += avdsp_strand_rcols(o.op, o.imm, aw); }
+        if (nres != d->nres || nres > 224) return set_err("strand plan: %d resolved columns (the kernel's table holds 224)", nres);
+        const void *fns[5] = {(const void *)strand_lanes<2>, (const void *)strand_lanes<3>, (const void *)strand_lanes<4>, (const void *)strand_lanes<5>, (const void *)strand_lanes<6>};
+        const hipError_t e = hipFuncSetAttribute(fns[pl.format - 2], hipFuncAttributeMaxDynamicSharedMemorySize, 224 * 256 + 8192 + 64 + kStrandMaxOps * (int)sizeof(avdsp_strand_op));
+        if (e != hipSuccess) return set_err("hipFuncSetAttribute(strand_lanes LDS): %s", hipGetErrorString(e));
+    }
+    pl.s_nops = d->nops; pl.s_nargs = d->nargs; pl.s_nstrands = d->nstrands; pl.s_nres = d->nres;
+    return 0;
+}
+
+int avdsp_hip_plan_strands(const avdsp_hip_prog *prog, int plan)
+{
+    return prog && plan >= 0 && plan < (int)prog->plans.size() ? prog->plans[plan].s_nstrands : 0;
+}
+
+/* does the strand kernel take this call's windows?  (Else the stretch runs through the interpreter, which handles every case.)
+ * The windows must not share IO numbers; a strand must not store into the input window (the next frame's input would replace the
+ * value, the interpreter keeps that order) nor load, outside the input window, an IO of the output window (the caller's row shows
+ * through there). */
+static bool strands_take(const Plan &pl, const BlockIO &io)
+{
+    if (!pl.s_nstrands) return false;
+    const bool overlap = io.in_stride > 0 && io.out_stride > 0 && io.in_base < io.out_base + io.out_stride && io.out_base < io.in_base + io.in_stride;
+    if (overlap) return false;
+    for (int s : pl.s_stored) if (s >= io.in_base && s < io.in_base + io.in_stride) return false;
+    for (int l : pl.s_loaded)
+        if (!(l >= io.in_base && l < io.in_base + io.in_stride) && l >= io.out_base && l < io.out_base + io.out_stride) return false;
+    return true;
+}
+
 int avdsp_hip_tpdf_reset(avdsp_hip_prog *prog, int seed, int default_dither)
 {
     if (!prog->d_tpdf) HIP_TRY(hipMalloc((void **)&prog->d_tpdf, sizeof(TpdfGlobals)));
@@ -2951,7 +3033,9 @@ int avdsp_hip_tpdf_reset(avdsp_hip_prog *prog, int seed, int default_dither)
 static bool wave_plan_fits(const avdsp_hip_prog *prog, const Plan &pl, const BlockIO &io, GenericArgs &a)
 {
     if (!pl.wave_ok || io.nframes < 2) return false;     /* a single frame (dspRuntime_N) has nothing to put side by side */
-    const int span = std::max(pl.io_span, std::max(io.in_base + io.in_stride, io.out_base + io.out_stride));
+    /* with slot lists the rows move slot by slot, so the columns only need to reach the core's own highest slot: a
+     * piece that touches little IO (the dither prefix of a wide core) stays frame-parallel whatever the windows' width */
+    const int span = a.rows_whole ? std::max(pl.io_span, std::max(io.in_base + io.in_stride, io.out_base + io.out_stride)) : pl.io_span;
     if (span > 256) return false;
     for (int s = 0; s < 256; s++)
         if (pl.carried_io[s >> 5] >> (s & 31) & 1u) {
@@ -2998,7 +3082,45 @@ static int launch_generic(avdsp_hip_prog *prog, Plan &pl, BlockIO io, hipStream_
     a.io = io;
     a.rows_whole = rows_whole(pl, io);
     if (tpdf_seq_for(prog, a, io.nframes)) return -1;
+    if (strands_take(pl, io)) {
+        ProfileScope scope(prog, stream, AVDSP_KERNEL_STRANDS); scope.begin();
+        StrandArgs sa{};
+        sa.buf = a.buf; sa.tpdf = a.tpdf; sa.tpdf_seq = a.tpdf_seq; sa.tpdf_role = a.tpdf_role;
+        sa.ops = pl.d_sops; sa.nops = pl.s_nops; sa.args = pl.d_sargs; sa.nargs = pl.s_nargs; sa.nstrands = pl.s_nstrands; sa.nres = pl.s_nres;
+        const size_t slds = (size_t)std::max(pl.s_nres, 1) * 256 + 8192 + 64 + (size_t)pl.s_nops * sizeof(avdsp_strand_op);   /* per-lane table, delay exchange area, dither values, operation list */
+        sa.prog_words = a.prog_words; sa.biquad_skip = a.biquad_skip; sa.biquad_offset = a.biquad_offset; sa.delay_factor = a.delay_factor;
+        sa.scratch = a.scratch; sa.io = io;
+#ifdef AVDSP_BQ_STAMPS
+        {
+            static unsigned long long *d_st = nullptr;
+            if (!d_st) { HIP_TRY(hipMalloc((void **)&d_st, 32 * 8)); HIP_TRY(hipMemset(d_st, 0, 32 * 8)); }
+            sa.stamps = d_st; g_bq_stamps = d_st; g_bq_stamp_waves = 1;
+        }
+#endif
+        const dim3 sgrid((pl.s_nstrands + 63) / 64), sblock(64);
+        switch (pl.format) {
+        case 2:  hipLaunchKernelGGL((strand_lanes<2>), sgrid, sblock, slds, stream, sa); break;
+        case 3:  hipLaunchKernelGGL((strand_lanes<3>), sgrid, sblock, slds, stream, sa); break;
+        case 4:  hipLaunchKernelGGL((strand_lanes<4>), sgrid, sblock, slds, stream, sa); break;
+        case 5:  hipLaunchKernelGGL((strand_lanes<5>), sgrid, sblock, slds, stream, sa); break;
+        default: hipLaunchKernelGGL((strand_lanes<6>), sgrid, sblock, slds, stream, sa); break;
+        }
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     const dim3 grid(1), block(64);
+    if (pl.dither_only && pl.wave_ok && io.nframes > 1) {      /* (wave_ok: frame-parallel forms not switched off) */
+        ProfileScope scope(prog, stream, AVDSP_KERNEL_GENERIC_WAVE); scope.begin();
+        switch (pl.format) {
+        case 2:  hipLaunchKernelGGL((tpdf_walk<2>), grid, block, 0, stream, a, pl.dither_arg, pl.dither_word, io.nframes); break;
+        case 3:  hipLaunchKernelGGL((tpdf_walk<3>), grid, block, 0, stream, a, pl.dither_arg, pl.dither_word, io.nframes); break;
+        case 4:  hipLaunchKernelGGL((tpdf_walk<4>), grid, block, 0, stream, a, pl.dither_arg, pl.dither_word, io.nframes); break;
+        case 5:  hipLaunchKernelGGL((tpdf_walk<5>), grid, block, 0, stream, a, pl.dither_arg, pl.dither_word, io.nframes); break;
+        default: hipLaunchKernelGGL((tpdf_walk<6>), grid, block, 0, stream, a, pl.dither_arg, pl.dither_word, io.nframes); break;
+        }
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     if (wave_plan_fits(prog, pl, io, a)) {
         ProfileScope scope(prog, stream, AVDSP_KERNEL_GENERIC_WAVE); scope.begin();
         const size_t lds = ((size_t)a.batch_lds + 128 + (size_t)a.nvm * 128 + a.seq_words) * 4;

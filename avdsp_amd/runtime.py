@@ -27,7 +27,7 @@ EXPORTED = [
     "dspHeaderPtr", "dspBiquadFreqSkip", "dspMantissa", "dspOpcodeText", "dspQNM", "dspQM64", "dspQM32",
     # block extension (include/avdsp_runtime.h)
     "dspRuntimeBlock_2", "dspRuntimeBlock_3", "dspRuntimeBlock_4", "dspRuntimeBlock_5", "dspRuntimeBlock_6",
-    "dspRuntimeBlockSubmit", "dspRuntimeBlockWait", "dspRuntimeBlockDevice", "dspRuntimeBlockPcm", "dspRuntimeUnpackPcmDevice", "dspRuntimeBlockAll", "dspRuntimeBlockAllDevice", "dspRuntimeBlockAllPcm",
+    "dspRuntimeStrandInfo", "dspRuntimeBlockSubmit", "dspRuntimeBlockWait", "dspRuntimeBlockDevice", "dspRuntimeBlockPcm", "dspRuntimeUnpackPcmDevice", "dspRuntimeBlockAll", "dspRuntimeBlockAllDevice", "dspRuntimeBlockAllPcm",
     "dspRuntimeSyncState", "dspRuntimeUploadState", "dspRuntimeUploadParams", "dspRuntimeSetOption", "dspRuntimeGetOption",
     "dspRuntimeCoreInfo", "dspRuntimeKernelTime", "dspRuntimeLastError", "dspRuntimeRelease", "dspRuntimeReleaseProgram", "dspRuntimeSelect",
     "dspRuntimeSetShard", "dspRuntimeShardInfo", "dspRuntimeTagOutput", "dspRuntimeTagOutputDevice", "dspRuntimeTagOutputReset",
@@ -113,6 +113,8 @@ def lib() -> C.CDLL:
         L.dspRuntimeGetOption.restype = i32; L.dspRuntimeGetOption.argtypes = [C.c_char_p]
         L.dspRuntimeCoreInfo.restype = i32
         L.dspRuntimeCoreInfo.argtypes = [i32, vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+        L.dspRuntimeStrandInfo.restype = i32
+        L.dspRuntimeStrandInfo.argtypes = [i32, vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
         L.dspRuntimeTagOutput.restype = i32; L.dspRuntimeTagOutput.argtypes = [vp, i32, i32, i32]
         L.dspRuntimeTagOutputDevice.restype = i32; L.dspRuntimeTagOutputDevice.argtypes = [vp, i32, i32, i32, vp]
         L.dspRuntimeTagOutputReset.restype = i32; L.dspRuntimeTagOutputReset.argtypes = [i32]
@@ -205,6 +207,12 @@ class Runtime:
         a, b, c = C.c_int(), C.c_int(), C.c_int()
         self._check(self.L.dspRuntimeCoreInfo(self.fmt, self.cores[core_index], C.byref(a), C.byref(b), C.byref(c)))
         return dict(chains=a.value, max_sections=b.value, max_taps=c.value)
+
+    def strand_info(self, core_index: int = 0):
+        """dspRuntimeStrandInfo (host-only): does the core's tail run as a strand plan?"""
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        self._check(self.L.dspRuntimeStrandInfo(self.fmt, self.cores[core_index], C.byref(a), C.byref(b), C.byref(c)))
+        return dict(strands=a.value, ops=b.value, prefix_words=c.value)
 
     def tag_output(self, out: np.ndarray, column: int):
         """dspRuntimeTagOutput on a host block [frames][out_stride] of int32, in place (linux/avdsp_plugin.c:133-137)."""

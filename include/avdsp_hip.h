@@ -86,6 +86,8 @@ typedef struct avdsp_generic_desc {
     int32_t  tpdf_calc;              /* the core holds the DSP_TPDF_CALC: it alone writes the dither globals     */
     int32_t  tpdf_role;              /* pieces of a core cut into strand groups: 1 = the piece with the TPDF_CALC leaves
                                         every frame's dither value for the later pieces (2) of that core; 0 otherwise    */
+    int32_t  dither_only;            /* the stretch is a DSP_TPDF_CALC and nothing else (the piece in front of a strand run):  */
+    int32_t  dither_arg, dither_result_word;   /* its dither width word and the mirror word its result goes to (tpdf_walk)   */
 } avdsp_generic_desc;
 
 /* A loaded program on the device: the mirror of the caller's buffer plus one plan per lowered core */
@@ -160,9 +162,44 @@ int avdsp_hip_run_block_pcm_host(avdsp_hip_prog *prog, int plan, int pcm, const 
  * the summed duration and the number of launches, and forgets them.  on: 0 = off, 1 = every kind,
  * 2 * mask = only the kinds whose bit is set in mask (an event pair costs a few microseconds of stream
  * time: a benchmark times the kernel it reports and nothing else).                               */
-enum { AVDSP_KERNEL_BIQUAD = 0, AVDSP_KERNEL_FIR = 1, AVDSP_KERNEL_PASS = 2, AVDSP_KERNEL_GENERIC = 3, AVDSP_KERNEL_UNPACK = 4, AVDSP_KERNEL_GENERIC_WAVE = 5 };
+enum { AVDSP_KERNEL_BIQUAD = 0, AVDSP_KERNEL_FIR = 1, AVDSP_KERNEL_PASS = 2, AVDSP_KERNEL_GENERIC = 3, AVDSP_KERNEL_UNPACK = 4, AVDSP_KERNEL_GENERIC_WAVE = 5, AVDSP_KERNEL_STRANDS = 6 };
 int avdsp_hip_profile_enable(avdsp_hip_prog *prog, int on);
 int avdsp_hip_profile_read(avdsp_hip_prog *prog, int kind, double *total_ms, int *launches);
+
+/* Strand plans (round 3): a stretch of an interpreted core that is N repetitions of ONE opcode sequence with different operands
+ * -- one strand per channel: LOAD[_GAIN] .. GAIN / DELAY / BIQUADS / X-Y moves .. SAT0DB[_TPDF][_GAIN] .. STORE, the shape of the
+ * reference's crossover programs -- runs that sequence once per frame batch with LANE = STRAND instead of one wave per strand group.
+ * The host proves the strands identical in shape and strangers to each other (avdsp_host.c strand_lower) and hands over the sequence
+ * as micro-operations plus one row of arguments per strand; attached to the stretch's generic plan, which stays the fallback for
+ * calls whose windows the strand kernel does not take (windows that share IO numbers, a STORE into the input window).           */
+enum { AVDSP_SOP_LOAD = 1, AVDSP_SOP_LOAD_GAIN, AVDSP_SOP_GAIN, AVDSP_SOP_COPYXY, AVDSP_SOP_SWAPXY, AVDSP_SOP_COPYYX, AVDSP_SOP_ADDXY, AVDSP_SOP_ADDYX,
+       AVDSP_SOP_SUBXY, AVDSP_SOP_SUBYX, AVDSP_SOP_NEGX, AVDSP_SOP_SHIFT, AVDSP_SOP_SAT0DB, AVDSP_SOP_SAT0DB_TPDF, AVDSP_SOP_SAT0DB_GAIN,
+       AVDSP_SOP_SAT0DB_TPDF_GAIN, AVDSP_SOP_STORE, AVDSP_SOP_LOAD_MEM, AVDSP_SOP_STORE_MEM, AVDSP_SOP_DELAY, AVDSP_SOP_DELAY_DP, AVDSP_SOP_BIQUADS };
+/* a0..a2: columns of the strand's argument row (values there: IO numbers, absolute word indices into the mirror, payload values);
+ * imm: the one operand the shape makes uniform (BIQUADS: sections per bank); rcol: first of the operation's columns in the
+ * kernel's per-lane table of resolved operands and running state (LDS; filled once per launch, avdsp_strand_rcols() of them) */
+typedef struct avdsp_strand_op { int32_t op, a0, a1, a2, imm, rcol; } avdsp_strand_op;
+typedef struct avdsp_strand_desc {
+    int32_t nops; const avdsp_strand_op *ops;
+    int32_t nstrands, nargs; const int32_t *args;          /* [nstrands][nargs] */
+    int32_t stored_io_max;                                 /* highest IO a strand stores (the scratch frame must reach it) */
+    int32_t nres;                                          /* columns of the resolved table: sum of avdsp_strand_rcols over the operations */
+} avdsp_strand_desc;
+/* resolved columns of one operation (format: 64-bit accumulator models keep memory values in two words) */
+static inline int avdsp_strand_rcols(int op, int imm, int alu_words)
+{
+    switch (op) {
+    case AVDSP_SOP_LOAD: case AVDSP_SOP_STORE: case AVDSP_SOP_GAIN: case AVDSP_SOP_SHIFT: case AVDSP_SOP_SAT0DB_GAIN:
+    case AVDSP_SOP_SAT0DB_TPDF_GAIN: case AVDSP_SOP_STORE_MEM: return 1;
+    case AVDSP_SOP_LOAD_GAIN: return 2;
+    case AVDSP_SOP_LOAD_MEM: return alu_words;
+    case AVDSP_SOP_DELAY: case AVDSP_SOP_DELAY_DP: return 4;           /* n, allocation, word of the line's counter, running position */
+    case AVDSP_SOP_BIQUADS: return 2 + 11 * imm;                        /* bypass, state word, per section 5 coefficients + 6 state words */
+    }
+    return 0;
+}
+int avdsp_hip_plan_add_strands(avdsp_hip_prog *prog, int plan, const avdsp_strand_desc *d);
+int avdsp_hip_plan_strands(const avdsp_hip_prog *prog, int plan);      /* strands of the plan (0 = none) */
 
 /* Launch arrangement of the chain kernels.  AVDSP_OPT_OVERLAP 1: the cascade of block k+1 may run under the FIR of
  * block k (side stream; see launch_all in avdsp_kernels.hip) -- the caller then guarantees that a block's input is

@@ -179,9 +179,13 @@ int dspRuntimeSetShard(int rank, int world);
 int dspRuntimeShardInfo(int format, opcode_t *core, int *total_chains, int *first_chain, int *nchains,
                         int *in_io_min, int *in_io_max, int *out_io_min, int *out_io_max);
 
+/* Host-only: the tail of an interpreted core that is N >= 2 repetitions of one opcode sequence -- one strand per channel, the shape of
+ * the reference's crossover programs -- runs with lane = strand (avdsp_hip.h, strand plans).  strands = 0: the core has no such tail. */
+int dspRuntimeStrandInfo(int format, opcode_t *core, int *strands, int *ops_per_strand, int *prefix_words);
+
 /* Tunables: "fir_impl" 0 = plain tap loop, 1 = MFMA (default); "biquad_impl" 0 = lane per channel,
  * 1 = section-pipelined (default: biquad_row where it applies, else biquad_pipe), 2 = round 2's biquad_pipe throughout; "interp_impl" 0 = interpreter always frame by frame, 1 = frame-parallel
- * where the core allows it (default); "strand_split" 0 = dspRuntimeBlockAll keeps cores whole; "generic" 1 = every core through the interpreter;
+ * where the core allows it (default); "strand_split" 0 = dspRuntimeBlockAll keeps cores whole; "strand_lanes" 0 = strand runs stay with the interpreter; "generic" 1 = every core through the interpreter;
  * "device" = HIP device ordinal (before the first block).                                        */
 int dspRuntimeSetOption(const char *key, int value);
 int dspRuntimeGetOption(const char *key);

@@ -439,20 +439,24 @@ def test_wide_core_is_cut_into_strand_groups():
         x = pb.lcg_input(256, nch, fmt == 6, seed=21)
         o = po.OracleProgram(fmt, prog, fs=48000, random=5, dither=24)
         want = o.run_block(x, nch, 128, 0, block=128, frame=np.zeros(4096, dtype=np.uint32))
-        for split in (1, 0):
+        for split in (2, 1, 0):                 # 2: the run of strands on lanes (the default), 1: strand groups of the interpreter, 0: whole
             r = rt.Runtime(fmt, prog, fs=48000, random=5, dither=24)
-            r.set_option("strand_split", split)
+            r.set_option("strand_split", 1 if split else 0)
+            r.set_option("strand_lanes", 1 if split == 2 else 0)
             try:
                 got = r.run_block_all(x, nch, 128, 0, block=128)
                 assert (got.view(np.uint32) == want.view(np.uint32)).all(), (fmt, split)
                 assert (r.sync_state() == o.state).all(), (fmt, split)
                 pieces, levels = r.get_option("pieces"), r.get_option("levels")
-                if split:
+                if split == 2:
+                    assert pieces == 2 and levels == 2 and r.get_option("strands") == nch, (pieces, levels)   # the TPDF_CALC, then the run
+                elif split:
                     assert pieces > 20 and levels == 2, (pieces, levels)       # TPDF_CALC's piece first, the rest together
                 else:
                     assert pieces == 1 and levels == 1
             finally:
                 r.set_option("strand_split", 1)
+                r.set_option("strand_lanes", 1)
                 r.release()
 
 
