@@ -1827,6 +1827,11 @@ static int find_strand_run(int format, opcode_t *begin, int *run_word, int *end_
     return -8;
 }
 
+/* A wave at lane = strand costs the same for 2 strands as for 64, and a strand's cheap opcodes cost it ten times what they cost the
+ * frame-parallel interpreter: below four strands the interpreter's strand groups are as fast (dacdiy1.bin: 0.56 us per frame either
+ * way, per-core calls 0.86 against 1.32).  "strand_lanes" 2 lowers every run there is. */
+static int strand_lanes_from(void) { return G.opt_strand_lanes >= 2 ? 2 : 4; }
+
 /* Host-only: would the core's tail run as a strand plan?  strands = 0: no.  (prefix_words: opcode words in front of the run that
  * stay with the interpreter; ops: micro-operations per strand) */
 int dspRuntimeStrandInfo(int format, opcode_t *core, int *strands, int *ops, int *prefix_words)
@@ -1840,8 +1845,9 @@ int dspRuntimeStrandInfo(int format, opcode_t *core, int *strands, int *ops, int
     opcode_t *begin = dspFindCoreBegin(core);
     strand_plan S;
     int w = 0, e = 0;
-    const int rc = find_strand_run(format, begin, &w, &e, &S);
+    int rc = find_strand_run(format, begin, &w, &e, &S);
     if (rc == -9) return fail(-9, "out of memory");
+    if (rc == 0 && (!G.opt_strand_lanes || S.d.nstrands < strand_lanes_from())) { strand_free(&S); rc = -8; }
     if (strands) *strands = rc ? 0 : S.d.nstrands;
     if (ops) *ops = rc ? 0 : S.d.nops;
     if (prefix_words) *prefix_words = rc ? 0 : w - (int)(begin - G.code);
@@ -1863,8 +1869,9 @@ static int expand_core(int format, opcode_t *c, core_plan **cp, int *pn)
     if (G.opt_strand_split && G.opt_strand_lanes && whole->total_chains == 0) {
         strand_plan S;
         int w = 0, core_end = 0;
-        const int rc = find_strand_run(format, begin, &w, &core_end, &S);
+        int rc = find_strand_run(format, begin, &w, &core_end, &S);
         if (rc == -9) return fail(-9, "out of memory");
+        if (rc == 0 && S.d.nstrands < strand_lanes_from()) { strand_free(&S); rc = -8; }
         if (rc == 0) {
             avdsp_generic_desc gd;
             static core_deps d0, d1;

@@ -226,3 +226,27 @@ def test_failed_loads_leave_no_context_behind():
     # a failed load does not take the current program away from calls that name none
     assert L.dspRuntimeInit(junk[0].ctypes.data, 64, 48000, 0, 31) == -1
     assert C.c_void_p.in_dll(L, "dspHeaderPtr").value == good.buf.ctypes.data
+
+
+def test_strand_info_reports_what_lowers():
+    """host-only: dspRuntimeStrandInfo -- the run of identical strands a core ends in, the opcode words in front of it, and the
+    four-strand floor ("strand_lanes" 2 lowers shorter runs too, 0 none)"""
+    from tests.test_gpu_strands import crossover_program
+    r = rt.Runtime(6, crossover_program(12, 6, "dither"), fs=48000, dither=24)
+    try:
+        info = r.strand_info(0)
+        assert info["strands"] == 12 and info["ops"] == 6 and info["prefix_words"] > 0      # the TPDF_CALC stays in front
+        r.set_option("strand_lanes", 0)
+        assert r.strand_info(0)["strands"] == 0
+    finally:
+        r.set_option("strand_lanes", 1)
+        r.release()
+    prog = np.fromfile(os.path.join(GOLDEN_DIR, "dacdiy1.bin"), dtype=np.uint32)
+    r = rt.Runtime(2, prog, fs=48000, dither=24)
+    try:
+        assert [r.strand_info(i)["strands"] for i in range(len(r.cores))] == [0, 0, 0, 0]      # runs of two: the interpreter's
+        r.set_option("strand_lanes", 2)
+        assert [r.strand_info(i)["strands"] for i in range(len(r.cores))] == [2, 2, 2, 0]
+    finally:
+        r.set_option("strand_lanes", 1)
+        r.release()

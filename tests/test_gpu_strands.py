@@ -112,8 +112,16 @@ def test_reference_programs_find_their_runs():
     x = pb.lcg_input(256, 16, False, seed=5)
     o = po.OracleProgram(2, prog, fs=48000, random=1, dither=24)
     want = o.run_block(x, 32, 8, 0)
-    r = rt.Runtime(2, prog, fs=48000, random=1, dither=24)
-    got = r.run_block_all(x, 32, 8, 0)
-    assert r.get_option("strands") == 6            # (the two strands of its last core store the same IOs: they meet, the interpreter keeps them)
-    assert (words(got) == words(want)).all()
-    assert (r.sync_state() == o.state).all()
+    for lanes, strands in ((2, 6), (1, 0)):        # runs of two strands stay with the interpreter unless asked for ("strand_lanes" 2)
+        o = po.OracleProgram(2, prog, fs=48000, random=1, dither=24)
+        want = o.run_block(x, 32, 8, 0)
+        r = rt.Runtime(2, prog, fs=48000, random=1, dither=24)
+        r.set_option("strand_lanes", lanes)
+        try:
+            got = r.run_block_all(x, 32, 8, 0)
+            assert r.get_option("strands") == strands      # (the two strands of its last core store the same IOs: they meet, the interpreter keeps them)
+            assert (words(got) == words(want)).all()
+            assert (r.sync_state() == o.state).all()
+        finally:
+            r.set_option("strand_lanes", 1)
+            r.release()

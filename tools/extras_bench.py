@@ -80,6 +80,8 @@ def program_level():
         prog = np.fromfile(os.path.join(gold, name), dtype=np.uint32)
         for frames in (256, 4096):
             r = rt.Runtime(fmt, prog, fs=48000, random=1, dither=24)
+            if os.environ.get("STRAND_LANES") is not None:                   # 0: strand runs stay with the interpreter's strand groups
+                r.set_option("strand_lanes", int(os.environ["STRAND_LANES"]))
             x = torch.from_numpy(pb.lcg_input(frames, in_stride, fmt in (5, 6), seed=5)).cuda()
             y = torch.zeros((frames, out_stride), dtype=x.dtype, device="cuda")
             stream = torch.cuda.current_stream().cuda_stream
@@ -105,6 +107,7 @@ def program_level():
                 res[mode] = e0.elapsed_time(e1) * 1e3 / reps / frames
             print(f"program {name:18s} fmt {fmt} block {frames:5d}: per core {res['per core']:6.3f} us/frame, "
                   f"BlockAll {res['all']:6.3f} us/frame ({r.get_option('cores')} cores in {r.get_option('levels')} levels)", flush=True)
+            r.set_option("strand_lanes", 1)
             r.L.dspRuntimeRelease()
 
 

@@ -75,18 +75,25 @@ def time_us_per_frame(fmt, prog, impl, x):
 
 
 def main():
-    fmt = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+    argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+    fmt = int(argv[0]) if argv else 6
+    only = [a[7:].split(",") for a in sys.argv[1:] if a.startswith("--only=")]       # --only=biquads1,biquads6
+    wave_only = "--wave-only" in sys.argv                                             # skip the (slow) frame-by-frame kernel
     ops = ["gain", "swapxy", "store", "load_gain", "load_mux4", "sat_tpdf_gain", "delay_1", "delay_100", "delay_dp_100",
            "dcblock", "rms", "dither", "biquads1", "biquads6", "biquads16", "biquads64"] + (["fir64"] if fmt != 2 else [])
+    if only: ops = [o for o in ops if o in only[0]]
+    impls = (1,) if wave_only else (1, 0)
     x = pb.lcg_input(FRAMES, 8, fmt in (5, 6), seed=5)
     K = 32
     print(f"DSP_FORMAT {fmt}, {FRAMES} frames per block; ns per opcode and frame")
     print(f"{'opcode':16s} {'frame-parallel':>15s} {'frame by frame':>15s} {'ratio':>7s}")
-    base = {impl: time_us_per_frame(fmt, program(fmt, "none", 0), impl, x if impl else x[:4096]) for impl in (1, 0)}
+    base = {impl: time_us_per_frame(fmt, program(fmt, "none", 0), impl, x if impl else x[:4096]) for impl in impls}
+    base.setdefault(0, float("nan"))
     print(f"{'(empty core)':16s} {base[1] * 1e3:15.1f} {base[0] * 1e3:15.1f}")
     for op in ops:
         prog = program(fmt, op, K)
-        c = {impl: (time_us_per_frame(fmt, prog, impl, x if impl else x[:4096]) - base[impl]) / K * 1e3 for impl in (1, 0)}
+        c = {impl: (time_us_per_frame(fmt, prog, impl, x if impl else x[:4096]) - base[impl]) / K * 1e3 for impl in impls}
+        c.setdefault(0, float("nan"))
         print(f"{op:16s} {c[1]:15.1f} {c[0]:15.1f} {c[0] / max(c[1], 1e-9):7.1f}", flush=True)
 
 
