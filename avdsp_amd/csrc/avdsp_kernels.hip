@@ -2195,6 +2195,11 @@ static constexpr int kStrandMaxOps = 512;         /* operations per strand (stra
  * ---------------------------------------------------------------------------------------- */
 struct LaneArgs {
     int *buf; const avdsp_chain *chains; const int *sec_coef, *sec_state; int nchains; BlockIO io;
+    /* chains with a FIR: the cascade's outputs go to the chain's row of a sequence buffer, x[m] of the block at seq[row + hist + m]
+     * with the delay line's content in front of it (m < 0), and fir_lane works from there; seq == nullptr: the FIR runs here, tap by
+     * tap on the mirror's delay line (single frames) */
+    unsigned *seq; int pitch, hist;
+    int rows_take;                   /* chains of 1 .. 16 sections run on chain_rows */
 };
 
 template <int FMT>
@@ -2206,6 +2211,7 @@ __global__ __launch_bounds__(64) void chain_lane(const LaneArgs a)
     const int cid = blockIdx.x * 64 + threadIdx.x;
     if (cid >= a.nchains) return;
     const avdsp_chain c = a.chains[cid];
+    if (a.rows_take && c.nsec >= 1 && c.nsec <= 16) return;                    /* chain_rows' */
     const unsigned *inp = a.io.in + (c.in_io - a.io.in_base);
     for (int n = 0; n < a.io.nframes; n++) {
         const unsigned raw = inp[(size_t)n * a.io.in_stride];
@@ -2219,13 +2225,157 @@ __global__ __launch_bounds__(64) void chain_lane(const LaneArgs a)
         }
         for (int s = 0; s < c.nsec; s++)                                        /* :827-849, section by section */
             X = biquads<FMT>(X, a.buf + a.sec_coef[c.sec_base + s], a.buf + a.sec_state[c.sec_base + s], 1, 0);
-        if (c.fir_taps) X = fir<FMT>(to_sp<FMT>(X), a.buf + c.fir_coef_word, a.buf + c.fir_state_word, c.fir_taps);   /* :928-969 */
+        if (c.fir_taps) {
+            if (a.seq) { a.seq[(size_t)cid * a.pitch + a.hist + n] = __float_as_uint(to_sp<FMT>(X)); continue; }
+            X = fir<FMT>(to_sp<FMT>(X), a.buf + c.fir_coef_word, a.buf + c.fir_state_word, c.fir_taps);   /* :928-969 */
+        }
         if (c.sat) X = sat0db<FMT>(X);                                          /* :464-475 */
         unsigned word;                                                          /* :610-633 */
         if constexpr (M<FMT>::smp_int) word = (unsigned)(s31_from_float(X.v) & a.io.store_mask);
         else word = __float_as_uint(to_sp<FMT>(X));
         emit_out(a.io, c, n, word);
     }
+}
+
+/* chain_rows<FMT>: the cascades of the float-accumulator models with ONE LANE PER (CHAIN, SECTION) -- biquad_pipe's arrangement on
+ * the interpreter's own section update (bq_step<FMT>: float sums of truncating products, ~150 instructions), four chains of up to 16
+ * sections per wave.  Frame f reaches section s at step f + s; a section hands its output to the next lane with a DPP row shift;
+ * the row's 16 lanes fetch and convert 16 frames at a time (one batch ahead, parked in LDS) and the section-0 lane takes one per
+ * step; the last section's lane stores what chain_lane would (or feeds the sequence buffer of fir_lane).  ids: the chains with
+ * 1 .. 16 sections; chain_lane keeps the others. */
+template <int FMT>
+__global__ __launch_bounds__(64) void chain_rows(const LaneArgs a, const int *ids, int nids)
+{
+    using namespace interp;
+    using alu_t = typename M<FMT>::alu;
+    flush_f32_subnormals_like_the_reference();
+    __shared__ int xin[2][4][16];
+    const int lane = threadIdx.x, row = lane >> 4, s = lane & 15;
+    const int gi = blockIdx.x * 4 + row;
+    const bool valid = gi < nids;
+    const int cid = ids[valid ? gi : nids - 1];
+    const avdsp_chain c = a.chains[cid];
+    const int S = c.nsec, B = a.io.nframes;
+    const bool mine = valid && s < S;
+    BqState<FMT> q; q.acc = 0; q.x1 = q.x2 = q.y1 = q.y2 = 0;
+    int cw[5] = {0, 0, 0, 0, 0};
+    int *stw = a.buf;
+    if (mine) {
+        stw = a.buf + a.sec_state[c.sec_base + s];
+        bq_load<FMT>(q, stw);
+        const int *cp = a.buf + a.sec_coef[c.sec_base + s];
+        for (int k = 0; k < 5; k++) cw[k] = cp[k];
+    }
+    const unsigned *inp = a.io.in + (c.in_io - a.io.in_base);
+    auto fetch = [&](int n) -> int {                     /* frame n as the first section's input word (dsp_runtime.c:565-607, :827-849) */
+        if (!valid || n >= B) return 0;
+        const unsigned raw = inp[(size_t)n * a.io.in_stride];
+        alu_t X;
+        if constexpr (M<FMT>::smp_int) {
+            if (c.load_mode == AVDSP_LOAD_GAIN) X = fmul<FMT>(int_to_float_scaled((int)raw, 31), __uint_as_float(c.gain_bits));
+            else X = from_int_scaled<FMT>((int)raw, 31);
+        } else {
+            X = to_alu<FMT>(__uint_as_float(raw));
+            if (c.load_mode == AVDSP_LOAD_GAIN) X *= to_alu<FMT>(__uint_as_float(c.gain_bits));
+        }
+        return bq_input<FMT>(X);
+    };
+    xin[0][row][s] = fetch(s);
+    __syncthreads();
+    int y = 0;
+    const int steps = B + 15;                            /* the longest row's last frame leaves its 16th section at step B - 1 + 15 */
+    for (int t0 = 0; t0 < steps; t0 += 16) {
+        const int cur = (t0 >> 4) & 1;
+        const int ahead = fetch(t0 + 16 + s);            /* (in flight under the batch's steps) */
+        for (int k = 0; k < 16; k++) {
+            const int t = t0 + k;
+            int x = __builtin_amdgcn_update_dpp(0, y, kRowShr1, 0xF, 0xF, false);      /* the section before, one step ago */
+            if (s == 0) x = xin[cur][row][k];
+            const int f = t - s;
+            if (mine && f >= 0 && f < B) {
+                y = bq_step<FMT>(q, x, cw);
+                if (s == S - 1) {
+                    alu_t X = q.acc;
+                    if (c.fir_taps && a.seq) a.seq[(size_t)cid * a.pitch + a.hist + f] = __float_as_uint(to_sp<FMT>(X));
+                    else {
+                        if (c.fir_taps) X = fir<FMT>(to_sp<FMT>(X), a.buf + c.fir_coef_word, a.buf + c.fir_state_word, c.fir_taps);
+                        if (c.sat) X = sat0db<FMT>(X);
+                        unsigned word;
+                        if constexpr (M<FMT>::smp_int) word = (unsigned)(s31_from_float(X.v) & a.io.store_mask);
+                        else word = __float_as_uint(to_sp<FMT>(X));
+                        emit_out(a.io, c, f, word);
+                    }
+                }
+            }
+        }
+        xin[cur ^ 1][row][s] = ahead;
+        __syncthreads();                                 /* (one wave: orders the row's writes against the section-0 lane's reads) */
+    }
+    if (mine) bq_store<FMT>(q, stw);
+}
+
+/* fir_lane<FMT>: the DSP_FIR of the float-accumulator models, ONE LANE PER (CHAIN, FRAME).  An output is a sum over the chain's
+ * inputs only -- no feedback -- so the frames of a block do not wait for each other; what must stay is the order inside one output:
+ * acc = acc + dspMulFloatFloat(x[n-i], c[i]) for i = 0, 1, ... (dsp_firSTD.h:38-52 with the truncating product of
+ * dsp_ieee754.h:342-375 and a float sum), which is what every lane does.  A workgroup takes 256 consecutive frames of one chain and
+ * walks the taps in chunks of kFirLaneChunk: the chunk's coefficients and the 256 + chunk - 1 inputs under them are staged in
+ * LDS (consecutive lanes read consecutive words, the coefficient is a broadcast).  SAT0DB and the stores follow as in chain_lane.
+ * fir_lane_history lays the delay line (st[i] = x[-1-i]) in front of the block's inputs, fir_lane_state leaves it as the
+ * reference's tap loop would (st[i] = x[B-1-i]). */
+constexpr int kFirLaneChunk = 2048, kFirLaneFrames = 256;
+
+__global__ __launch_bounds__(256) void fir_lane_history(const LaneArgs a)
+{
+    const int cid = blockIdx.x;
+    const avdsp_chain c = a.chains[cid];
+    const int i = blockIdx.y * 256 + threadIdx.x;
+    if (i < c.fir_taps - 1) a.seq[(size_t)cid * a.pitch + a.hist - 1 - i] = (unsigned)a.buf[c.fir_state_word + i];
+}
+
+__global__ __launch_bounds__(256) void fir_lane_state(const LaneArgs a)
+{
+    const int cid = blockIdx.x;
+    const avdsp_chain c = a.chains[cid];
+    const int i = blockIdx.y * 256 + threadIdx.x;
+    if (i < c.fir_taps) a.buf[c.fir_state_word + i] = (int)a.seq[(size_t)cid * a.pitch + a.hist + a.io.nframes - 1 - i];
+}
+
+template <int FMT>
+__global__ __launch_bounds__(kFirLaneFrames) void fir_lane(const LaneArgs a)
+{
+    using namespace interp;
+    using alu_t = typename M<FMT>::alu;
+    flush_f32_subnormals_like_the_reference();
+    __shared__ unsigned ws[kFirLaneChunk + kFirLaneFrames], cs[kFirLaneChunk];
+    const int cid = blockIdx.x, t = threadIdx.x, n0 = blockIdx.y * kFirLaneFrames;
+    const avdsp_chain c = a.chains[cid];
+    const int T = c.fir_taps;
+    if (T == 0) return;                                  /* (uniform: the whole workgroup is one chain's) */
+    const unsigned *x = a.seq + (size_t)cid * a.pitch + a.hist;          /* x[m], m = -(T-1) .. nframes-1 */
+    alu_t acc = 0;
+    for (int i0 = 0; i0 < T; i0 += kFirLaneChunk) {
+        const int tc = min(kFirLaneChunk, T - i0);
+        /* ws[k] = x[n0 - i0 - (tc - 1) + k], k < tc + 255: lane t's tap i0 + ii reads ws[t + tc - 1 - ii] */
+        const int base = n0 - i0 - (tc - 1);
+        __syncthreads();
+        for (int k = t; k < tc + kFirLaneFrames - 1; k += kFirLaneFrames) {
+            const int m = base + k;
+            ws[k] = m < a.io.nframes ? x[m] : 0u;
+        }
+        for (int k = t; k < tc; k += kFirLaneFrames) cs[k] = (unsigned)a.buf[c.fir_coef_word + i0 + k];
+        __syncthreads();
+        const unsigned *w = ws + t + tc - 1;
+#pragma unroll 4
+        for (int ii = 0; ii < tc; ii++) acc = fmacc<FMT>(acc, __uint_as_float(w[-ii]), __uint_as_float(cs[ii]));
+    }
+    const int n = n0 + t;
+    if (n >= a.io.nframes) return;
+    alu_t X = acc;
+    if (c.sat) X = sat0db<FMT>(X);                                              /* :464-475 */
+    unsigned word;                                                              /* :610-633 */
+    if constexpr (M<FMT>::smp_int) word = (unsigned)(s31_from_float(X.v) & a.io.store_mask);
+    else word = __float_as_uint(to_sp<FMT>(X));
+    emit_out(a.io, c, n, word);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -2257,6 +2407,8 @@ struct Plan {
     int *d_own = nullptr;                                /* owned mirror ranges (pairs), generic plans */
     double *d_taps64 = nullptr; int pitch64 = 0;         /* fir_tile: the taps as doubles, [chain][pitch64] */
     bool lane_mode = false;                              /* formats 3 and 5: chain_lane, one lane per chain, state in the mirror */
+    int *d_lane_rows = nullptr; int n_lane_rows = 0;     /* ... chain_rows' chains (1 .. 16 sections) */
+    int n_lane_fir = 0; unsigned *d_lseq = nullptr; int lseq_pitch = 0;      /* ... and fir_lane's sequence buffer: [nchains][max_taps - 1 + frames of the largest block so far] */
     /* strand plan attached to a generic plan (include/avdsp_hip.h): the stretch as micro-operations, one argument row per strand */
     avdsp_strand_op *d_sops = nullptr; int *d_sargs = nullptr; int s_nops = 0, s_nargs = 0, s_nstrands = 0, s_nres = 0;
     std::vector<int> s_loaded, s_stored;                 /* the IOs the strands load / store: per call against the windows */
@@ -2338,7 +2490,7 @@ void free_plan(Plan &p)
 {
     (void)hipFree(p.d_chains); (void)hipFree(p.d_sec_coef); (void)hipFree(p.d_sec_state);
     for (auto &g : p.bq) { (void)hipFree(g.d_ids); (void)hipFree(g.d_rows); (void)hipFree(g.d_lanes); }
-    (void)hipFree(p.d_sops); (void)hipFree(p.d_sargs);
+    (void)hipFree(p.d_sops); (void)hipFree(p.d_sargs); (void)hipFree(p.d_lseq); (void)hipFree(p.d_lane_rows);
     (void)hipFree(p.d_fir_ids); (void)hipFree(p.d_pass_ids); (void)hipFree(p.d_ring); (void)hipFree(p.d_ring64); (void)hipFree(p.d_own); (void)hipFree(p.d_taps64);
 }
 
@@ -2759,6 +2911,11 @@ int avdsp_hip_prog_add_plan(avdsp_hip_prog *prog, const avdsp_plan_desc *d)
     }
     if (upload_vec(&pl.d_chains, chains) || upload_vec(&pl.d_sec_coef, coef) || upload_vec(&pl.d_sec_state, state)) { free_plan(pl); return -1; }
     if (pl.lane_mode) {                                  /* no launch groups, no rings: chain_lane walks the chain list itself */
+        pl.n_lane_fir = (int)fir.size();             /* (n_fir stays 0: that one counts chains with a ring) */
+        std::vector<int> rows;
+        for (int i = 0; i < d->nchains; i++) if (chains[i].nsec >= 1 && chains[i].nsec <= 16) rows.push_back(i);
+        pl.n_lane_rows = (int)rows.size();
+        if (upload_vec(&pl.d_lane_rows, rows)) { free_plan(pl); return -1; }
         prog->plans.push_back(pl);
         return (int)prog->plans.size() - 1;
     }
@@ -3253,8 +3410,38 @@ int avdsp_hip_run_block(avdsp_hip_prog *prog, int plan, const void *d_in, int in
         a.io.out = (unsigned *)d_out;      a.io.out_stride = out_stride; a.io.out_base = out_io_base;
         a.io.nframes = nframes; a.io.store_mask = pl.store_mask;
         const dim3 grid((pl.nchains + 63) / 64), block(64);
-        if (pl.format == 3) hipLaunchKernelGGL(chain_lane<3>, grid, block, 0, (hipStream_t)stream, a);
-        else                hipLaunchKernelGGL(chain_lane<5>, grid, block, 0, (hipStream_t)stream, a);
+        hipStream_t st = (hipStream_t)stream;
+        /* blocks: the FIRs frame-parallel behind the cascades (fir_lane); single frames keep the tap loop on the delay line */
+        const bool tiles = pl.n_lane_fir > 0 && nframes > 1;
+        if (tiles) {
+            const int pitch = (pl.max_taps - 1 + nframes + 63) / 64 * 64;
+            if (pitch > pl.lseq_pitch) {
+                HIP_TRY(hipDeviceSynchronize());
+                (void)hipFree(pl.d_lseq); pl.d_lseq = nullptr; pl.lseq_pitch = 0;
+                HIP_TRY(hipMalloc((void **)&pl.d_lseq, (size_t)pl.nchains * pitch * sizeof(unsigned)));
+                pl.lseq_pitch = pitch;
+            }
+            a.seq = pl.d_lseq; a.pitch = pl.lseq_pitch; a.hist = pl.max_taps - 1;
+            if (pl.max_taps > 1) hipLaunchKernelGGL(fir_lane_history, dim3(pl.nchains, (pl.max_taps - 1 + 255) / 256), dim3(256), 0, st, a);
+        }
+        /* blocks: cascades of up to 16 sections with a lane per section (chain_rows); the rest, and single frames, a lane per chain */
+        const bool rows = pl.n_lane_rows > 0 && nframes > 1;
+        a.rows_take = rows ? 1 : 0;
+        if (rows) {
+            const dim3 rgrid((pl.n_lane_rows + 3) / 4);
+            if (pl.format == 3) hipLaunchKernelGGL(chain_rows<3>, rgrid, block, 0, st, a, (const int *)pl.d_lane_rows, pl.n_lane_rows);
+            else                hipLaunchKernelGGL(chain_rows<5>, rgrid, block, 0, st, a, (const int *)pl.d_lane_rows, pl.n_lane_rows);
+        }
+        if (!rows || pl.n_lane_rows < pl.nchains) {
+            if (pl.format == 3) hipLaunchKernelGGL(chain_lane<3>, grid, block, 0, st, a);
+            else                hipLaunchKernelGGL(chain_lane<5>, grid, block, 0, st, a);
+        }
+        if (tiles) {
+            const dim3 fgrid(pl.nchains, (nframes + kFirLaneFrames - 1) / kFirLaneFrames), fblock(kFirLaneFrames);
+            if (pl.format == 3) hipLaunchKernelGGL(fir_lane<3>, fgrid, fblock, 0, st, a);
+            else                hipLaunchKernelGGL(fir_lane<5>, fgrid, fblock, 0, st, a);
+            hipLaunchKernelGGL(fir_lane_state, dim3(pl.nchains, (pl.max_taps + 255) / 256), dim3(256), 0, st, a);
+        }
         HIP_TRY(hipGetLastError());
         return 0;
     }

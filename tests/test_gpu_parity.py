@@ -439,12 +439,13 @@ def test_north_star_program_sampled_oracle():
 
 
 @pytest.mark.parametrize("fmt", [3, 5])
-@pytest.mark.parametrize("channels,sections,taps", [(1, 1, 0), (70, 5, 0), (130, 16, 33), (9, 0, 120), (3, 24, 7)])
+@pytest.mark.parametrize("channels,sections,taps", [(1, 1, 0), (70, 5, 0), (130, 16, 33), (9, 0, 120), (3, 24, 7), (4, 1, 2300), (3, 0, 4100), (6, 2, 257)])
 def test_float_accumulator_models_on_chain_lane(fmt, channels, sections, taps):
-    """DSP_FORMAT 3 and 5 (float accumulator, truncating dspMulFloatFloat): chain programs run one lane per chain; ragged blocks,
-    state carried, and the same chains cut into shards, against the oracle bit for bit."""
+    """DSP_FORMAT 3 and 5 (float accumulator, truncating dspMulFloatFloat): chain programs run one lane per chain, their FIRs one
+    lane per (chain, frame) over blocks (fir_lane: tap chunks of 2048, frame tiles of 256) and tap by tap on single frames; ragged
+    blocks, state carried, and the same chains cut into shards, against the oracle bit for bit."""
     prog = pb.synth_program(fmt, channels, sections, taps)
-    blocks = [1, 7, 64, 100, 33, 2]
+    blocks = [1, 7, 64, 100, 33, 2] if taps < 200 else [300, 1, 700, 1, 257, 2]
     x = pb.lcg_input(sum(blocks), channels, fmt == 5, seed=50 + channels)
     r = _oracle_vs_device(fmt, prog, x, channels, channels, blocks)
     assert r.core_info()["chains"] == channels

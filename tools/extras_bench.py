@@ -111,7 +111,33 @@ def program_level():
             r.L.dspRuntimeRelease()
 
 
+def single_frame():
+    """dspRuntime_N, the reference's own entry point: one frame per call, samples[] in host memory (BASELINE config 1 is
+    "block = 1").  Every call is a PCIe round trip and one kernel launch per core; microseconds per call, wall clock."""
+    gold = os.path.join(ROOT, "tests", "golden")
+    for name, fmt in (("crossoverLV6.bin", 2), ("dacdiy1.bin", 2)):
+        prog = np.fromfile(os.path.join(gold, name), dtype=np.uint32)
+        r = rt.Runtime(fmt, prog, fs=48000, random=1, dither=24)
+        frame = np.zeros(64, dtype=np.int32)
+        x = pb.lcg_input(1200, 16, False, seed=5)
+        lat = []
+        for n in range(1200):
+            frame[8:24] = x[n]
+            t0 = time.perf_counter()
+            for k in range(len(r.cores)):
+                r.run_frame(frame, k)
+            lat.append(time.perf_counter() - t0)
+        lat = np.array(lat[200:]) * 1e6
+        print(f"single frame {name:18s} fmt {fmt}: dspRuntime_{fmt} over {len(r.cores)} cores, 1000 frames: median {np.median(lat):7.1f} us per frame "
+              f"(p10 {np.percentile(lat, 10):.1f}, p90 {np.percentile(lat, 90):.1f}) = {np.median(lat) / len(r.cores):.1f} us per core call; "
+              f"real time at 48 kHz allows 20.8 us per frame", flush=True)
+        r.L.dspRuntimeRelease()
+
+
 if __name__ == "__main__":
+    if "single" in sys.argv[1:]:
+        single_frame()
+        sys.exit(0)
     if "program" in sys.argv[1:]:
         program_level()
         sys.exit(0)
