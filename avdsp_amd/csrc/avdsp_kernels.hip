@@ -2426,6 +2426,8 @@ struct avdsp_hip_prog {
     unsigned *d_frame = nullptr; int frame_words = 0;     /* samples[] frame of the general interpreter */
     std::vector<Plan> plans;
     unsigned *d_in = nullptr, *d_out = nullptr; size_t in_cap = 0, out_cap = 0;   /* host-call staging */
+    static constexpr int kSmallWords = 4096;             /* host calls of up to that many sample words (dspRuntime_N) ... */
+    unsigned *h_small = nullptr, *d_small = nullptr;     /* ... go through a pinned area the kernels access in place */
     /* optional per-kernel timing with HIP events on the launch stream (avdsp_hip_profile_*) */
     int num_cus = 0;                    /* compute units of the device (fir_stream's grid) */
     unsigned profile = 0;               /* bit k: time the launches of kind k (AVDSP_KERNEL_*) */
@@ -2866,6 +2868,7 @@ void avdsp_hip_prog_destroy(avdsp_hip_prog *p)
     if (p->ev_unpack) (void)hipEventDestroy(p->ev_unpack);
     for (int i = 0; i < avdsp_hip_prog::kAhead; i++) { if (p->ev_bq[i]) (void)hipEventDestroy(p->ev_bq[i]); if (p->ev_fir[i]) (void)hipEventDestroy(p->ev_fir[i]); }
     (void)hipFree(p->d_buf); (void)hipFree(p->d_in); (void)hipFree(p->d_out); (void)hipFree(p->d_tpdf); (void)hipFree(p->d_frame);
+    (void)hipHostFree(p->h_small);
     (void)hipFree(p->d_tpdf_seq);
     delete p;
 }
@@ -3554,6 +3557,22 @@ int avdsp_hip_run_block_host(avdsp_hip_prog *prog, int plan, const void *h_in, i
         }
         HIP_TRY(hipStreamSynchronize(prog->s_d2h));
         HIP_TRY(hipStreamSynchronize(prog->s_run));
+        return 0;
+    }
+    /* A frame or a few (dspRuntime_N: one): three synchronous copies would be most of the call.  The samples go through a small
+     * pinned area the kernels read and write in place over PCIe -- a handful of words each way. */
+    if (in_words + out_words <= avdsp_hip_prog::kSmallWords) {
+        if (!prog->h_small) {
+            HIP_TRY(hipHostMalloc((void **)&prog->h_small, (size_t)avdsp_hip_prog::kSmallWords * 4, hipHostMallocMapped));
+            HIP_TRY(hipHostGetDevicePointer((void **)&prog->d_small, prog->h_small, 0));
+        }
+        unsigned *hi = prog->h_small, *ho = prog->h_small + in_words;
+        memcpy(hi, h_in, in_words * 4);
+        memcpy(ho, h_out, out_words * 4);                   /* unstored slots keep their content */
+        if (avdsp_hip_run_block(prog, plan, prog->d_small, in_stride, in_io_base, prog->d_small + in_words, out_stride, out_io_base,
+                                nframes, fir_impl, biquad_impl, nullptr)) return -1;
+        HIP_TRY(hipDeviceSynchronize());
+        memcpy(h_out, ho, out_words * 4);
         return 0;
     }
     HIP_TRY(hipMemcpy(prog->d_in, h_in, in_words * 4, hipMemcpyHostToDevice));
