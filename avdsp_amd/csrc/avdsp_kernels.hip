@@ -816,13 +816,18 @@ __global__ __launch_bounds__(kBlock) void biquad_row(const BiquadArgs a)
         return q2 ? hi : lo;
     };
     /* any batch, any chain: the general way */
+    const bool one_store = (rr.flags >> 16 & 0xFF) == 1;
     auto flush = [&](int u0, unsigned w) __attribute__((always_inline)) {
         const int n = u0 + rp - (1 + 2 * L);
         if (have_chain && n >= 0 && n < B) {
             if (to_ring) ring_put(ring_l, cid, n, w);
             else {
-                const avdsp_chain oc = a.chains[cid];
-                emit_out(io_l, oc, n, c_sat ? __float_as_uint(saturate_f32_0db(__uint_as_float(w))) : w);
+                const unsigned v = c_sat ? __float_as_uint(saturate_f32_0db(__uint_as_float(w))) : w;
+                if (one_store) io_l.out[(size_t)n * io_l.out_stride + (rr.out_io - io_l.out_base)] = v;     /* (the record has the column: no look at the chain) */
+                else {
+                    const avdsp_chain oc = a.chains[cid];
+                    emit_out(io_l, oc, n, v);
+                }
             }
         }
     };
@@ -1074,8 +1079,11 @@ __global__ __launch_bounds__(kBlock) void biquad_row_i64(const BiquadArgs a)
     auto flush = [&](int u0, unsigned w) __attribute__((always_inline)) {
         const int n = u0 + rp - (1 + 2 * L);
         if (have_chain && n >= 0 && n < B) {
-            const avdsp_chain oc = a.chains[cid];
-            emit_out(io_l, oc, n, w);
+            if ((rr.flags >> 16 & 0xFF) == 1) io_l.out[(size_t)n * io_l.out_stride + (rr.out_io - io_l.out_base)] = w;   /* (the record has the column) */
+            else {
+                const avdsp_chain oc = a.chains[cid];
+                emit_out(io_l, oc, n, w);
+            }
         }
     };
     const bool lean = __ballot(have_chain && (rr.flags >> 16 & 0xFF) != 1) == 0;

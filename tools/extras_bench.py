@@ -105,8 +105,14 @@ def program_level():
                 e1.record()
                 torch.cuda.synchronize()
                 res[mode] = e0.elapsed_time(e1) * 1e3 / reps / frames
+            r.set_option("profile", 1)
+            for k in (3, 5, 6): r.kernel_time(k)
+            once(); torch.cuda.synchronize()
+            kt = {k: r.kernel_time(k) for k in (3, 5, 6)}
+            r.set_option("profile", 0)
             print(f"program {name:18s} fmt {fmt} block {frames:5d}: per core {res['per core']:6.3f} us/frame, "
-                  f"BlockAll {res['all']:6.3f} us/frame ({r.get_option('cores')} cores in {r.get_option('levels')} levels)", flush=True)
+                  f"BlockAll {res['all']:6.3f} us/frame ({r.get_option('cores')} cores in {r.get_option('levels')} levels, {r.get_option('pieces')} pieces; "
+                  f"launches of one call: frame-parallel {kt[5][1]} = {kt[5][0] * 1e3 / frames:.3f} us/frame, frame by frame {kt[3][1]}, strand plans {kt[6][1]})", flush=True)
             r.set_option("strand_lanes", 1)
             r.L.dspRuntimeRelease()
 

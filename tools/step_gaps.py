@@ -29,6 +29,12 @@ for k, v in dur.items():
 for k, v in gaps.items():
     if v:
         print(f"gap {k}: median {np.median(v) / 1e3:.1f} us, p10 {np.percentile(v, 10) / 1e3:.1f}, p90 {np.percentile(v, 90) / 1e3:.1f}")
+# the overlap mode: the FIRs follow each other on the caller's stream, the cascades run beside them
+firs = [(s_, e_) for s_, e_, n_ in rows if short(n_) == "fir"]
+if len(firs) > 8:
+    ff = [b[0] - a[1] for a, b in zip(firs[:-1], firs[1:])]
+    st = [b[0] - a[0] for a, b in zip(firs[:-1], firs[1:])]
+    print(f"fir end -> next fir start: median {np.median(ff) / 1e3:.1f} us (p10 {np.percentile(ff, 10) / 1e3:.1f}, p90 {np.percentile(ff, 90) / 1e3:.1f}); fir start -> next fir start {np.median(st) / 1e3:.1f} us")
 # a few consecutive launches in full, relative times
 t0 = rows[0][0]
 print("start_us  end_us  dur_us  kernel")
