@@ -58,6 +58,7 @@ typedef struct {
     opcode_t   *core;            /* key: the pointer the host passes (after dspFindCoreBegin) */
     int         format;
     int         end_word;        /* 0: the whole core; else a strand group [core, end_word) of it */
+    int         skip_from;       /* ... that leaves [skip_from, skip_to) out (0: nothing) */
     int         plan_id;         /* id inside the device program, < 0 = lowering failed */
     int         nchains, max_sections, max_taps;      /* nchains 0 = general interpreter */
     int         total_chains, first_chain;            /* chain cores: the core has total_chains, this process runs
@@ -89,6 +90,7 @@ typedef struct avdsp_ctx {
     int             device_selected;
     int             last_levels, last_cores, last_pieces;  /* of the latest dspRuntimeBlockAll: dspRuntimeGetOption("levels" / "cores" / "pieces") */
     int             opt_strand_split, next_tpdf_role;
+    int             next_skip_from, next_skip_to;          /* the piece being scanned / planned leaves [from, to) out (0: nothing) */
     int             opt_strand_lanes;                      /* uniform strand runs of an interpreted core on lanes (strand_lower) */
     const avdsp_strand_desc *next_strands;                 /* get_plan_range attaches this to the plan it makes */
     int             last_strands;                          /* strands of the latest dspRuntimeBlockAll arrangement that run on lanes */
@@ -1136,8 +1138,10 @@ static int scan_generic(int format, opcode_t *core, int end_word, avdsp_generic_
         }
         if (rc) { free(smap); return g_err_code; }
         p += skip;
+        if (G.next_skip_from && (int)(p - G.code) == G.next_skip_from) p = G.code + G.next_skip_to;      /* a piece that leaves a stretch out */
     }
     free(smap);
+    d->skip_from = G.next_skip_from; d->skip_to = G.next_skip_from ? G.next_skip_to : 0;
     d->dither_only = nreal == 1 && S.w.tpdf_calc_seen;
     if (d->io_span == 0) d->io_span = 1;
     if (d->io_span > WAVE_IO_LIMIT) S.w.ok = S.w.complete = 0;
@@ -1191,7 +1195,7 @@ static core_plan *get_plan_range(int format, opcode_t *core, int end_word)
     /* one key per core: a host may pass the DSP_CORE word or the first executable word behind it */
     if (!end_word) core = dspFindCoreBegin(core);
     for (int i = 0; i < G.nplans; i++)
-        if (G.plans[i].core == core && G.plans[i].format == format && G.plans[i].end_word == end_word) {
+        if (G.plans[i].core == core && G.plans[i].format == format && G.plans[i].end_word == end_word && G.plans[i].skip_from == G.next_skip_from) {
             if (G.plans[i].plan_id < 0 && !G.plans[i].empty) { fail(-8, "core was refused earlier"); return 0; }
             return &G.plans[i];
         }
@@ -1239,7 +1243,7 @@ static core_plan *get_plan_range(int format, opcode_t *core, int end_word)
         }
     }
     core_plan *cp = &G.plans[G.nplans];
-    cp->core = core; cp->format = format; cp->end_word = end_word;
+    cp->core = core; cp->format = format; cp->end_word = end_word; cp->skip_from = G.next_skip_from;
     cp->nchains = 0; cp->max_sections = 0; cp->max_taps = 0;
     cp->total_chains = 0; cp->first_chain = 0; cp->empty = 0;
     cp->deps = deps;
@@ -1551,7 +1555,7 @@ static int split_core(opcode_t *core, int *starts)
         p += skip;
     }
     starts[0] = (int)(p0 - G.code);
-    if (n < 8) return 1;
+    if (n < 4) return 1;
     /* legal cuts */
     int ncut = 0;
     for (int i = 1; i < n; i++) {
@@ -1565,8 +1569,22 @@ static int split_core(opcode_t *core, int *starts)
         if (legal) cut[ncut++] = i;
     }
     if (!ncut) return 1;
-    /* pieces of at least 4 opcodes, at most MAX_GROUPS of them, as even as the cuts allow */
-    int groups = n / 4;
+    /* Pieces worth a wave of their own, at most MAX_GROUPS of them, as even as the cuts allow.  What a piece costs is its
+     * opcodes whose state runs from frame to frame (a cascade or a FIR is 100 ns per frame, a gain or a store 4: tools/interp_opcost.py),
+     * so those count four: a strand of LOAD_GAIN, BIQUADS, STORE_MEM is a piece (dacdiy1.bin's first core: two of them, 0.23 -> 0.13 us). */
+    static int wsum[MAXOPS + 1];
+    wsum[0] = 0;
+    for (int i = 0; i < n; i++) {
+        int w = 1;
+        switch (op[i]) {
+        case DSP_BIQUADS: case DSP_FIR: case DSP_RMS: case DSP_DCBLOCK: case DSP_DITHER: case DSP_DITHER_NS2:
+        case DSP_DISTRIB: case DSP_SINE: case DSP_TPDF_CALC: w = 4; break;
+        }
+        wsum[i + 1] = wsum[i] + w;
+    }
+#define PIECE_W(lo, hi) (wsum[hi] - wsum[lo])
+    if (wsum[n] < 8) return 1;
+    int groups = wsum[n] / 4;
     if (groups > MAX_GROUPS) groups = MAX_GROUPS;
     if (groups > ncut + 1) groups = ncut + 1;
     int ng = 1, last = 0;
@@ -1575,17 +1593,18 @@ static int split_core(opcode_t *core, int *starts)
     for (int i = 0; i < n; i++)
         if (op[i] == DSP_TPDF_CALC) {
             for (int c = 0; c < ncut; c++)
-                if (cut[c] > i) { if (n - cut[c] >= 4) { starts[ng++] = at[cut[c]]; last = cut[c]; } break; }
+                if (cut[c] > i) { if (PIECE_W(cut[c], n) >= 4) { starts[ng++] = at[cut[c]]; last = cut[c]; } break; }
             break;
         }
     for (int g = 1; g < groups && ng < MAX_GROUPS; g++) {
-        const int want = (int)((long long)n * g / groups);
+        const int want = (int)((long long)wsum[n] * g / groups);
         int best = -1;
-        for (int c = 0; c < ncut; c++) if (cut[c] >= want && cut[c] > last) { best = cut[c]; break; }
-        if (best < 0 || n - best < 4 || best - last < 4) continue;
+        for (int c = 0; c < ncut; c++) if (wsum[cut[c]] >= want && cut[c] > last) { best = cut[c]; break; }
+        if (best < 0 || PIECE_W(best, n) < 4 || PIECE_W(last, best) < 4) continue;
         starts[ng++] = at[best];
         last = best;
     }
+#undef PIECE_W
     return ng;
 }
 
@@ -1827,10 +1846,11 @@ static int find_strand_run(int format, opcode_t *begin, int *run_word, int *end_
     return -8;
 }
 
-/* A wave at lane = strand costs the same for 2 strands as for 64, and a strand's cheap opcodes cost it ten times what they cost the
- * frame-parallel interpreter: below four strands the interpreter's strand groups are as fast (dacdiy1.bin: 0.56 us per frame either
- * way, per-core calls 0.86 against 1.32).  "strand_lanes" 2 lowers every run there is. */
-static int strand_lanes_from(void) { return G.opt_strand_lanes >= 2 ? 2 : 4; }
+/* A wave at lane = strand costs the same for 2 strands as for 64 (0.39 us per frame for a strand of gains, a cascade, a delay line and
+ * a dithered store), and a strand's cheap opcodes cost it ten times what they cost the frame-parallel interpreter, which gives up to
+ * 64 strand groups a wave each: 16 such strands 0.23 us per frame there against 0.46 on lanes, 100 strands (two per group) 0.52
+ * against 0.45 (tools/wide_core_bench.py).  So: runs of more than 64 strands; "strand_lanes" 2 lowers every run there is. */
+static int strand_lanes_from(void) { return G.opt_strand_lanes >= 2 ? 2 : 65; }
 
 /* Host-only: would the core's tail run as a strand plan?  strands = 0: no.  (prefix_words: opcode words in front of the run that
  * stay with the interpreter; ops: micro-operations per strand) */
@@ -1853,6 +1873,39 @@ int dspRuntimeStrandInfo(int format, opcode_t *core, int *strands, int *ops, int
     if (prefix_words) *prefix_words = rc ? 0 : w - (int)(begin - G.code);
     if (!rc) strand_free(&S);
     return 0;
+}
+
+/* Is the stretch [start, end) one strand of the shape  LOAD | LOAD_GAIN | LOAD_MEM, COPYXY, <way 1>, SWAPXY, <way 2>  with both ways made of
+ * opcodes that work on X alone (gains, cascades, FIRs, delay lines, saturation, stores) and each holding a cascade or a FIR (else the
+ * fork is not worth a wave)?  Then way 2 sees exactly the load's value (the copy in Y, untouched by way 1) and nothing of way 1, and the
+ * Y it leaves behind is never read (the strand ends the piece, and a piece ends at a legal cut).  Words of the COPYXY, the SWAPXY and
+ * the opcode behind it are returned. */
+static int two_way_fork(int start, int end, int *copy_word, int *swap_word, int *after_word)
+{
+    int i = 0, heavy1 = 0, heavy2 = 0, seen_swap = 0;
+    for (int w = start; w < end;) {
+        const opcode_t *p = G.code + w;
+        const int op = p->op.opcode; const unsigned skip = p->op.skip;
+        if (skip == 0 || op == DSP_CORE || op == DSP_END_OF_CODE) break;
+        if (op != DSP_NOP && op != DSP_PARAM && op != DSP_PARAM_NUM && op != DSP_SERIAL) {
+            if (i == 0) { if (op != DSP_LOAD && op != DSP_LOAD_GAIN && op != DSP_LOAD_MEM) return 0; }
+            else if (i == 1) { if (op != DSP_COPYXY) return 0; *copy_word = w; }
+            else if (op == DSP_SWAPXY) {
+                if (seen_swap) return 0;
+                seen_swap = 1; *swap_word = w; *after_word = w + (int)skip;
+            } else {
+                switch (op) {
+                case DSP_BIQUADS: case DSP_FIR: if (seen_swap) heavy2 = 1; else heavy1 = 1; break;
+                case DSP_GAIN: case DSP_DELAY: case DSP_DELAY_DP: case DSP_SHIFT: case DSP_NEGX: case DSP_STORE:
+                case DSP_SAT0DB: case DSP_SAT0DB_TPDF: case DSP_SAT0DB_GAIN: case DSP_SAT0DB_TPDF_GAIN: break;
+                default: return 0;
+                }
+            }
+            i++;
+        }
+        w += (int)skip;
+    }
+    return seen_swap && heavy1 && heavy2 && *after_word < end;
 }
 
 /* one core -> its pieces (or itself), appended to cp[] */
@@ -1934,15 +1987,47 @@ static int expand_core(int format, opcode_t *c, core_plan **cp, int *pn)
         }
     }
     const int pd_calc_first = ng > 1 && pd[0].tpdf_calc;           /* the first piece holds the TPDF_CALC: it publishes */
-    if (ng <= 1) {
+    /* Two-way strands: LOAD.., COPYXY, <first way>, SWAPXY, <second way> -- the second way works on the copy of the load's value
+     * and never looks at the first way's result, so it is a piece of its own: the load again, then what follows the SWAPXY
+     * (two_way_fork; the piece leaves [COPYXY .. SWAPXY] out).  crossoverLV6.bin's second core: its two cascades side by side. */
+    typedef struct { int start, end, skip_from, skip_to; } piece_t;
+    static piece_t pc[MAX_GROUPS * 2 + 2];
+    int np = 0;
+    const int interpreted = whole->total_chains == 0 && !whole->empty && G.opt_strand_split;
+    starts[ng] = dspHeaderPtr->totalLength;
+    for (int g = 0; g < ng; g++) {
+        const int ps = ng > 1 ? starts[g] : (int)(begin - G.code), pe = ng > 1 ? starts[g + 1] : dspHeaderPtr->totalLength;
+        int cw = 0, sw = 0, aw = 0;
+        if (interpreted && np + 2 <= MAX_GROUPS * 2 && G.nplans + np + 4 < MAX_CORE_PLANS && n + np + 4 < MAX_CORE_PLANS &&
+            two_way_fork(ps, pe, &cw, &sw, &aw)) {
+            /* both ways scanned as pieces: they must be strangers like any two pieces of a core */
+            static core_deps da, db;
+            avdsp_generic_desc gd;
+            int ok = !scan_generic(format, G.code + ps, sw, &gd, &da);
+            if (ok) {
+                G.next_skip_from = cw; G.next_skip_to = aw;
+                ok = !scan_generic(format, G.code + ps, pe, &gd, &db);
+                G.next_skip_from = G.next_skip_to = 0;
+            }
+            if (ok && !cores_meet_ex(&da, &db, 1)) {
+                pc[np++] = (piece_t){ps, sw, 0, 0};
+                pc[np++] = (piece_t){ps, pe, cw, aw};
+                continue;
+            }
+            g_err[0] = 0;
+        }
+        pc[np++] = (piece_t){ps, pe, 0, 0};
+    }
+    if (np <= 1) {
         if (n == MAX_CORE_PLANS) return fail(-9, "too many cores");
         if (!whole->empty) cp[n++] = whole;                    /* a shard without chains of this core: nothing to run */
     } else
-        for (int g = 0; g < ng; g++) {
+        for (int g = 0; g < np; g++) {
             if (n == MAX_CORE_PLANS) return fail(-9, "too many cores");
             G.next_tpdf_role = pd_calc_first ? (g == 0 ? 1 : 2) : 0;
-            cp[n] = get_plan_range(format, G.code + starts[g], g + 1 < ng ? starts[g + 1] : dspHeaderPtr->totalLength);
-            G.next_tpdf_role = 0;
+            G.next_skip_from = pc[g].skip_from; G.next_skip_to = pc[g].skip_to;
+            cp[n] = get_plan_range(format, G.code + pc[g].start, pc[g].end);
+            G.next_tpdf_role = 0; G.next_skip_from = G.next_skip_to = 0;
             if (!cp[n]) return g_err_code;
             n++;
         }

@@ -3035,6 +3035,9 @@ int avdsp_hip_prog_add_generic(avdsp_hip_prog *prog, const avdsp_generic_desc *d
     GenericArgs &a = pl.ga;
     a.buf = prog->d_buf; a.tpdf = prog->d_tpdf;
     a.core_word = d->core_word; a.prog_words = d->prog_words; a.end_word = d->end_word;
+    if (d->skip_from && (d->skip_from <= d->core_word || d->skip_to <= d->skip_from || d->skip_to >= d->prog_words))
+        return set_err("generic plan: skipped stretch [%d, %d) outside the piece", d->skip_from, d->skip_to);
+    a.skip_from = d->skip_from; a.skip_to = d->skip_to;
     a.freq_index = d->freq_index; a.num_freq = d->num_freq;
     a.biquad_skip = d->biquad_freq_skip; a.biquad_offset = d->biquad_freq_offset;
     a.delay_factor = d->delay_line_factor;

@@ -86,6 +86,9 @@ typedef struct avdsp_generic_desc {
     int32_t  tpdf_calc;              /* the core holds the DSP_TPDF_CALC: it alone writes the dither globals     */
     int32_t  tpdf_role;              /* pieces of a core cut into strand groups: 1 = the piece with the TPDF_CALC leaves
                                         every frame's dither value for the later pieces (2) of that core; 0 otherwise    */
+    int32_t  skip_from, skip_to;     /* a piece that leaves a stretch of its range out: execution jumps from opcode word skip_from
+                                        to skip_to (the second way of a two-way strand: its load, then what follows the SWAPXY);
+                                        0 = nothing left out                                                                   */
     int32_t  dither_only;            /* the stretch is a DSP_TPDF_CALC and nothing else (the piece in front of a strand run):  */
     int32_t  dither_arg, dither_result_word;   /* its dither width word and the mirror word its result goes to (tpdf_walk)   */
 } avdsp_generic_desc;

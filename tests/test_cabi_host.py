@@ -230,14 +230,20 @@ def test_failed_loads_leave_no_context_behind():
 
 def test_strand_info_reports_what_lowers():
     """host-only: dspRuntimeStrandInfo -- the run of identical strands a core ends in, the opcode words in front of it, and the
-    four-strand floor ("strand_lanes" 2 lowers shorter runs too, 0 none)"""
+    floor of 65 strands ("strand_lanes" 2 lowers shorter runs too, 0 none)"""
     from tests.test_gpu_strands import crossover_program
     r = rt.Runtime(6, crossover_program(12, 6, "dither"), fs=48000, dither=24)
     try:
+        assert r.strand_info(0)["strands"] == 0                 # up to 64 strands: the interpreter's strand groups are faster
+        r.set_option("strand_lanes", 2)
         info = r.strand_info(0)
         assert info["strands"] == 12 and info["ops"] == 6 and info["prefix_words"] > 0      # the TPDF_CALC stays in front
         r.set_option("strand_lanes", 0)
         assert r.strand_info(0)["strands"] == 0
+        r.set_option("strand_lanes", 1)
+        r.release()
+        r = rt.Runtime(6, crossover_program(100, 6, "dither"), fs=48000, dither=24)
+        assert r.strand_info(0)["strands"] == 100
     finally:
         r.set_option("strand_lanes", 1)
         r.release()

@@ -73,7 +73,7 @@ def test_strand_run_matches_the_oracle(fmt, shape, nch):
     x = pb.lcg_input(sum(blocks), nch, fmt in (5, 6), seed=3 + nch)
     o = po.OracleProgram(fmt, prog, fs=48000, random=1, dither=24)
     want = np.concatenate([o.run_block(x[a:a + n], nout, 128) for a, n in zip(np.cumsum([0] + blocks[:-1]), blocks)])
-    for lanes in (1, 0):
+    for lanes in (2, 0):                             # 2: every run on lanes (the default keeps runs of up to 64 strands with the interpreter)
         r = rt.Runtime(fmt, prog, fs=48000, random=1, dither=24)
         r.set_option("strand_lanes", lanes)
         got = np.concatenate([r.run_block_all(x[a:a + n], nout, 128) for a, n in zip(np.cumsum([0] + blocks[:-1]), blocks)])
@@ -93,6 +93,7 @@ def test_per_core_entry_point_and_window_fallback():
     o = po.OracleProgram(fmt, prog, fs=48000, random=1, dither=24)
     want = o.run_block(x, nch, 128)
     r = rt.Runtime(fmt, prog, fs=48000, random=1, dither=24)
+    r.set_option("strand_lanes", 2)
     got = r.run_block(x, nch, 128)
     assert r.get_option("strands") == nch
     assert (words(got) == words(want)).all()
@@ -104,6 +105,7 @@ def test_per_core_entry_point_and_window_fallback():
     got2 = r2.run_block(row, 140, 0, 0)
     assert (words(got2) == words(want2)).all()
     assert (r2.sync_state() == o2.state).all()
+    r2.set_option("strand_lanes", 1)
 
 
 def test_reference_programs_find_their_runs():
@@ -112,7 +114,7 @@ def test_reference_programs_find_their_runs():
     x = pb.lcg_input(256, 16, False, seed=5)
     o = po.OracleProgram(2, prog, fs=48000, random=1, dither=24)
     want = o.run_block(x, 32, 8, 0)
-    for lanes, strands in ((2, 6), (1, 0)):        # runs of two strands stay with the interpreter unless asked for ("strand_lanes" 2)
+    for lanes, strands in ((2, 6), (1, 0)):        # short runs stay with the interpreter unless asked for ("strand_lanes" 2)
         o = po.OracleProgram(2, prog, fs=48000, random=1, dither=24)
         want = o.run_block(x, 32, 8, 0)
         r = rt.Runtime(2, prog, fs=48000, random=1, dither=24)

@@ -493,3 +493,25 @@ def test_block_all_on_wide_and_nan_heavy_random_programs(seed, switch, monkeypat
         fs, block = [48000, 48000, 96000][seed % 3], [5, 64, 150][seed % 3]
         x = pb.lcg_input(150, fz.N_IN, fmt in (5, 6), seed=seed)
         _all_vs_per_core(fmt, prog, x, fz.N_OUT, fz.IN_BASE, 0, block, fs=fs, seed=seed)
+
+
+@pytest.mark.parametrize("fmt", [2, 3, 4, 5, 6])
+def test_two_way_strands_fork_into_two_pieces(fmt):
+    """LOAD, COPYXY, <way 1>, SWAPXY, <way 2> (crossoverLV6.bin's second core): way 2 only needs the load's value, so it runs as a
+    piece of its own -- the load again, then what follows the SWAPXY -- beside way 1.  The subtractive shape (way 2 takes Y - X)
+    must stay in one piece.  Both against the oracle, outputs and state, blocks around the batch size."""
+    from tests.test_gpu_strands import crossover_program
+    for shape, nch, pieces in (("two_way", 3, 1 + 2 * 3), ("subtractive", 3, 1 + 3)):
+        prog = crossover_program(nch, fmt, shape)
+        x = pb.lcg_input(300, nch, fmt in (5, 6), seed=31)
+        o = po.OracleProgram(fmt, prog, fs=48000, random=3, dither=24)
+        blocks = [1, 64, 100, 135]
+        want = np.concatenate([o.run_block(x[a:a + n], 2 * nch, 128) for a, n in zip(np.cumsum([0] + blocks[:-1]), blocks)])
+        r = rt.Runtime(fmt, prog, fs=48000, random=3, dither=24)
+        try:
+            got = np.concatenate([r.run_block_all(x[a:a + n], 2 * nch, 128) for a, n in zip(np.cumsum([0] + blocks[:-1]), blocks)])
+            assert r.get_option("pieces") == pieces, (shape, r.get_option("pieces"))
+            assert (got.view(np.uint32) == want.view(np.uint32)).all(), (fmt, shape)
+            assert (r.sync_state() == o.state).all(), (fmt, shape)
+        finally:
+            r.release()
