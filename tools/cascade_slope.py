@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Where does the cascade kernel's time go?  Launch time of biquad_pipe against frames per block (the slope is the cost of a
+"""Where does the cascade kernel's time go?  Launch time of the cascade kernel (biquad_row / biquad_row_i64 by default) against frames per block (the slope is the cost of a
 step, the intercept what a launch costs besides stepping: loading coefficients and state, the pipeline's fill, the state
 write-back) and against channels (waves per SIMD).   python tools/cascade_slope.py [fmt]"""
 import os
