@@ -54,6 +54,7 @@ for fmt in (2, 6):
     prev = 0.0
     for upto, name in enumerate(STEPS):
         r = rt.Runtime(fmt, program(nch, fmt, upto), fs=48000, random=1, dither=24)
+        r.set_option("strand_lanes", 2)
         st = torch.cuda.current_stream().cuda_stream
         call = lambda: r._check(r.L.dspRuntimeBlockAllDevice(fmt, r.rundata, x.data_ptr(), nch, nch, y.data_ptr(), nch, 0, frames, st))
         for _ in range(3): call()
@@ -73,4 +74,5 @@ for fmt in (2, 6):
             if r.L.avdsp_hip_debug_bq_stamps(buf.ctypes.data, 1) == 1:
                 t = buf.astype(np.int64); k = int(np.count_nonzero(t))
                 print("      cycles per operation of one batch of 16 frames (s_memtime): " + " ".join(str(int(v)) for v in np.diff(t[:k])), flush=True)
+        r.set_option("strand_lanes", 1)
         r.L.dspRuntimeRelease()
