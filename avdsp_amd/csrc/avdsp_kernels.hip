@@ -2418,7 +2418,7 @@ struct Plan {
     int *d_lane_rows = nullptr; int n_lane_rows = 0;     /* ... chain_rows' chains (1 .. 16 sections) */
     int n_lane_fir = 0; unsigned *d_lseq = nullptr; int lseq_pitch = 0;      /* ... and fir_lane's sequence buffer: [nchains][max_taps - 1 + frames of the largest block so far] */
     /* strand plan attached to a generic plan (include/avdsp_hip.h): the stretch as micro-operations, one argument row per strand */
-    avdsp_strand_op *d_sops = nullptr; int *d_sargs = nullptr; int s_nops = 0, s_nargs = 0, s_nstrands = 0, s_nres = 0;
+    avdsp_strand_op *d_sops = nullptr; int *d_sargs = nullptr; int s_nops = 0, s_nargs = 0, s_nstrands = 0, s_nres = 0; bool s_usey = false;
     std::vector<int> s_loaded, s_stored;                 /* the IOs the strands load / store: per call against the windows */
     bool stores_whole_window = false;                    /* every IO of [io_out_min, io_out_max] is stored by some chain */
     bool overlap_ok = false;                             /* every cascade of the plan feeds a FIR: its launches may run under the previous block's FIR */
@@ -3162,8 +3162,15 @@ int avdsp_hip_plan_add_strands(avdsp_hip_prog *prog, int plan, const avdsp_stran
         const int aw = (pl.format == 3 || pl.format == 5) ? 1 : 2;
         for (auto &o : ops) { if (o.rcol != nres) return set_err("strand plan: resolved columns are not laid out in order"); nres += avdsp_strand_rcols(o.op, o.imm, aw); }
         if (nres != d->nres || nres > 224) return set_err("strand plan: %d resolved columns (the kernel's table holds 224)", nres);
-        const void *fns[5] = {(const void *)strand_lanes<2>, (const void *)strand_lanes<3>, (const void *)strand_lanes<4>, (const void *)strand_lanes<5>, (const void *)strand_lanes<6>};
-        const hipError_t e = hipFuncSetAttribute(fns[pl.format - 2], hipFuncAttributeMaxDynamicSharedMemorySize, 224 * 256 + 8192 + 64 + kStrandMaxOps * (int)sizeof(avdsp_strand_op));
+        pl.s_usey = false;                               /* does any operation read Y?  (else the kernel does not keep it) */
+        for (auto &o : ops)
+            pl.s_usey = pl.s_usey || o.op == AVDSP_SOP_COPYYX || o.op == AVDSP_SOP_SWAPXY || o.op == AVDSP_SOP_ADDXY || o.op == AVDSP_SOP_ADDYX ||
+                        o.op == AVDSP_SOP_SUBXY || o.op == AVDSP_SOP_SUBYX;
+        const void *fns[10] = {(const void *)strand_lanes<2, false>, (const void *)strand_lanes<3, false>, (const void *)strand_lanes<4, false>,
+                               (const void *)strand_lanes<5, false>, (const void *)strand_lanes<6, false>,
+                               (const void *)strand_lanes<2, true>, (const void *)strand_lanes<3, true>, (const void *)strand_lanes<4, true>,
+                               (const void *)strand_lanes<5, true>, (const void *)strand_lanes<6, true>};
+        const hipError_t e = hipFuncSetAttribute(fns[pl.format - 2 + (pl.s_usey ? 5 : 0)], hipFuncAttributeMaxDynamicSharedMemorySize, 224 * 256 + 8192 + 64 + kStrandMaxOps * (int)sizeof(avdsp_strand_op));
         if (e != hipSuccess) return set_err("hipFuncSetAttribute(strand_lanes LDS): %s", hipGetErrorString(e));
     }
     pl.s_nops = d->nops; pl.s_nargs = d->nargs; pl.s_nstrands = d->nstrands; pl.s_nres = d->nres;
@@ -3269,13 +3276,17 @@ static int launch_generic(avdsp_hip_prog *prog, Plan &pl, BlockIO io, hipStream_
         }
 #endif
         const dim3 sgrid((pl.s_nstrands + 63) / 64), sblock(64);
+#define AVDSP_LAUNCH_STRANDS(F) \
+        if (pl.s_usey) hipLaunchKernelGGL((strand_lanes<F, true>), sgrid, sblock, slds, stream, sa); \
+        else           hipLaunchKernelGGL((strand_lanes<F, false>), sgrid, sblock, slds, stream, sa)
         switch (pl.format) {
-        case 2:  hipLaunchKernelGGL((strand_lanes<2>), sgrid, sblock, slds, stream, sa); break;
-        case 3:  hipLaunchKernelGGL((strand_lanes<3>), sgrid, sblock, slds, stream, sa); break;
-        case 4:  hipLaunchKernelGGL((strand_lanes<4>), sgrid, sblock, slds, stream, sa); break;
-        case 5:  hipLaunchKernelGGL((strand_lanes<5>), sgrid, sblock, slds, stream, sa); break;
-        default: hipLaunchKernelGGL((strand_lanes<6>), sgrid, sblock, slds, stream, sa); break;
+        case 2:  AVDSP_LAUNCH_STRANDS(2); break;
+        case 3:  AVDSP_LAUNCH_STRANDS(3); break;
+        case 4:  AVDSP_LAUNCH_STRANDS(4); break;
+        case 5:  AVDSP_LAUNCH_STRANDS(5); break;
+        default: AVDSP_LAUNCH_STRANDS(6); break;
         }
+#undef AVDSP_LAUNCH_STRANDS
         HIP_TRY(hipGetLastError());
         return 0;
     }
