@@ -463,3 +463,14 @@ def test_float_accumulator_models_on_chain_lane(fmt, channels, sections, taps):
         r.set_shard(0, 1)
         assert (got.view(np.uint32) == want.view(np.uint32)).all()
         assert (r.sync_state() == o.state).all()
+
+
+@pytest.mark.parametrize("fmt", [3, 5])
+def test_float_accumulator_models_at_the_headline_geometry(fmt):
+    """the north-star chain shape (16 sections + 4096 taps, blocks of 1024 frames) on 100 chains in DSP_FORMAT 3 / 5: chain_rows feeding
+    fir_lane through the sequence buffer, two full blocks and a ragged one, state carried -- against the oracle bit for bit"""
+    C = 100
+    prog = pb.synth_program(fmt, C, 16, 4096)
+    blocks = [1024, 1024, 333]
+    x = pb.lcg_input(sum(blocks), C, fmt == 5, seed=77)
+    _oracle_vs_device(fmt, prog, x, C, C, blocks).release()
