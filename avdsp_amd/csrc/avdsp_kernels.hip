@@ -2220,6 +2220,7 @@ __global__ __launch_bounds__(64) void chain_lane(const LaneArgs a)
     if (cid >= a.nchains) return;
     const avdsp_chain c = a.chains[cid];
     if (a.rows_take && c.nsec >= 1 && c.nsec <= 16) return;                    /* chain_rows' */
+    if (a.seq && c.nsec == 0 && c.fir_taps) return;                            /* fir_lane_feed's: no cascade, every frame's input at once */
     const unsigned *inp = a.io.in + (c.in_io - a.io.in_base);
     for (int n = 0; n < a.io.nframes; n++) {
         const unsigned raw = inp[(size_t)n * a.io.in_stride];
@@ -2340,6 +2341,29 @@ __global__ __launch_bounds__(256) void fir_lane_history(const LaneArgs a)
     if (i < c.fir_taps - 1) a.seq[(size_t)cid * a.pitch + a.hist - 1 - i] = (unsigned)a.buf[c.fir_state_word + i];
 }
 
+/* chains that are a FIR and nothing in front of it: the block's inputs, converted (dsp_runtime.c:565-607), straight into the sequence
+ * buffer, a lane per (chain, frame) */
+template <int FMT>
+__global__ __launch_bounds__(256) void fir_lane_feed(const LaneArgs a)
+{
+    using namespace interp;
+    using alu_t = typename M<FMT>::alu;
+    flush_f32_subnormals_like_the_reference();
+    const int cid = blockIdx.x, n = blockIdx.y * 256 + threadIdx.x;
+    const avdsp_chain c = a.chains[cid];
+    if (c.nsec != 0 || c.fir_taps == 0 || n >= a.io.nframes) return;
+    const unsigned raw = a.io.in[(size_t)n * a.io.in_stride + (c.in_io - a.io.in_base)];
+    alu_t X;
+    if constexpr (M<FMT>::smp_int) {
+        if (c.load_mode == AVDSP_LOAD_GAIN) X = fmul<FMT>(int_to_float_scaled((int)raw, 31), __uint_as_float(c.gain_bits));
+        else X = from_int_scaled<FMT>((int)raw, 31);
+    } else {
+        X = to_alu<FMT>(__uint_as_float(raw));
+        if (c.load_mode == AVDSP_LOAD_GAIN) X *= to_alu<FMT>(__uint_as_float(c.gain_bits));
+    }
+    a.seq[(size_t)cid * a.pitch + a.hist + n] = __float_as_uint(to_sp<FMT>(X));
+}
+
 __global__ __launch_bounds__(256) void fir_lane_state(const LaneArgs a)
 {
     const int cid = blockIdx.x;
@@ -2354,13 +2378,23 @@ __global__ __launch_bounds__(kFirLaneFrames) void fir_lane(const LaneArgs a)
     using namespace interp;
     using alu_t = typename M<FMT>::alu;
     flush_f32_subnormals_like_the_reference();
-    __shared__ unsigned ws[kFirLaneChunk + kFirLaneFrames], cs[kFirLaneChunk];
+    /* Both operands of dspMulFloatFloat are taken apart ONCE, while they are staged (an input is multiplied by 256 x 2048 taps
+     * out of one workgroup's image, a tap by 256 frames): word 0 = the mantissa with its hidden bit in bits 0..23 and the sign in
+     * bit 31 (the 24-bit multiplies do not look above bit 23), word 1 = the biased exponent -- the tap's already less 127 -- or a
+     * large negative number for exponent 0, which sends the sum of the two below 1 like the reference's "operand or product too
+     * small: the accumulator stays" (interp::fmacc).  What is left per tap is dsp_ieee754.h:342-375's integer arithmetic, literally:
+     * exponent sum, sign into bit 8, 24 x 24 mantissa product >> 22, one normalising shift with its exponent step, pack, float add. */
+    __shared__ uint2 ws[kFirLaneChunk + kFirLaneFrames], cs[kFirLaneChunk];
     const int cid = blockIdx.x, t = threadIdx.x, n0 = blockIdx.y * kFirLaneFrames;
     const avdsp_chain c = a.chains[cid];
     const int T = c.fir_taps;
     if (T == 0) return;                                  /* (uniform: the whole workgroup is one chain's) */
     const unsigned *x = a.seq + (size_t)cid * a.pitch + a.hist;          /* x[m], m = -(T-1) .. nframes-1 */
-    alu_t acc = 0;
+    auto apart = [](unsigned w, int bias) -> uint2 {
+        const int e = (int)(w >> 23 & 255u);
+        return make_uint2((w & 0x807FFFFFu) | 0x800000u, (unsigned)(e ? e - bias : -4096));
+    };
+    float acc = 0.0f;
     for (int i0 = 0; i0 < T; i0 += kFirLaneChunk) {
         const int tc = min(kFirLaneChunk, T - i0);
         /* ws[k] = x[n0 - i0 - (tc - 1) + k], k < tc + 255: lane t's tap i0 + ii reads ws[t + tc - 1 - ii] */
@@ -2368,17 +2402,37 @@ __global__ __launch_bounds__(kFirLaneFrames) void fir_lane(const LaneArgs a)
         __syncthreads();
         for (int k = t; k < tc + kFirLaneFrames - 1; k += kFirLaneFrames) {
             const int m = base + k;
-            ws[k] = m < a.io.nframes ? x[m] : 0u;
+            ws[k] = apart(m < a.io.nframes ? x[m] : 0u, 0);
         }
-        for (int k = t; k < tc; k += kFirLaneFrames) cs[k] = (unsigned)a.buf[c.fir_coef_word + i0 + k];
+        for (int k = t; k < tc; k += kFirLaneFrames) cs[k] = apart((unsigned)a.buf[c.fir_coef_word + i0 + k], 127);
         __syncthreads();
-        const unsigned *w = ws + t + tc - 1;
+        const uint2 *w = ws + t + tc - 1;
+        const float acc0 = acc;
+        int emax = 0;
 #pragma unroll 4
-        for (int ii = 0; ii < tc; ii++) acc = fmacc<FMT>(acc, __uint_as_float(w[-ii]), __uint_as_float(cs[ii]));
+        for (int ii = 0; ii < tc; ii++) {
+            const uint2 xv = w[-ii], cv = cs[ii];
+            const int e = (int)xv.y + (int)cv.y;
+            const unsigned p = (unsigned)(((unsigned long long)(xv.x & 0xFFFFFFu) * (cv.x & 0xFFFFFFu)) >> 22);
+            const unsigned up = p >> 25 & 1u;                       /* the product reached 2: one more shift, one more in the exponent */
+            const unsigned e9 = ((unsigned)e | ((xv.x ^ cv.x) >> 23 & 0x100u)) + up;
+            const unsigned word = ((p >> (1u + up)) & 0x7FFFFFu) | (e9 << 23);
+            const float sum = acc + __uint_as_float(word);
+            acc = e >= 1 ? sum : acc;
+            emax = max(emax, e);
+        }
+        /* a product whose exponent field filled up can read as a NaN, and two NaNs add the SSE way in the reference (FF::operator+=):
+         * such a chunk -- no audio gets there -- is summed again through the interpreter's own fmacc on the words put back together */
+        if (__builtin_expect(__ballot(emax >= 254) != 0, 0)) {
+            alu_t A = FF(acc0);
+            auto whole = [](uint2 v, int bias) { const int e = (int)v.y; return (v.x & 0x807FFFFFu) | (unsigned)(e == -4096 ? 0 : e + bias) << 23; };
+            for (int ii = 0; ii < tc; ii++) A = fmacc<FMT>(A, __uint_as_float(whole(w[-ii], 0)), __uint_as_float(whole(cs[ii], 127)));
+            acc = A.v;
+        }
     }
     const int n = n0 + t;
     if (n >= a.io.nframes) return;
-    alu_t X = acc;
+    alu_t X = FF(acc);
     if (c.sat) X = sat0db<FMT>(X);                                              /* :464-475 */
     unsigned word;                                                              /* :610-633 */
     if constexpr (M<FMT>::smp_int) word = (unsigned)(s31_from_float(X.v) & a.io.store_mask);
@@ -2416,6 +2470,7 @@ struct Plan {
     double *d_taps64 = nullptr; int pitch64 = 0;         /* fir_tile: the taps as doubles, [chain][pitch64] */
     bool lane_mode = false;                              /* formats 3 and 5: chain_lane, one lane per chain, state in the mirror */
     int *d_lane_rows = nullptr; int n_lane_rows = 0;     /* ... chain_rows' chains (1 .. 16 sections) */
+    int n_lane_feed = 0;                                 /* ... chains that are a FIR alone (fir_lane_feed) */
     int n_lane_fir = 0; unsigned *d_lseq = nullptr; int lseq_pitch = 0;      /* ... and fir_lane's sequence buffer: [nchains][max_taps - 1 + frames of the largest block so far] */
     /* strand plan attached to a generic plan (include/avdsp_hip.h): the stretch as micro-operations, one argument row per strand */
     avdsp_strand_op *d_sops = nullptr; int *d_sargs = nullptr; int s_nops = 0, s_nargs = 0, s_nstrands = 0, s_nres = 0; bool s_usey = false;
@@ -2926,6 +2981,7 @@ int avdsp_hip_prog_add_plan(avdsp_hip_prog *prog, const avdsp_plan_desc *d)
         std::vector<int> rows;
         for (int i = 0; i < d->nchains; i++) if (chains[i].nsec >= 1 && chains[i].nsec <= 16) rows.push_back(i);
         pl.n_lane_rows = (int)rows.size();
+        for (int i = 0; i < d->nchains; i++) pl.n_lane_feed += chains[i].nsec == 0 && chains[i].fir_taps != 0;
         if (upload_vec(&pl.d_lane_rows, rows)) { free_plan(pl); return -1; }
         prog->plans.push_back(pl);
         return (int)prog->plans.size() - 1;
@@ -3457,7 +3513,12 @@ int avdsp_hip_run_block(avdsp_hip_prog *prog, int plan, const void *d_in, int in
             if (pl.format == 3) hipLaunchKernelGGL(chain_rows<3>, rgrid, block, 0, st, a, (const int *)pl.d_lane_rows, pl.n_lane_rows);
             else                hipLaunchKernelGGL(chain_rows<5>, rgrid, block, 0, st, a, (const int *)pl.d_lane_rows, pl.n_lane_rows);
         }
-        if (!rows || pl.n_lane_rows < pl.nchains) {
+        if (tiles && pl.n_lane_feed > 0) {
+            const dim3 fg(pl.nchains, (nframes + 255) / 256);
+            if (pl.format == 3) hipLaunchKernelGGL(fir_lane_feed<3>, fg, dim3(256), 0, st, a);
+            else                hipLaunchKernelGGL(fir_lane_feed<5>, fg, dim3(256), 0, st, a);
+        }
+        if ((rows ? pl.n_lane_rows : 0) + (tiles ? pl.n_lane_feed : 0) < pl.nchains) {      /* the rest: longer cascades, chains without filters, single frames */
             if (pl.format == 3) hipLaunchKernelGGL(chain_lane<3>, grid, block, 0, st, a);
             else                hipLaunchKernelGGL(chain_lane<5>, grid, block, 0, st, a);
         }
