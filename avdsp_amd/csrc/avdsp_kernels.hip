@@ -2512,6 +2512,7 @@ struct avdsp_hip_prog {
     int overlap = 0;
     int fir_rows = 0;                    /* fir_tile: row tiles per wave (1, 2, 4), 0 = by the number of chains */
     hipStream_t s_bq = nullptr;
+    hipStream_t s_fir[2] = {nullptr, nullptr};           /* "overlap" 2: the FIRs of consecutive blocks in turn */
     static constexpr int kAhead = 3;     /* cascade k waits for FIR k - kAhead: it may run under FIR k - 2 and be done before FIR k - 1 ends */
     hipEvent_t ev_bq[kAhead] = {nullptr, nullptr, nullptr}, ev_fir[kAhead] = {nullptr, nullptr, nullptr};
     int *d_tag_prev = nullptr;           /* tagoutput: the plugin's `previoussample` */
@@ -2830,6 +2831,7 @@ static int overlap_ready(avdsp_hip_prog *prog)
 {
     if (prog->s_bq) return 0;
     HIP_TRY(hipStreamCreateWithFlags(&prog->s_bq, hipStreamNonBlocking));
+    for (auto &fs : prog->s_fir) HIP_TRY(hipStreamCreateWithFlags(&fs, hipStreamNonBlocking));
     for (int i = 0; i < avdsp_hip_prog::kAhead; i++) {
         /* they order kernels of this device among themselves: no system-scope fence (tools/stream_handover_bench.hip: 8.1 instead of 10.6 us) */
         HIP_TRY(hipEventCreateWithFlags(&prog->ev_bq[i], hipEventDisableTiming | hipEventDisableSystemFence));
@@ -2851,9 +2853,21 @@ int launch_all(avdsp_hip_prog *prog, Plan &pl, BlockIO io, int fir_impl, int biq
             auto &g = pl.bq[gi];
             if (launch_biquad<FMT>(prog, pl, g, g.d_ids, g.n, io, biquad_impl, prog->s_bq, gi + 1 == pl.bq.size() ? prog->ev_bq[slot] : nullptr)) return -1;
         }
-        HIP_TRY(hipStreamWaitEvent(stream, prog->ev_bq[slot], 0));
-        if (launch_fir<FMT>(prog, pl, pl.d_fir_ids, pl.n_fir, io, fir_impl, stream)) return -1;
-        HIP_TRY(hipEventRecord(prog->ev_fir[slot], stream));
+        if (prog->overlap >= 2) {
+            /* the FIRs of consecutive blocks on two streams of the library's own, in turn: FIR k+1 needs nothing of FIR k, and on one
+             * stream it would start a queue hand-over (~10 us) after FIR k's last wave; here its first workgroups fill the chip as FIR
+             * k's last ones leave.  The caller's stream only waits for each FIR's end.  (The mode's contract then covers the output
+             * too: the block a call writes must not be one an earlier call's FIR may still be writing.) */
+            hipStream_t fs = prog->s_fir[prog->blk & 1];
+            HIP_TRY(hipStreamWaitEvent(fs, prog->ev_bq[slot], 0));
+            if (launch_fir<FMT>(prog, pl, pl.d_fir_ids, pl.n_fir, io, fir_impl, fs)) return -1;
+            HIP_TRY(hipEventRecord(prog->ev_fir[slot], fs));
+            HIP_TRY(hipStreamWaitEvent(stream, prog->ev_fir[slot], 0));
+        } else {
+            HIP_TRY(hipStreamWaitEvent(stream, prog->ev_bq[slot], 0));
+            if (launch_fir<FMT>(prog, pl, pl.d_fir_ids, pl.n_fir, io, fir_impl, stream)) return -1;
+            HIP_TRY(hipEventRecord(prog->ev_fir[slot], stream));
+        }
         prog->ev_fir_set[slot] = true;
         prog->blk++;
     } else {
@@ -2928,6 +2942,7 @@ void avdsp_hip_prog_destroy(avdsp_hip_prog *p)
         for (auto e : {sl.h2d, sl.run, sl.d2h}) if (e) (void)hipEventDestroy(e);
     }
     if (p->s_bq) (void)hipStreamDestroy(p->s_bq);
+    for (auto fs : p->s_fir) if (fs) (void)hipStreamDestroy(fs);
     if (p->ev_unpack) (void)hipEventDestroy(p->ev_unpack);
     for (int i = 0; i < avdsp_hip_prog::kAhead; i++) { if (p->ev_bq[i]) (void)hipEventDestroy(p->ev_bq[i]); if (p->ev_fir[i]) (void)hipEventDestroy(p->ev_fir[i]); }
     (void)hipFree(p->d_buf); (void)hipFree(p->d_in); (void)hipFree(p->d_out); (void)hipFree(p->d_tpdf); (void)hipFree(p->d_frame);
@@ -3999,7 +4014,7 @@ int avdsp_hip_prog_set_option(avdsp_hip_prog *prog, int key, int value)
 {
     HIP_TRY(hipDeviceSynchronize());                    /* nothing in flight when the launch arrangement changes */
     switch (key) {
-    case AVDSP_OPT_OVERLAP:  prog->overlap = value != 0; for (bool &f : prog->ev_fir_set) f = false; return 0;
+    case AVDSP_OPT_OVERLAP:  prog->overlap = value; for (bool &f : prog->ev_fir_set) f = false; return 0;
     case AVDSP_OPT_FIR_ROWS: if (value != 0 && value != 1 && value != 2 && value != 4) return set_err("fir_tile row tiles: 0 (auto), 1, 2 or 4");
                              prog->fir_rows = value; return 0;
     case AVDSP_OPT_PROFILE_STRIDE: if (value < 1) return set_err("profile_stride: every n-th launch, n >= 1"); prog->profile_stride = value; return 0;

@@ -237,7 +237,7 @@ def main():
     ap.add_argument("--workload", default="north", choices=sorted(WORKLOADS))
     ap.add_argument("--fir-impl", type=int, default=1)
     ap.add_argument("--biquad-impl", type=int, default=1)
-    ap.add_argument("--overlap", type=int, default=1, help="cascade of the next block under the FIR of this one (the blocks are resident in HBM, which is that mode's contract): 0 off, 1 on")
+    ap.add_argument("--overlap", type=int, default=1, help="cascade of the next block under the FIR of this one (the blocks are resident in HBM, which is that mode's contract): 0 off, 1 on, 2 also the FIRs of consecutive blocks on two streams in turn")
     ap.add_argument("--fir-rows", type=int, default=-1, help="fir_tile row tiles per wave: 0 auto, 1, 2, 4")
     ap.add_argument("--shard", default=None, help="RANK/WORLD: run that one shard of the program on this GPU alone (what one rank of a WORLD-GPU job does)")
     ap.add_argument("--host-buffers", action="store_true", help="also time dspRuntimeBlock_N with HOST buffers (PCIe inclusive), reported beside value")
@@ -320,8 +320,14 @@ def main():
     y = torch.zeros((B, Cl), dtype=x.dtype, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
+    # "overlap" 2 lets the FIRs of consecutive blocks run into each other: a block's output must then not be the buffer an earlier
+    # call may still be writing (the mode's contract) -- three output blocks in turn
+    ys = [y] + ([torch.zeros_like(y), torch.zeros_like(y)] if args.overlap >= 2 else [])
+    turn = [0]
+
     def step():
-        r.run_block_device(x.data_ptr(), Cl, in_base, y.data_ptr(), Cl, out_base, B, stream)
+        yo = ys[turn[0] % len(ys)]; turn[0] += 1
+        r.run_block_device(x.data_ptr(), Cl, in_base, yo.data_ptr(), Cl, out_base, B, stream)
 
     # Every timed launch costs the stream an event pair (a few microseconds each).  In the timed region only the
     # kernel the roofline is quoted on carries one; the cascade in front of a FIR is timed over a few extra
@@ -478,6 +484,11 @@ def main():
                 # the same kernel without the next block's cascade beside it (10 untimed steps, overlap off)
                 roof["launch_ms_alone"] = fir_alone[0] / fir_alone[1]
                 roof["frac_alone"] = flops / (roof["launch_ms_alone"] * 1e-3) / 1e12 / PEAK_F64_TFLOPS
+            # the FIR's flops of a step against the step's wall time: what the matrix pipe delivered over the whole timed region
+            roof["frac_of_step"] = flops * launches_per_step / (elapsed / args.steps) / 1e12 / PEAK_F64_TFLOPS
+            if args.overlap >= 2:
+                roof["timing_note"] = ("overlap 2: the FIR launches of consecutive blocks are in flight together, a launch's own start-to-end "
+                                       "time spans two kernels sharing the chip -- frac reads about half of what the pipe does; see frac_of_step")
         elif bq_n:
             # The cascade is a recurrence: what binds it is vector-instruction issue, not memory.  Both ceilings, the binding one first
             # (SURVEY.md 8d): double models 10 flop per section and sample against the FP64 vector peak; int64 5 32x32->64 MADs per

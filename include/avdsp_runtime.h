@@ -186,7 +186,13 @@ int dspRuntimeStrandInfo(int format, opcode_t *core, int *strands, int *ops_per_
 /* Tunables: "fir_impl" 0 = plain tap loop, 1 = MFMA (default); "biquad_impl" 0 = lane per channel,
  * 1 = section-pipelined (default: biquad_row where it applies, else biquad_pipe), 2 = round 2's biquad_pipe throughout; "interp_impl" 0 = interpreter always frame by frame, 1 = frame-parallel
  * where the core allows it (default); "strand_split" 0 = dspRuntimeBlockAll keeps cores whole; "strand_lanes" 0 = strand runs stay with the interpreter, 1 = runs of more than 64 strands on lanes (default: up to 64 strand groups get a wave each from the interpreter, which is faster), 2 = every run; "generic" 1 = every core through the interpreter;
- * "device" = HIP device ordinal (before the first block).                                        */
+ * "device" = HIP device ordinal (before the first block);
+ * "overlap" (chain cores with cascades in front of FIRs, blocks resident on the device) 1 = the cascades run up to three blocks ahead of
+ * the FIRs on a stream of the library's own -- the caller then guarantees that a block's INPUT is complete in memory when the call is made
+ * (stream order no longer covers it); 2 = also the FIRs of consecutive blocks on two streams in turn, so that one starts while the other's
+ * last workgroups leave (worth 5 % on a 4096-channel program, a loss below ~2000 channels) -- the caller then also guarantees that the
+ * OUTPUT block of a call is not one an earlier call's FIR may still be writing (the caller's stream still waits for every block's end).
+ * Results are identical in every mode.                                                          */
 int dspRuntimeSetOption(const char *key, int value);
 int dspRuntimeGetOption(const char *key);
 
