@@ -2289,37 +2289,80 @@ __global__ __launch_bounds__(64) void chain_rows(const LaneArgs a, const int *id
         }
         return bq_input<FMT>(X);
     };
-    xin[0][row][s] = fetch(s);
-    __syncthreads();
-    int y = 0;
-    const int steps = B + 15;                            /* the longest row's last frame leaves its 16th section at step B - 1 + 15 */
-    for (int t0 = 0; t0 < steps; t0 += 16) {
-        const int cur = (t0 >> 4) & 1;
-        const int ahead = fetch(t0 + 16 + s);            /* (in flight under the batch's steps) */
-        for (int k = 0; k < 16; k++) {
-            const int t = t0 + k;
-            int x = __builtin_amdgcn_update_dpp(0, y, kRowShr1, 0xF, 0xF, false);      /* the section before, one step ago */
-            if (s == 0) x = xin[cur][row][k];
-            const int f = t - s;
-            if (mine && f >= 0 && f < B) {
-                y = bq_step<FMT>(q, x, cw);
-                if (s == S - 1) {
-                    alu_t X = q.acc;
-                    if (c.fir_taps && a.seq) a.seq[(size_t)cid * a.pitch + a.hist + f] = __float_as_uint(to_sp<FMT>(X));
+    /* The section update (dsp_biquadSTD.h:84-119 with a float accumulator: five dspMaccFloatFloat) with every operand of the software
+     * product TAKEN APART ONCE -- the coefficients for the block, a sample when it enters the section (it is then multiplied three
+     * times: as x, x1, x2) and an output when it is made (y1, y2): word m = mantissa with hidden bit and the sign in bit 31, word e =
+     * biased exponent (a coefficient's less 127), a large negative number for exponent 0 (fir_lane).  prod() is dsp_ieee754.h:342-375's
+     * integer arithmetic, literally.  Two NaNs add the SSE way in the reference (FF::operator+=): a product whose exponent field
+     * filled up may read as one, so the largest exponent sum is tracked and a wave that met one runs its block AGAIN through the
+     * interpreter's own bq_step (exact = true): stores and the sequence buffer are simply written twice, state leaves only at the end. */
+    struct Apart { unsigned m; int e; };
+    auto apart = [](unsigned w, int bias) -> Apart {
+        const int e = (int)(w >> 23 & 255u);
+        return Apart{(w & 0x807FFFFFu) | 0x800000u, e ? e - bias : -4096};
+    };
+    auto whole = [](Apart v) -> unsigned { return (v.m & 0x807FFFFFu) | (unsigned)(v.e == -4096 ? 0 : v.e) << 23; };
+    Apart cf[5];
+    for (int k = 0; k < 5; k++) cf[k] = apart((unsigned)cw[k], 127);
+    const BqState<FMT> q0 = q;
+    int emax = 0;
+    auto macc = [&](float acc, Apart x, Apart cc) -> float {
+        const int e = x.e + cc.e;
+        const unsigned p = (unsigned)(((unsigned long long)(x.m & 0xFFFFFFu) * (cc.m & 0xFFFFFFu)) >> 22);
+        const unsigned up = p >> 25 & 1u;
+        const unsigned e9 = ((unsigned)e | ((x.m ^ cc.m) >> 23 & 0x100u)) + up;
+        const unsigned word = ((p >> (1u + up)) & 0x7FFFFFu) | (e9 << 23);
+        const float sum = acc + __uint_as_float(word);
+        emax = max(emax, e);
+        return e >= 1 ? sum : acc;
+    };
+    auto run = [&](auto exact_c) {
+        constexpr bool exact = decltype(exact_c)::value;
+        float acc = q.acc.v;
+        Apart x1 = apart((unsigned)q.x1, 0), x2 = apart((unsigned)q.x2, 0), y1 = apart((unsigned)q.y1, 0), y2 = apart((unsigned)q.y2, 0);
+        xin[0][row][s] = fetch(s);
+        __syncthreads();
+        int y = 0;
+        const int steps = B + 15;                        /* the longest row's last frame leaves its 16th section at step B - 1 + 15 */
+        for (int t0 = 0; t0 < steps; t0 += 16) {
+            const int cur = (t0 >> 4) & 1;
+            const int ahead = fetch(t0 + 16 + s);        /* (in flight under the batch's steps) */
+            for (int k = 0; k < 16; k++) {
+                const int t = t0 + k;
+                int x = __builtin_amdgcn_update_dpp(0, y, kRowShr1, 0xF, 0xF, false);      /* the section before, one step ago */
+                if (s == 0) x = xin[cur][row][k];
+                const int f = t - s;
+                if (mine && f >= 0 && f < B) {
+                    float outv;
+                    if constexpr (exact) { y = bq_step<FMT>(q, x, cw); outv = q.acc.v; }
                     else {
-                        if (c.fir_taps) X = fir<FMT>(to_sp<FMT>(X), a.buf + c.fir_coef_word, a.buf + c.fir_state_word, c.fir_taps);
-                        if (c.sat) X = sat0db<FMT>(X);
-                        unsigned word;
-                        if constexpr (M<FMT>::smp_int) word = (unsigned)(s31_from_float(X.v) & a.io.store_mask);
-                        else word = __float_as_uint(to_sp<FMT>(X));
-                        emit_out(a.io, c, f, word);
+                        const Apart xn = apart((unsigned)x, 0);
+                        acc = macc(acc, xn, cf[0]); acc = macc(acc, x1, cf[1]); acc = macc(acc, x2, cf[2]);
+                        acc = macc(acc, y1, cf[3]); acc = macc(acc, y2, cf[4]);
+                        x2 = x1; x1 = xn; y2 = y1; y1 = apart(__float_as_uint(acc), 0);
+                        y = __float_as_int(acc); outv = acc;
+                    }
+                    if (s == S - 1) {
+                        alu_t X = FF(outv);
+                        if (c.fir_taps && a.seq) a.seq[(size_t)cid * a.pitch + a.hist + f] = __float_as_uint(to_sp<FMT>(X));
+                        else {
+                            if (c.fir_taps) X = fir<FMT>(to_sp<FMT>(X), a.buf + c.fir_coef_word, a.buf + c.fir_state_word, c.fir_taps);
+                            if (c.sat) X = sat0db<FMT>(X);
+                            unsigned word;
+                            if constexpr (M<FMT>::smp_int) word = (unsigned)(s31_from_float(X.v) & a.io.store_mask);
+                            else word = __float_as_uint(to_sp<FMT>(X));
+                            emit_out(a.io, c, f, word);
+                        }
                     }
                 }
             }
+            xin[cur ^ 1][row][s] = ahead;
+            __syncthreads();                             /* (one wave: orders the row's writes against the section-0 lane's reads) */
         }
-        xin[cur ^ 1][row][s] = ahead;
-        __syncthreads();                                 /* (one wave: orders the row's writes against the section-0 lane's reads) */
-    }
+        if constexpr (!exact) { q.acc = FF(acc); q.x1 = (int)whole(x1); q.x2 = (int)whole(x2); q.y1 = (int)whole(y1); q.y2 = (int)whole(y2); }
+    };
+    run(std::false_type{});
+    if (__builtin_expect(__ballot(emax >= 254) != 0, 0)) { q = q0; run(std::true_type{}); }
     if (mine) bq_store<FMT>(q, stw);
 }
 

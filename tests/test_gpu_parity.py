@@ -474,3 +474,21 @@ def test_float_accumulator_models_at_the_headline_geometry(fmt):
     blocks = [1024, 1024, 333]
     x = pb.lcg_input(sum(blocks), C, fmt == 5, seed=77)
     _oracle_vs_device(fmt, prog, x, C, C, blocks).release()
+
+
+@pytest.mark.parametrize("sections,taps", [(3, 40), (0, 300), (2, 0)])
+def test_float_accumulator_models_with_nan_inf_and_huge_samples(sections, taps):
+    """DSP_FORMAT 5 (float samples): Inf, NaN, values next to FLT_MAX and subnormals among the inputs.  chain_rows and fir_lane take
+    the software product's operands apart ahead of time and add with the hardware; a product whose exponent field fills up may read as a
+    NaN, which the reference adds the SSE way -- those blocks run again through the interpreter's own functions.  Bit for bit against
+    the oracle, outputs and state."""
+    C = 6
+    prog = pb.synth_program(5, C, sections, taps)
+    blocks = [64, 200, 1, 90]
+    x = pb.lcg_input(sum(blocks), C, True, seed=123)
+    odd = np.array([np.inf, -np.inf, np.nan, 3.0e38, -3.3e38, 1e-40, -1e-42, 2.0e38], dtype=np.float32)
+    rng = np.random.default_rng(7)
+    for k in range(40):
+        x[rng.integers(0, x.shape[0]), rng.integers(0, C)] = odd[k % len(odd)]
+    x[70:75, 2] = odd[:5]                                     # a run of them inside one FIR window
+    _oracle_vs_device(5, prog, x, C, C, blocks).release()
