@@ -783,8 +783,10 @@ __global__ __launch_bounds__(kBlock) void biquad_row(const BiquadArgs a)
 
     double cd[5] = {0, 0, 0, 0, 0}, acc = 0, dx1 = 0, dx2 = 0, dy1 = 0, dy2 = 0, P = 0;
     unsigned hy = 0;
+    int raw_x1 = 0, raw_y1 = 0;                         /* a one-frame block hands them on as x2 / y2 unchanged: as words (mulop drops a zero's sign) */
     if (lane_on) {
         const int *st = a.buf + lr.state_word;
+        raw_x1 = st[2]; raw_y1 = st[4];
         const unsigned long long raw = ((unsigned long long)(unsigned)st[1] << 32) | (unsigned)st[0];
         acc = __longlong_as_double((long long)raw);
         for (int k = 0; k < 5; k++) cd[k] = mulop(__int_as_float(a.buf[lr.coef_word + k]));
@@ -1000,8 +1002,8 @@ __global__ __launch_bounds__(kBlock) void biquad_row(const BiquadArgs a)
         int *st = a.buf + lr.state_word;
         const unsigned long long bits = (unsigned long long)__double_as_longlong(acc);
         st[0] = (int)(unsigned)bits; st[1] = (int)(unsigned)(bits >> 32);
-        st[2] = __float_as_int(narrow_f32(dx1)); st[3] = __float_as_int(narrow_f32(dx2));
-        st[4] = (int)hy; st[5] = __float_as_int(narrow_f32(dy2));
+        st[2] = __float_as_int(narrow_f32(dx1)); st[3] = B == 1 ? raw_x1 : __float_as_int(narrow_f32(dx2));
+        st[4] = (int)hy; st[5] = B == 1 ? raw_y1 : __float_as_int(narrow_f32(dy2));
     }
     if (replay && have_chain && sec == 0) {
         const BiquadArgs a2 = a;

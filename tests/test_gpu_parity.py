@@ -492,3 +492,32 @@ def test_float_accumulator_models_with_nan_inf_and_huge_samples(sections, taps):
         x[rng.integers(0, x.shape[0]), rng.integers(0, C)] = odd[k % len(odd)]
     x[70:75, 2] = odd[:5]                                     # a run of them inside one FIR window
     _oracle_vs_device(5, prog, x, C, C, blocks).release()
+
+
+@pytest.mark.parametrize("fmt", [4, 6])
+@pytest.mark.parametrize("sections", [1, 3, 16])
+def test_signed_zeros_in_the_state_across_one_frame_blocks(fmt, sections):
+    """-0 and negative subnormal samples, blocks of one frame between longer ones: a one-frame block hands x1 / y1 on as x2 / y2
+    unchanged, sign of zero included (tests/dev/gpu_fuzz_sweep.py seed 9008 found biquad_row writing +0 there).  The state is
+    compared with the oracle's after every block."""
+    C = 5
+    prog = pb.synth_program(fmt, C, sections, 0)
+    blocks = [64, 1, 1, 7, 1, 33, 1]
+    x = pb.lcg_input(sum(blocks), C, fmt == 6, seed=9)
+    if fmt == 6:
+        xv = x.view(np.uint32)
+        xv[60:72:2, :] = 0x80000000                           # -0
+        xv[61:71:4, 1] = 0x802D27B4                           # a negative subnormal
+        xv[100:108, 3] = 0x80000000
+    else:
+        x[60:72:2, :] = 0
+    o = po.OracleProgram(fmt, prog)
+    r = rt.Runtime(fmt, prog)
+    pos = 0
+    for b in blocks:
+        want = o.run_block(x[pos:pos + b], C, C)
+        got = r.run_block(x[pos:pos + b], C, C)
+        assert (got.view(np.uint32) == want.view(np.uint32)).all(), f"block at frame {pos}"
+        assert (r.sync_state() == o.state).all(), f"state after the block at frame {pos} ({b} frames)"
+        pos += b
+    r.release()
