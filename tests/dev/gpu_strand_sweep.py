@@ -17,12 +17,12 @@ IN0 = 512
 def shape_of(rng):
     """one strand as a list of (name, argument kind); X/Y use is kept legal for a cut in front of every strand: the first opcode
     replaces X, and Y is only read after the strand itself has set it"""
-    ops = [str(rng.choice(["load", "load_gain", "load_gain"]))]
+    ops = [str(rng.choice(["load", "load_gain", "load_gain", "load_mem"]))]       # load_mem: a word a core in front of this one stores
     y_set = True                                            # LOAD / LOAD_GAIN leave the old X in Y -- but that is the strand's own only after a COPYXY
     y_own = False
     nst = 0
     for _ in range(int(rng.integers(2, 9))):
-        pool = ["gain", "biquads", "delay", "sat", "sat_tpdf", "sat_gain", "sat_tpdf_gain", "shift", "negx", "copyxy", "store"]
+        pool = ["gain", "biquads", "delay", "sat", "sat_tpdf", "sat_gain", "sat_tpdf_gain", "shift", "negx", "copyxy", "store", "store_mem"]
         if y_own:
             pool += ["swapxy", "addxy", "subxy", "addyx", "subyx", "copyyx"]
         op = str(rng.choice(pool))
@@ -47,15 +47,23 @@ def program(nch, fmt, ops, rng):
 
     def build(L):
         banks = {}
+        mem_in, mem_out = [], {}
         for c in range(nch):
             if c % 32 == 0:
                 L.dsp_PARAM()
+            mem_in.append(L.dspMem_Location())
+            for i, o in enumerate(ops):
+                if o == "store_mem": mem_out[(c, i)] = L.dspMem_Location()
             for i, o in enumerate(ops):
                 if o == "biquads":
                     b = L.dspBiquad_Sections(nbq[i])
                     for k in range(nbq[i]):
                         L.dsp_Filter2ndOrder(FPEAK if k % 2 == 0 else FLP2, 120.0 * (k + 1) + 5 * c + 40 * i, 0.8, 0.9)
                     banks[(c, i)] = b
+        if ops[0] == "load_mem":                              # a core that fills the memories the strands start from
+            L.dsp_CORE()
+            for c in range(nch):
+                L.dsp_LOAD_GAIN_Fixed(IN0 + c, 0.7); L.dsp_STORE_MEM(mem_in[c])
         L.dsp_CORE()
         if any(o in ("sat_tpdf", "sat_tpdf_gain") for o in ops):
             L.dsp_TPDF_CALC(0)
@@ -63,6 +71,8 @@ def program(nch, fmt, ops, rng):
             k = 0
             for i, o in enumerate(ops):
                 if o == "load": L.dsp_LOAD(IN0 + c)
+                elif o == "load_mem": L.dsp_LOAD_MEM(mem_in[c])
+                elif o == "store_mem": L.dsp_STORE_MEM(mem_out[(c, i)])
                 elif o == "load_gain": L.dsp_LOAD_GAIN_Fixed(IN0 + c, gains[i])
                 elif o == "gain": L.dsp_GAIN_Fixed(gains[i])
                 elif o == "biquads": L.dsp_BIQUADS(banks[(c, i)])
