@@ -1991,14 +1991,15 @@ static int expand_core(int format, opcode_t *c, core_plan **cp, int *pn)
      * and never looks at the first way's result, so it is a piece of its own: the load again, then what follows the SWAPXY
      * (two_way_fork; the piece leaves [COPYXY .. SWAPXY] out).  crossoverLV6.bin's second core: its two cascades side by side. */
     typedef struct { int start, end, skip_from, skip_to; } piece_t;
-    static piece_t pc[MAX_GROUPS * 2 + 2];
+    static piece_t pc[MAX_GROUPS + 2];
     int np = 0;
     const int interpreted = whole->total_chains == 0 && !whole->empty && G.opt_strand_split;
     starts[ng] = dspHeaderPtr->totalLength;
     for (int g = 0; g < ng; g++) {
         const int ps = ng > 1 ? starts[g] : (int)(begin - G.code), pe = ng > 1 ? starts[g + 1] : dspHeaderPtr->totalLength;
         int cw = 0, sw = 0, aw = 0;
-        if (interpreted && np + 2 <= MAX_GROUPS * 2 && G.nplans + np + 4 < MAX_CORE_PLANS && n + np + 4 < MAX_CORE_PLANS &&
+        /* (a core stays within MAX_GROUPS pieces, forks included: the per-core entry points take no more) */
+        if (interpreted && np + 2 + (ng - g - 1) <= MAX_GROUPS && G.nplans + np + 4 < MAX_CORE_PLANS && n + np + 4 < MAX_CORE_PLANS &&
             two_way_fork(ps, pe, &cw, &sw, &aw)) {
             /* both ways scanned as pieces: they must be strangers like any two pieces of a core */
             static core_deps da, db;
