@@ -180,7 +180,8 @@ int dspRuntimeShardInfo(int format, opcode_t *core, int *total_chains, int *firs
                         int *in_io_min, int *in_io_max, int *out_io_min, int *out_io_max);
 
 /* Host-only: the tail of an interpreted core that is N >= 2 repetitions of one opcode sequence -- one strand per channel, the shape of
- * the reference's crossover programs -- runs with lane = strand (avdsp_hip.h, strand plans).  strands = 0: the core has no such tail. */
+ * the reference's crossover programs -- runs with lane = strand (avdsp_hip.h, strand plans).  strands = 0: the core has no such tail, or
+ * the run is too short for the current "strand_lanes" setting (default: more than 64 strands; 2: any run). */
 int dspRuntimeStrandInfo(int format, opcode_t *core, int *strands, int *ops_per_strand, int *prefix_words);
 
 /* Tunables: "fir_impl" 0 = plain tap loop, 1 = MFMA (default); "biquad_impl" 0 = lane per channel,
