@@ -1496,13 +1496,17 @@ constexpr int kTapsLead = 64;                /* zeros in front of a chain's taps
 constexpr int kTapsTail = 384;               /* zeros behind them (the last k-steps and the operand prefetch read on) */
 __host__ __device__ inline int taps64_pitch(int max_taps) { return (kTapsLead + max_taps + kTapsTail + 1) & ~1; }
 
-template <int R> struct TileGeom {
+/* BIG (R = 1 only): chunks twice as long for launches that leave a SIMD one wave at most -- nothing hides a chunk boundary there
+ * (2200 cycles each, 16 % of a wave's life on 256 chains x 4096 taps: tools/fir_timeline.py), and a workgroup may have the CU's LDS to
+ * itself (35 KB per wave) */
+template <int R, bool BIG = false> struct TileGeom {
+    static_assert(!BIG || R == 1, "long chunks: one row tile");
     static constexpr int NR = 16 * R;                        /* rows of the output tile: frames per column step */
     static constexpr int FW = 256 * R;                       /* frames per wave */
     static constexpr int WPC = 4 / R;                        /* waves per channel and launch */
     static constexpr int QD = 4 * (R - 1);                   /* k-steps a taps operand waits for its last use */
-    static constexpr int CKMAX = R == 4 ? 96 : R == 2 ? 128 : 160;           /* k-steps per chunk, multiple of 16 */
-    static constexpr int ROW = R == 4 ? 23 : R == 2 ? 33 : 57;               /* doubles per window row, odd: >= 16 + ceil(4 (CKMAX-1) / NR) */
+    static constexpr int CKMAX = R == 4 ? 96 : R == 2 ? 128 : BIG ? 320 : 160;       /* k-steps per chunk, multiple of 16 */
+    static constexpr int ROW = R == 4 ? 23 : R == 2 ? 33 : BIG ? 97 : 57;            /* doubles per window row, odd: >= 16 + ceil(4 (CKMAX-1) / NR) */
     static constexpr int HNEED = 4 * CKMAX + 16 * (R - 1) + 28;              /* doubles of a chunk's taps image */
     static constexpr int HLEN = (HNEED + 127) / 128 * 128;                   /* ... in whole 1-KiB pieces of the LDS-DMA that fills it */
     static constexpr int WLEN = NR * ROW + (NR * ROW & 1);
@@ -1510,7 +1514,8 @@ template <int R> struct TileGeom {
     static constexpr int NW = (NR * ROW + 63) / 64;          /* window elements a lane stages per chunk */
 };
 static_assert(TileGeom<4>::ROW >= 16 + (4 * (TileGeom<4>::CKMAX - 1) + 63) / 64 && TileGeom<2>::ROW >= 16 + (4 * (TileGeom<2>::CKMAX - 1) + 31) / 32 &&
-              TileGeom<1>::ROW >= 16 + (4 * (TileGeom<1>::CKMAX - 1) + 15) / 16, "window rows hold a chunk");
+              TileGeom<1>::ROW >= 16 + (4 * (TileGeom<1>::CKMAX - 1) + 15) / 16 &&
+              TileGeom<1, true>::ROW >= 16 + (4 * (TileGeom<1, true>::CKMAX - 1) + 15) / 16, "window rows hold a chunk");
 
 struct FirTileArgs {
     int *buf; const avdsp_chain *chains; const int *group; int ngroup; Ring ring; int per_xcd;
@@ -1531,17 +1536,17 @@ struct FirTileArgs {
 #endif
 
 /* one taps double per lane and k-step, the window double of lane (a, k) likewise; offsets inside a group of 16 k-steps */
-template <int R> __device__ __forceinline__ constexpr int win_off(int j)
+template <int R, bool BIG = false> __device__ __forceinline__ constexpr int win_off(int j)
 {
     constexpr int NR = 16 * R;
     /* row part ((-4 j) mod NR) * ROW, entry part -(ceil(4 j / NR)), shifted so that the smallest offset of a group is 0 */
-    return ((NR - (4 * j) % NR) % NR) * TileGeom<R>::ROW - (4 * j + NR - 1) / NR + (64 / NR - 1);
+    return ((NR - (4 * j) % NR) % NR) * TileGeom<R, BIG>::ROW - (4 * j + NR - 1) / NR + (64 / NR - 1);
 }
 
-template <int FMT, int R>
+template <int FMT, int R, bool BIG = false>
 __global__ __launch_bounds__(kBlock, 2) void fir_tile(const FirTileArgs a)
 {
-    using G = TileGeom<R>;
+    using G = TileGeom<R, BIG>;
     constexpr int NR = G::NR;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1657,13 +1662,13 @@ __global__ __launch_bounds__(kBlock, 2) void fir_tile(const FirTileArgs a)
 #pragma unroll
         for (int j = 0; j < G::QD; j++) q[(16 - G::QD + j) & 15] = hp[4 * j];
         q[0] = hp[16 * (R - 1)]; q[1] = hp[16 * (R - 1) + 4];
-        bq[0] = wp[win_off<R>(0)]; bq[1] = wp[win_off<R>(1)];
+        bq[0] = wp[win_off<R, BIG>(0)]; bq[1] = wp[win_off<R, BIG>(1)];
     };
     /* one k-step: the reads of step j + 2 (of the next group for j = 14, 15: the same code, offsets continue), R MFMAs */
     auto kstep = [&](const double *hg, const double *wg, auto jc) {
         constexpr int j = decltype(jc)::value;
         q[(j + 2) & 15] = hg[4 * (j + 2)];
-        bq[(j + 2) & 3] = j + 2 < 16 ? wg[win_off<R>((j + 2) & 15)] : (wg - 64 / NR)[win_off<R>((j + 2) & 15)];
+        bq[(j + 2) & 3] = j + 2 < 16 ? wg[win_off<R, BIG>((j + 2) & 15)] : (wg - 64 / NR)[win_off<R, BIG>((j + 2) & 15)];
         __builtin_amdgcn_sched_barrier(0);          /* the reads stay two steps ahead of their MFMAs */
 #pragma unroll
         for (int r = 0; r < R; r++)
@@ -2752,16 +2757,16 @@ extern "C" int avdsp_hip_debug_fir_stamps(unsigned long long *host_out, int max_
 }
 #endif
 
-template <int FMT, int R>
+template <int FMT, int R, bool BIG = false>
 int launch_fir_tile(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, BlockIO io, hipStream_t stream, ProfileScope &scope)
 {
     (void)prog;
     FirTileArgs a{};
     a.buf = prog->d_buf; a.chains = pl.d_chains; a.group = ids; a.ngroup = n;
     a.ring = plan_ring(pl); a.io = io; a.taps64 = pl.d_taps64; a.pitch64 = pl.pitch64;
-    const int nwg = (n * TileGeom<R>::WPC + 3) / 4;
+    const int nwg = (n * TileGeom<R, BIG>::WPC + 3) / 4;
     a.per_xcd = (nwg + 7) / 8;
-    const size_t lds = (size_t)4 * TileGeom<R>::LDS_DOUBLES * sizeof(double) + 64;      /* + the four words the waves exchange at the end */
+    const size_t lds = (size_t)4 * TileGeom<R, BIG>::LDS_DOUBLES * sizeof(double) + 64;      /* + the four words the waves exchange at the end */
 #ifdef AVDSP_FIR_STAMPS
     static unsigned long long *d_stamps = nullptr;
     if (!d_stamps) { HIP_TRY(hipMalloc((void **)&d_stamps, (size_t)8192 * 4 * 32 * 8)); }
@@ -2769,7 +2774,7 @@ int launch_fir_tile(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, Block
     a.stamps = d_stamps;
     g_fir_stamps = d_stamps; g_fir_stamp_waves = a.per_xcd * 8 * 4;
 #endif
-    return launch_timed(scope, (const void *)fir_tile<FMT, R>, dim3(a.per_xcd * 8), dim3(kBlock), lds, stream, a);
+    return launch_timed(scope, (const void *)fir_tile<FMT, R, BIG>, dim3(a.per_xcd * 8), dim3(kBlock), lds, stream, a);
 }
 
 
@@ -2832,6 +2837,9 @@ int launch_fir(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, BlockIO io
             int rows = prog->fir_rows;
             if (rows != 1 && rows != 2 && rows != 4) rows = n >= 2048 ? 4 : n >= 1024 ? 2 : 1;
             while (rows > 1 && 128 * rows >= io.nframes) rows >>= 1;       /* a tile twice the block would multiply zeros */
+            /* one row tile and at most a wave per SIMD (1024): chunks twice as long -- nothing hides a boundary there */
+            const long long waves1 = (long long)n * ((io.nframes + 255) / 256);
+            if (rows == 1 && waves1 <= 1024 && prog->fir_rows != 1) return launch_fir_tile<FMT, 1, true>(prog, pl, ids, n, io, stream, scope);
             return rows == 4 ? launch_fir_tile<FMT, 4>(prog, pl, ids, n, io, stream, scope)
                  : rows == 2 ? launch_fir_tile<FMT, 2>(prog, pl, ids, n, io, stream, scope)
                              : launch_fir_tile<FMT, 1>(prog, pl, ids, n, io, stream, scope);
@@ -3101,11 +3109,13 @@ int avdsp_hip_prog_add_plan(avdsp_hip_prog *prog, const avdsp_plan_desc *d)
             }
         }
         {   /* fir_tile: LDS opt-in per variant, and the taps as doubles */
-            const void *tiles[3] = { d->format == 4 ? (const void *)fir_tile<4, 1> : (const void *)fir_tile<6, 1>,
+            const void *tiles[4] = { d->format == 4 ? (const void *)fir_tile<4, 1> : (const void *)fir_tile<6, 1>,
                                      d->format == 4 ? (const void *)fir_tile<4, 2> : (const void *)fir_tile<6, 2>,
-                                     d->format == 4 ? (const void *)fir_tile<4, 4> : (const void *)fir_tile<6, 4> };
-            const int tlds[3] = { 4 * TileGeom<1>::LDS_DOUBLES * 8 + 64, 4 * TileGeom<2>::LDS_DOUBLES * 8 + 64, 4 * TileGeom<4>::LDS_DOUBLES * 8 + 64 };
-            for (int v = 0; v < 3; v++) {
+                                     d->format == 4 ? (const void *)fir_tile<4, 4> : (const void *)fir_tile<6, 4>,
+                                     d->format == 4 ? (const void *)fir_tile<4, 1, true> : (const void *)fir_tile<6, 1, true> };
+            const int tlds[4] = { 4 * TileGeom<1>::LDS_DOUBLES * 8 + 64, 4 * TileGeom<2>::LDS_DOUBLES * 8 + 64, 4 * TileGeom<4>::LDS_DOUBLES * 8 + 64,
+                                  4 * TileGeom<1, true>::LDS_DOUBLES * 8 + 64 };
+            for (int v = 0; v < 4; v++) {
                 hipError_t e2 = hipFuncSetAttribute(tiles[v], hipFuncAttributeMaxDynamicSharedMemorySize, tlds[v]);
                 if (e2 != hipSuccess) { free_plan(pl); return set_err("hipFuncSetAttribute(fir_tile LDS %d): %s", tlds[v], hipGetErrorString(e2)); }
             }
