@@ -235,11 +235,46 @@ __device__ __forceinline__ float *ring_at(const Ring &r, int cid, int q)
     return r.base + (size_t)cid * r.R + ((r.wpos + q) & (r.R - 1));
 }
 /* every writer of the ring goes through here: the float (the reference's delay-line value) and the operand made of it */
+/* (write-through stores, `sc1`: what the cascade puts into the ring is handed to FIR waves of another launch through the ready words
+ * below, and write-through payload stores are that hand-over's cheap form -- no release fence, which would write back the whole
+ * XCD's L2 under the running FIR: MI355X_MICROARCH.md, "Valid forms", R1) */
 __device__ __forceinline__ void ring_put(const Ring &r, int cid, int q, unsigned bits)
 {
     const size_t row = (size_t)cid * r.R;
-    r.base[row + ((r.wpos + q) & (r.R - 1))] = __uint_as_float(bits);
-    if (r.wide) r.wide[row + ((r.wpos + q + 3) & (r.R - 1))] = mulop(__uint_as_float(bits));
+    __hip_atomic_store(reinterpret_cast<unsigned *>(r.base) + row + ((r.wpos + q) & (r.R - 1)), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (r.wide)
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(r.wide) + row + ((r.wpos + q + 3) & (r.R - 1)),
+                           (unsigned long long)__double_as_longlong(mulop(__uint_as_float(bits))), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+/* Cascade -> FIR inside the device, without an event between two queues ("ready words"): the cascade of launch n
+ * leaves `n` in ready[chain] once the chain's block is in the ring, the FIR wave of launch n that takes the chain waits for it.
+ * The hand-over is MI355X_MICROARCH.md's R1: the ring stores are write-through (`sc1`, ring_put), every storing wave drains them
+ * (s_waitcnt vmcnt(0)), then a relaxed agent-scope store of the word; the reader polls it relaxed (one word, all lanes the same
+ * address), then one agent-scope acquire, then plain loads.  (A first version released with an agent-scope fence per cascade wave:
+ * buffer_wbl2 writes back the XCD's whole L2, under the FIR that is filling it -- the cascade alone went 34 -> 52 us, the 4096-chain
+ * step 0.519 -> 0.541 ms.)  The numbers only grow (compared modulo 2^32), so nothing is re-armed between launches.  The poll is
+ * bounded: the cascade it waits for was enqueued before the FIR and needs nothing of it, so the bound is never met; if it ever
+ * were, the wave leaves a mark (AVDSP_OPT_READY_TIMEOUTS reads it) and goes on rather than hang the device.                  */
+__device__ __forceinline__ void chain_ready_release()
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      /* every storing wave drains its write-through ring stores (ring_put) before its chains' words go out */
+}
+__device__ __forceinline__ void chain_ready_publish(unsigned *ready, int cid, unsigned seq)
+{
+    __hip_atomic_store(ready + cid, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void chain_ready_wait(unsigned *ready, int cid, unsigned seq, unsigned *timeouts)
+{
+    unsigned spins = 0;
+    while ((int)(__hip_atomic_load(ready + cid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0) {
+        __builtin_amdgcn_s_sleep(32);
+        if (++spins > (1u << 19)) {                        /* ~ a second */
+            if ((threadIdx.x & 63) == 0) atomicAdd(timeouts, 1u);
+            break;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
 struct BlockIO {
@@ -290,6 +325,8 @@ struct BiquadArgs {
     Ring            ring;           /* where (float)X goes when a FIR follows the cascade */
     int             per_xcd;
     BlockIO         io;
+    unsigned       *ready;          /* [chain]: number of the latest launch whose cascade has left this chain's block in the ring (chain_ready below); may be null */
+    unsigned        seq;            /* ... this launch's number */
 #ifdef AVDSP_BQ_STAMPS
     unsigned long long *stamps;     /* diagnostic build (tools/cascade_timeline.py): 32 s_memtime stamps per wave */
 #endif
@@ -661,8 +698,10 @@ __global__ __launch_bounds__(kBlock) void biquad_pipe(const BiquadArgs a)
             if (owner) {
                 if (to_ring) {
                     const unsigned w = flush_word(true);
-                    rrow[ridx] = __uint_as_float(w);
-                    if (wrow) wrow[(ridx + 3u) & rmask] = mulop(__uint_as_float(w));
+                    /* (write-through, like ring_put) */
+                    __hip_atomic_store(reinterpret_cast<unsigned *>(rrow) + ridx, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (wrow) __hip_atomic_store(reinterpret_cast<unsigned long long *>(wrow) + ((ridx + 3u) & rmask),
+                                                 (unsigned long long)__double_as_longlong(mulop(__uint_as_float(w))), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 } else {
                     const unsigned w = flush_word(false);
                     if (more_stores) emit_out(io_l, oc, n_run, w);      /* (several STOREs of the same value: the general way) */
@@ -719,6 +758,10 @@ __global__ __launch_bounds__(kBlock) void biquad_pipe(const BiquadArgs a)
             const avdsp_chain c2 = a2.chains[cid];
             cascade_in_reference_order<FMT>(a2, cid, c2);
         }
+    }
+    if (a.ready) {                                      /* the chains' blocks are in the ring: say so (a chain's lanes sit in one wave) */
+        chain_ready_release();
+        if (have_chain && s == 0 && c.fir_taps) chain_ready_publish(a.ready, cid, a.seq);
     }
     BQ_STAMP(29);
 }
@@ -842,9 +885,13 @@ __global__ __launch_bounds__(kBlock) void biquad_row(const BiquadArgs a)
     const unsigned owrap = to_ring ? (unsigned)ring_l.R * 4u - 1u : 0xFFFFFFFFu;
     const bool dosat = FMT == 6 && c_sat && !to_ring;
     unsigned ooff = 0;
+    const bool wt = a.ready != nullptr;               /* the launch's rings are handed over through ready words: write-through stores (ring_put) */
     auto store_lean = [&](unsigned w) __attribute__((always_inline)) {
         const unsigned v = dosat ? __float_as_uint(__builtin_amdgcn_fmed3f(__uint_as_float(w), -1.0f, 1.0f)) : w;     /* = saturate_f32_0db for every value but a NaN (the replay's business) */
-        if (have_chain) *reinterpret_cast<unsigned *>(obase + ooff) = v;
+        if (have_chain) {
+            if (wt) __hip_atomic_store(reinterpret_cast<unsigned *>(obase + ooff), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else *reinterpret_cast<unsigned *>(obase + ooff) = v;
+        }
         ooff = (ooff + oinc) & owrap;
     };
 
@@ -1009,6 +1056,10 @@ __global__ __launch_bounds__(kBlock) void biquad_row(const BiquadArgs a)
         const BiquadArgs a2 = a;
         const avdsp_chain c2 = a2.chains[cid];
         cascade_in_reference_order<FMT>(a2, cid, c2);
+    }
+    if (a.ready) {                                      /* the rows' blocks are in the ring: say so */
+        chain_ready_release();
+        if (have_chain && rp == 15 && to_ring) chain_ready_publish(a.ready, cid, a.seq);
     }
     BQ_STAMP(29);
 }
@@ -1284,9 +1335,12 @@ __global__ __launch_bounds__(64) void biquad_simple(const BiquadArgs a)
 {
     if constexpr (FMT != 2) flush_f32_subnormals_like_the_reference();
     const int slot = blockIdx.x * 64 + threadIdx.x;
-    if (slot >= a.ngroup) return;
-    const int cid = a.group[slot];
-    cascade_in_reference_order<FMT>(a, cid, a.chains[cid]);
+    const int cid = slot < a.ngroup ? a.group[slot] : -1;
+    if (cid >= 0) cascade_in_reference_order<FMT>(a, cid, a.chains[cid]);
+    if (a.ready) {
+        chain_ready_release();
+        if (cid >= 0 && a.chains[cid].fir_taps) chain_ready_publish(a.ready, cid, a.seq);
+    }
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -1521,6 +1575,7 @@ struct FirTileArgs {
     int *buf; const avdsp_chain *chains; const int *group; int ngroup; Ring ring; int per_xcd;
     const double *taps64; int pitch64;       /* f64 copy of the taps, [chain id][pitch64] */
     BlockIO io;
+    unsigned *ready; unsigned seq; unsigned *timeouts;      /* chain_ready_wait: null = the launch is ordered behind its cascades by the stream / an event */
 #ifdef AVDSP_FIR_STAMPS
     unsigned long long *stamps;              /* diagnostic build (tools/fir_timeline.py): 32 s_memtime stamps per wave */
 #endif
@@ -1591,6 +1646,7 @@ __global__ __launch_bounds__(kBlock, 2) void fir_tile(const FirTileArgs a)
     const int cid = __builtin_amdgcn_readfirstlane(a.group[slot]);
     const avdsp_chain c = a.chains[cid];
     const int T = __builtin_amdgcn_readfirstlane(c.fir_taps);
+    if (a.ready && c.nsec) chain_ready_wait(a.ready, cid, a.seq, a.timeouts);       /* the chain's cascade of this launch has left its block in the ring */
     double *hs = lds + (size_t)wv * G::LDS_DOUBLES, *ws = hs + 2 * G::HLEN;     /* taps images at hs and hs + HLEN */
     const double *hbuf = a.taps64 + (size_t)cid * a.pitch64;
     const float *ringrow = a.ring.base + (size_t)cid * a.ring.R;
@@ -2527,6 +2583,7 @@ struct Plan {
     std::vector<int> s_loaded, s_stored;                 /* the IOs the strands load / store: per call against the windows */
     bool stores_whole_window = false;                    /* every IO of [io_out_min, io_out_max] is stored by some chain */
     bool overlap_ok = false;                             /* every cascade of the plan feeds a FIR: its launches may run under the previous block's FIR */
+    unsigned *d_ready = nullptr; unsigned seq = 0;       /* [nchains] ready words (chain_ready_*): the number of the latest launch whose cascade is through, and the launch counter */
 };
 
 }  // namespace
@@ -2539,6 +2596,7 @@ struct avdsp_hip_prog {
     unsigned *d_frame = nullptr; int frame_words = 0;     /* samples[] frame of the general interpreter */
     std::vector<Plan> plans;
     unsigned *d_in = nullptr, *d_out = nullptr; size_t in_cap = 0, out_cap = 0;   /* host-call staging */
+    unsigned *d_alias = nullptr; size_t alias_cap = 0;    /* copy of the input block of an in-place device call (avdsp_hip_run_block) */
     static constexpr int kSmallWords = 4096;             /* host calls of up to that many sample words (dspRuntime_N) ... */
     unsigned *h_small = nullptr, *d_small = nullptr;     /* ... go through a pinned area the kernels access in place */
     /* optional per-kernel timing with HIP events on the launch stream (avdsp_hip_profile_*) */
@@ -2546,7 +2604,8 @@ struct avdsp_hip_prog {
     unsigned profile = 0;               /* bit k: time the launches of kind k (AVDSP_KERNEL_*) */
     int profile_stride = 1;             /* ... every profile_stride-th of them (an event pair costs the stream ~5 us) */
     unsigned profile_seen[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    struct Span { int kind; hipEvent_t a, b; };
+    struct Span { int kind; hipEvent_t a, b; bool pair; };   /* pair: two events recorded around the launch (reads ~5 us more than the kernel took), else the dispatch's own stamps */
+    int last_read_pairs[8] = {0, 0, 0, 0, 0, 0, 0, 0};       /* avdsp_hip_profile_read: how many of the spans it summed were event pairs */
     std::vector<Span> spans;            /* recorded, not yet read */
     std::vector<hipEvent_t> free_events;
     /* cores of one level side by side (avdsp_hip_run_levels): side streams and their fork / join events */
@@ -2565,6 +2624,8 @@ struct avdsp_hip_prog {
     hipStream_t s_fir[2] = {nullptr, nullptr};           /* "overlap" 2: the FIRs of consecutive blocks in turn */
     static constexpr int kAhead = 3;     /* cascade k waits for FIR k - kAhead: it may run under FIR k - 2 and be done before FIR k - 1 ends */
     hipEvent_t ev_bq[kAhead] = {nullptr, nullptr, nullptr}, ev_fir[kAhead] = {nullptr, nullptr, nullptr};
+    int ready_words = 1;                 /* "overlap": the FIR waits for its cascades through the plans' ready words (in the kernel) instead of an event between the two queues */
+    unsigned *d_ready_timeouts = nullptr;        /* waves whose bounded wait for a ready word ran out (never, see chain_ready_wait) */
     int *d_tag_prev = nullptr;           /* tagoutput: the plugin's `previoussample` */
     /* host-pointer block calls: the caller's buffers pinned in place (cache), copies and kernels on three streams */
     struct Pinned { const void *ptr; size_t bytes; bool ours; int refs; };   /* refs: queued blocks still copying from / into it */
@@ -2608,6 +2669,7 @@ void free_plan(Plan &p)
     for (auto &g : p.bq) { (void)hipFree(g.d_ids); (void)hipFree(g.d_rows); (void)hipFree(g.d_lanes); }
     (void)hipFree(p.d_sops); (void)hipFree(p.d_sargs); (void)hipFree(p.d_lseq); (void)hipFree(p.d_lane_rows);
     (void)hipFree(p.d_fir_ids); (void)hipFree(p.d_pass_ids); (void)hipFree(p.d_ring); (void)hipFree(p.d_ring64); (void)hipFree(p.d_own); (void)hipFree(p.d_taps64);
+    (void)hipFree(p.d_ready);
 }
 
 int fir_groups_per_chunk(int max_taps)
@@ -2645,20 +2707,20 @@ struct ProfileScope {
     {
         on = (prog->profile >> kind & 1u) && prog->profile_seen[kind & 7]++ % (unsigned)prog->profile_stride == 0;
     }
-    void keep(hipEvent_t s, hipEvent_t e)
+    void keep(hipEvent_t s, hipEvent_t e, bool pair)
     {
         if (prog->spans.size() >= 65536) {                 /* nobody reads the timers: forget the oldest half (their events go back to the pool) */
             for (size_t i = 0; i < 32768; i++) { prog->free_events.push_back(prog->spans[i].a); prog->free_events.push_back(prog->spans[i].b); }
             prog->spans.erase(prog->spans.begin(), prog->spans.begin() + 32768);
         }
-        prog->spans.push_back({kind, s, e});
+        prog->spans.push_back({kind, s, e, pair});
     }
     bool ride(hipEvent_t &s, hipEvent_t &e)                /* events for hipExtLaunchKernel's start / stop slots, if this launch is sampled */
     {
         if (!on) return false;
         s = take_event(prog); e = take_event(prog);
         if (!s || !e) { if (s) prog->free_events.push_back(s); if (e) prog->free_events.push_back(e); return false; }
-        keep(s, e);
+        keep(s, e, false);
         return true;
     }
     void begin() { if (on && !a && (a = take_event(prog))) (void)hipEventRecord(a, stream); }
@@ -2668,7 +2730,7 @@ struct ProfileScope {
         hipEvent_t b = take_event(prog);
         if (!b) { prog->free_events.push_back(a); return; }
         (void)hipEventRecord(b, stream);
-        keep(a, b);
+        keep(a, b, true);
     }
 };
 
@@ -2704,6 +2766,7 @@ int launch_biquad(avdsp_hip_prog *prog, Plan &pl, const Plan::Group &g, const in
     BiquadArgs a{};
     a.buf = prog->d_buf; a.chains = pl.d_chains; a.sec_coef = pl.d_sec_coef; a.sec_state = pl.d_sec_state;
     a.group = ids; a.ngroup = n; a.nsec = g.nsec; a.ring = plan_ring(pl); a.io = io;
+    a.ready = pl.d_ready; a.seq = pl.seq;               /* (plans whose cascades all feed FIRs; kept up in every mode, so the modes may alternate) */
 #ifdef AVDSP_BQ_STAMPS
     {
         static unsigned long long *d_stamps = nullptr;
@@ -2758,12 +2821,12 @@ extern "C" int avdsp_hip_debug_fir_stamps(unsigned long long *host_out, int max_
 #endif
 
 template <int FMT, int R, bool BIG = false>
-int launch_fir_tile(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, BlockIO io, hipStream_t stream, ProfileScope &scope)
+int launch_fir_tile(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, BlockIO io, hipStream_t stream, ProfileScope &scope, bool wait_ready)
 {
-    (void)prog;
     FirTileArgs a{};
     a.buf = prog->d_buf; a.chains = pl.d_chains; a.group = ids; a.ngroup = n;
     a.ring = plan_ring(pl); a.io = io; a.taps64 = pl.d_taps64; a.pitch64 = pl.pitch64;
+    if (wait_ready) { a.ready = pl.d_ready; a.seq = pl.seq; a.timeouts = prog->d_ready_timeouts; }
     const int nwg = (n * TileGeom<R, BIG>::WPC + 3) / 4;
     a.per_xcd = (nwg + 7) / 8;
     const size_t lds = (size_t)4 * TileGeom<R, BIG>::LDS_DOUBLES * sizeof(double) + 64;      /* + the four words the waves exchange at the end */
@@ -2816,9 +2879,9 @@ int launch_fir_stream(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, Blo
 
 /* fir_impl: 0 = fir_plain (the reference's loop), 1 = fir_tile (default), 2 = fir_mfma (round 1's workgroup-per-channel kernel) */
 template <int FMT>
-int launch_fir(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, BlockIO io, int fir_impl, hipStream_t stream)
+int launch_fir(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, BlockIO io, int fir_impl, hipStream_t stream, bool wait_ready = false)
 {
-    if constexpr (FMT == 2) { (void)prog; (void)pl; (void)ids; (void)n; (void)io; (void)fir_impl; (void)stream; return 0; }
+    if constexpr (FMT == 2) { (void)prog; (void)pl; (void)ids; (void)n; (void)io; (void)fir_impl; (void)stream; (void)wait_ready; return 0; }
     else {
         ProfileScope scope(prog, stream, AVDSP_KERNEL_FIR);
         if (fir_impl != 1) scope.begin();
@@ -2839,10 +2902,10 @@ int launch_fir(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, BlockIO io
             while (rows > 1 && 128 * rows >= io.nframes) rows >>= 1;       /* a tile twice the block would multiply zeros */
             /* one row tile and at most a wave per SIMD (1024): chunks twice as long -- nothing hides a boundary there */
             const long long waves1 = (long long)n * ((io.nframes + 255) / 256);
-            if (rows == 1 && waves1 <= 1024 && prog->fir_rows != 1) return launch_fir_tile<FMT, 1, true>(prog, pl, ids, n, io, stream, scope);
-            return rows == 4 ? launch_fir_tile<FMT, 4>(prog, pl, ids, n, io, stream, scope)
-                 : rows == 2 ? launch_fir_tile<FMT, 2>(prog, pl, ids, n, io, stream, scope)
-                             : launch_fir_tile<FMT, 1>(prog, pl, ids, n, io, stream, scope);
+            if (rows == 1 && waves1 <= 1024 && prog->fir_rows != 1) return launch_fir_tile<FMT, 1, true>(prog, pl, ids, n, io, stream, scope, wait_ready);
+            return rows == 4 ? launch_fir_tile<FMT, 4>(prog, pl, ids, n, io, stream, scope, wait_ready)
+                 : rows == 2 ? launch_fir_tile<FMT, 2>(prog, pl, ids, n, io, stream, scope, wait_ready)
+                             : launch_fir_tile<FMT, 1>(prog, pl, ids, n, io, stream, scope, wait_ready);
         }
         FirArgs a{};
         a.buf = prog->d_buf; a.chains = pl.d_chains; a.group = ids; a.ngroup = n;
@@ -2897,14 +2960,17 @@ template <int FMT>
 int launch_all(avdsp_hip_prog *prog, Plan &pl, BlockIO io, int fir_impl, int biquad_impl, hipStream_t stream)
 {
     const bool under = prog->overlap && pl.overlap_ok && biquad_impl && fir_impl;
+    pl.seq++;                                             /* this launch's number in the plan's ready words */
     if (under) {
         if (overlap_ready(prog)) return -1;
+        /* fir_tile finds its cascades' blocks through the ready words; the other FIR kernels wait for the cascades' event */
+        const bool words = prog->ready_words && fir_impl == 1 && pl.d_ready && prog->d_ready_timeouts;
         const int slot = (int)(prog->blk % avdsp_hip_prog::kAhead);
         if (prog->ev_fir_set[slot]) HIP_TRY(hipStreamWaitEvent(prog->s_bq, prog->ev_fir[slot], 0));   /* FIR k-3 */
         if (prog->input_ready) HIP_TRY(hipStreamWaitEvent(prog->s_bq, prog->input_ready, 0));           /* (queued host blocks: the copy of this block) */
         for (size_t gi = 0; gi < pl.bq.size(); gi++) {        /* (the last group's kernel carries the event: the stream is in order) */
             auto &g = pl.bq[gi];
-            if (launch_biquad<FMT>(prog, pl, g, g.d_ids, g.n, io, biquad_impl, prog->s_bq, gi + 1 == pl.bq.size() ? prog->ev_bq[slot] : nullptr)) return -1;
+            if (launch_biquad<FMT>(prog, pl, g, g.d_ids, g.n, io, biquad_impl, prog->s_bq, !words && gi + 1 == pl.bq.size() ? prog->ev_bq[slot] : nullptr)) return -1;
         }
         if (prog->overlap >= 2) {
             /* the FIRs of consecutive blocks on two streams of the library's own, in turn: FIR k+1 needs nothing of FIR k, and on one
@@ -2912,13 +2978,16 @@ int launch_all(avdsp_hip_prog *prog, Plan &pl, BlockIO io, int fir_impl, int biq
              * k's last ones leave.  The caller's stream only waits for each FIR's end.  (The mode's contract then covers the output
              * too: the block a call writes must not be one an earlier call's FIR may still be writing.) */
             hipStream_t fs = prog->s_fir[prog->blk & 1];
-            HIP_TRY(hipStreamWaitEvent(fs, prog->ev_bq[slot], 0));
-            if (launch_fir<FMT>(prog, pl, pl.d_fir_ids, pl.n_fir, io, fir_impl, fs)) return -1;
+            if (!words) HIP_TRY(hipStreamWaitEvent(fs, prog->ev_bq[slot], 0));
+            if (launch_fir<FMT>(prog, pl, pl.d_fir_ids, pl.n_fir, io, fir_impl, fs, words)) return -1;
             HIP_TRY(hipEventRecord(prog->ev_fir[slot], fs));
             HIP_TRY(hipStreamWaitEvent(stream, prog->ev_fir[slot], 0));
         } else {
-            HIP_TRY(hipStreamWaitEvent(stream, prog->ev_bq[slot], 0));
-            if (launch_fir<FMT>(prog, pl, pl.d_fir_ids, pl.n_fir, io, fir_impl, stream)) return -1;
+            /* The FIR follows the previous block's FIR on the caller's stream with nothing in between: an event wait here -- a barrier
+             * packet on another queue's signal -- holds the next dispatch back by ~9 us even when the signal is long down
+             * (tools/step_gaps.py: 10.7 us between two FIRs of the 4096-chain program, 1.5-2 us between two kernels of one queue). */
+            if (!words) HIP_TRY(hipStreamWaitEvent(stream, prog->ev_bq[slot], 0));
+            if (launch_fir<FMT>(prog, pl, pl.d_fir_ids, pl.n_fir, io, fir_impl, stream, words)) return -1;
             HIP_TRY(hipEventRecord(prog->ev_fir[slot], stream));
         }
         prog->ev_fir_set[slot] = true;
@@ -2970,6 +3039,7 @@ avdsp_hip_prog *avdsp_hip_prog_create(int total_words)
     /* + 2 words: the interpreter fetches the two words behind every head word, also behind the last one */
     hipError_t e = hipMalloc((void **)&p->d_buf, ((size_t)(total_words > 0 ? total_words : 1) + 2) * sizeof(int));
     if (e != hipSuccess) { set_err("hipMalloc(mirror, %d words): %s", total_words, hipGetErrorString(e)); delete p; return nullptr; }
+    if (hipMalloc((void **)&p->d_ready_timeouts, 16) != hipSuccess || hipMemset(p->d_ready_timeouts, 0, 16) != hipSuccess) p->d_ready_timeouts = nullptr;   /* (without it the FIR waits for events) */
     return p;
 }
 
@@ -3000,7 +3070,7 @@ void avdsp_hip_prog_destroy(avdsp_hip_prog *p)
     for (int i = 0; i < avdsp_hip_prog::kAhead; i++) { if (p->ev_bq[i]) (void)hipEventDestroy(p->ev_bq[i]); if (p->ev_fir[i]) (void)hipEventDestroy(p->ev_fir[i]); }
     (void)hipFree(p->d_buf); (void)hipFree(p->d_in); (void)hipFree(p->d_out); (void)hipFree(p->d_tpdf); (void)hipFree(p->d_frame);
     (void)hipHostFree(p->h_small);
-    (void)hipFree(p->d_tpdf_seq);
+    (void)hipFree(p->d_tpdf_seq); (void)hipFree(p->d_ready_timeouts); (void)hipFree(p->d_alias);
     delete p;
 }
 
@@ -3138,6 +3208,10 @@ int avdsp_hip_prog_add_plan(avdsp_hip_prog *prog, const avdsp_plan_desc *d)
     pl.overlap_ok = pl.n_fir > 0 && !pl.bq.empty();
     for (int i = 0; i < d->nchains && pl.overlap_ok; i++)
         if (chains[i].nsec && !chains[i].fir_taps) pl.overlap_ok = false;
+    if (pl.overlap_ok) {                                  /* ready words, all at launch number 0 */
+        if (hipMalloc((void **)&pl.d_ready, (size_t)d->nchains * sizeof(unsigned)) != hipSuccess ||
+            hipMemset(pl.d_ready, 0, (size_t)d->nchains * sizeof(unsigned)) != hipSuccess) { free_plan(pl); return set_err("hipMalloc(ready words)"); }
+    }
     prog->plans.push_back(pl);
     return (int)prog->plans.size() - 1;
 }
@@ -3244,10 +3318,28 @@ int avdsp_hip_prog_add_generic(avdsp_hip_prog *prog, const avdsp_generic_desc *d
     return (int)prog->plans.size() - 1;
 }
 
+static int plan_add_strands(avdsp_hip_prog *prog, Plan &pl, const avdsp_strand_desc *d);
+
+/* A strand plan is an extra on a generic plan that is complete without it: when it cannot be attached (a shape the kernel's tables do
+ * not hold, an offset that fails the checks below, a device that refuses the LDS request), nothing of it stays behind -- the plan then
+ * runs through the interpreter as if it had never been asked -- and the caller learns why from the return value and the message. */
 int avdsp_hip_plan_add_strands(avdsp_hip_prog *prog, int plan, const avdsp_strand_desc *d)
 {
     if (plan < 0 || plan >= (int)prog->plans.size() || !prog->plans[plan].generic) return set_err("strand plan: %d is not a generic plan", plan);
     Plan &pl = prog->plans[plan];
+    const int rc = plan_add_strands(prog, pl, d);
+    if (rc) {
+        (void)hipFree(pl.d_sops); (void)hipFree(pl.d_sargs);
+        pl.d_sops = nullptr; pl.d_sargs = nullptr;
+        pl.s_loaded.clear(); pl.s_stored.clear();
+        pl.s_nops = pl.s_nargs = pl.s_nstrands = pl.s_nres = 0; pl.s_usey = false;
+    }
+    return rc;
+}
+
+static int plan_add_strands(avdsp_hip_prog *prog, Plan &pl, const avdsp_strand_desc *d)
+{
+    const int aw = (pl.format == 3 || pl.format == 5) ? 1 : 2;      /* words of an accumulator in memory */
     if (d->nops < 1 || d->nstrands < 1 || d->nargs < 1) return set_err("strand plan: empty");
     if (d->nops > kStrandMaxOps) return set_err("strand plan: %d operations per strand (the kernel's list holds %d)", d->nops, kStrandMaxOps);
     std::vector<avdsp_strand_op> ops(d->ops, d->ops + d->nops);
@@ -3266,11 +3358,11 @@ int avdsp_hip_plan_add_strands(avdsp_hip_prog *prog, int plan, const avdsp_stran
             case AVDSP_SOP_LOAD_GAIN: ok = row[o.a0] >= 0 && row[o.a0] < prog->frame_words && word_ok(row[o.a1], 1); pl.s_loaded.push_back(row[o.a0]); break;
             case AVDSP_SOP_STORE: ok = row[o.a0] >= 0 && row[o.a0] < prog->frame_words; pl.s_stored.push_back(row[o.a0]); break;
             case AVDSP_SOP_GAIN: case AVDSP_SOP_SAT0DB_GAIN: case AVDSP_SOP_SAT0DB_TPDF_GAIN: ok = word_ok(row[o.a0], 1); break;
-            case AVDSP_SOP_LOAD_MEM: case AVDSP_SOP_STORE_MEM: ok = word_ok(row[o.a0], 2); break;
+            case AVDSP_SOP_LOAD_MEM: case AVDSP_SOP_STORE_MEM: ok = word_ok(row[o.a0], aw); break;
             case AVDSP_SOP_DELAY: case AVDSP_SOP_DELAY_DP:
                 {   /* the line: the first word is its size in samples when a parameter word gives the delay, else microseconds */
                     const long long nline = row[o.a2] ? (long long)row[o.a0] : (long long)(((unsigned long long)(unsigned)row[o.a0] * pl.ga.delay_factor) >> 32);
-                    ok = row[o.a0] >= 0 && word_ok(row[o.a1], 1) && (long long)row[o.a1] + 1 + nline * (o.op == AVDSP_SOP_DELAY_DP ? 2 : 1) <= prog->total_words &&
+                    ok = row[o.a0] >= 0 && word_ok(row[o.a1], 1) && (long long)row[o.a1] + 1 + nline * (o.op == AVDSP_SOP_DELAY_DP ? aw : 1) <= prog->total_words &&
                          (row[o.a2] == 0 || word_ok(row[o.a2], 1));
                 }
                 break;
@@ -3279,13 +3371,12 @@ int avdsp_hip_plan_add_strands(avdsp_hip_prog *prog, int plan, const avdsp_stran
                 break;
             default: break;
             }
-            if (!ok) { pl.s_loaded.clear(); pl.s_stored.clear(); return set_err("strand plan: strand %d addresses words or IOs outside the loaded buffer", r); }
+            if (!ok) return set_err("strand plan: strand %d addresses words or IOs outside the loaded buffer", r);
         }
     }
     if (upload_vec(&pl.d_sops, ops) || upload_vec(&pl.d_sargs, args)) return -1;
     {
         int nres = 0;
-        const int aw = (pl.format == 3 || pl.format == 5) ? 1 : 2;
         for (auto &o : ops) { if (o.rcol != nres) return set_err("strand plan: resolved columns are not laid out in order"); nres += avdsp_strand_rcols(o.op, o.imm, aw); }
         if (nres != d->nres || nres > 224) return set_err("strand plan: %d resolved columns (the kernel's table holds 224)", nres);
         pl.s_usey = false;                               /* does any operation read Y?  (else the kernel does not keep it) */
@@ -3296,8 +3387,19 @@ int avdsp_hip_plan_add_strands(avdsp_hip_prog *prog, int plan, const avdsp_stran
                                (const void *)strand_lanes<5, false>, (const void *)strand_lanes<6, false>,
                                (const void *)strand_lanes<2, true>, (const void *)strand_lanes<3, true>, (const void *)strand_lanes<4, true>,
                                (const void *)strand_lanes<5, true>, (const void *)strand_lanes<6, true>};
-        const hipError_t e = hipFuncSetAttribute(fns[pl.format - 2 + (pl.s_usey ? 5 : 0)], hipFuncAttributeMaxDynamicSharedMemorySize, 224 * 256 + 8192 + 64 + kStrandMaxOps * (int)sizeof(avdsp_strand_op));
-        if (e != hipSuccess) return set_err("hipFuncSetAttribute(strand_lanes LDS): %s", hipGetErrorString(e));
+        /* the attribute is the function's ceiling: raised to what the largest plan seen so far needs (a launch asks for its own
+         * plan's), never to the tables' limit -- a part with less LDS than that limit still runs the plans that fit */
+        static int lds_ceilings[64][10];                 /* [device][function]: the attribute is set per device */
+        int dev_now = 0;
+        HIP_TRY(hipGetDevice(&dev_now));
+        int *lds_ceiling = lds_ceilings[dev_now & 63];
+        const int fi = pl.format - 2 + (pl.s_usey ? 5 : 0);
+        const int need = std::max(nres, 1) * 256 + 8192 + 64 + d->nops * (int)sizeof(avdsp_strand_op);
+        if (need > lds_ceiling[fi]) {
+            const hipError_t e = hipFuncSetAttribute(fns[fi], hipFuncAttributeMaxDynamicSharedMemorySize, need);
+            if (e != hipSuccess) return set_err("hipFuncSetAttribute(strand_lanes LDS, %d bytes): %s", need, hipGetErrorString(e));
+            lds_ceiling[fi] = need;
+        }
     }
     pl.s_nops = d->nops; pl.s_nargs = d->nargs; pl.s_nstrands = d->nstrands; pl.s_nres = d->nres;
     return 0;
@@ -3553,6 +3655,26 @@ int avdsp_hip_run_block(avdsp_hip_prog *prog, int plan, const void *d_in, int in
         pl.ga.batch_frames = std::max(1, std::min(64, kGenericBatchLds / std::max(1, in_stride + out_stride)));
         return launch_generic(prog, pl, io, (hipStream_t)stream);
     }
+    /* In-place calls: input and output windows in the same memory (the usual way to process a block where it lies -- the IO numbers
+     * differ, the columns coincide).  The block kernels read a frame before they store it, but a cascade that met an Inf / NaN /
+     * huge exponent runs its block AGAIN from the input (the replays of biquad_row, biquad_pipe, chain_rows), and would then filter
+     * its own outputs: chains that store straight from the cascade get their input from a copy made first (a FIR stores after the
+     * cascades of its launch are through; the int64 model has no replay). */
+    {
+        const char *i0 = (const char *)d_in, *i1 = i0 + (size_t)nframes * in_stride * 4;
+        const char *o0 = (const char *)d_out, *o1 = o0 + (size_t)nframes * out_stride * 4;
+        const bool direct = pl.format != 2 && (pl.lane_mode || (!pl.bq.empty() && !pl.overlap_ok));
+        if (direct && nframes > 1 && i0 < o1 && o0 < i1) {
+            const size_t words = (size_t)nframes * in_stride;
+            if (words > prog->alias_cap) {
+                HIP_TRY(hipDeviceSynchronize());
+                (void)hipFree(prog->d_alias); prog->d_alias = nullptr; prog->alias_cap = 0;
+                HIP_TRY(hipMalloc((void **)&prog->d_alias, words * 4)); prog->alias_cap = words;
+            }
+            HIP_TRY(hipMemcpyAsync(prog->d_alias, d_in, words * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+            d_in = prog->d_alias;
+        }
+    }
     if (pl.lane_mode) {
         ProfileScope scope(prog, (hipStream_t)stream, AVDSP_KERNEL_BIQUAD); scope.begin();
         LaneArgs a{};
@@ -3625,14 +3747,32 @@ int avdsp_hip_run_block(avdsp_hip_prog *prog, int plan, const void *d_in, int in
  * receive DMA into the OLD pages.  Hence opt-in; without it the synchronous calls copy through the driver's own staging and
  * the queued calls (avdsp_hip_submit_block_host) register a block's buffers for the time the block is in flight only --
  * avdsp_hip_wait_block_host releases them as it lets the block through, so a buffer may be freed once its block is back.   */
+static void unpin_block(avdsp_hip_prog *prog, const void *ptr);
 static void pin_in_place(avdsp_hip_prog *prog, const void *ptr, size_t bytes, bool hold = false)
 {
-    for (auto &pn : prog->pinned)
-        if (pn.ptr == ptr && pn.bytes >= bytes) { pn.refs += hold; return; }
+    auto find = [&]() -> long { for (size_t i = 0; i < prog->pinned.size(); i++) if (prog->pinned[i].ptr == ptr) return (long)i; return -1; };
+    long at = find();
+    if (at >= 0 && prog->pinned[at].bytes >= bytes) { prog->pinned[at].refs += hold; return; }
+    if (at >= 0) {
+        /* the same address with more bytes than were registered: one entry per address -- the old registration goes (once no queued
+         * block copies through it any more) and the buffer is registered again at its new size */
+        if (prog->pinned[at].refs > 0) { (void)avdsp_hip_wait_block_host(prog, 0); at = find(); }      /* (the wait may have dropped the entry) */
+        if (at >= 0) {
+            if (prog->pinned[at].ours) (void)hipHostUnregister(const_cast<void *>(ptr));
+            prog->pinned.erase(prog->pinned.begin() + at);
+        }
+    }
     if (prog->pinned.size() >= 16) {
-        (void)avdsp_hip_wait_block_host(prog, 0);           /* (queued blocks may be copying from the buffers about to be released) */
-        for (auto &pn : prog->pinned) if (pn.ours) (void)hipHostUnregister(const_cast<void *>(pn.ptr));
-        prog->pinned.clear();
+        /* the table is full: registrations nobody holds go; those of queued blocks still copying (and the one a caller of this
+         * function has just taken for its other buffer) stay */
+        bool idle = false;
+        for (auto &pn : prog->pinned) idle = idle || pn.refs == 0;
+        if (!idle) (void)avdsp_hip_wait_block_host(prog, 0);
+        for (size_t i = 0; i < prog->pinned.size();) {
+            if (prog->pinned[i].refs > 0) { i++; continue; }
+            if (prog->pinned[i].ours) (void)hipHostUnregister(const_cast<void *>(prog->pinned[i].ptr));
+            prog->pinned.erase(prog->pinned.begin() + (long)i);
+        }
     }
     const hipError_t e = hipHostRegister(const_cast<void *>(ptr), bytes, hipHostRegisterDefault);
     (void)hipGetLastError();
@@ -3684,7 +3824,12 @@ int avdsp_hip_run_block_host(avdsp_hip_prog *prog, int plan, const void *h_in, i
             HIP_TRY(hipStreamCreateWithFlags(&prog->s_d2h, hipStreamNonBlocking));
         }
         HIP_TRY(hipDeviceSynchronize());                    /* earlier work of any stream has finished: the pipeline starts clean */
-        if (prog->host_pin) { pin_in_place(prog, h_in, in_words * 4); pin_in_place(prog, h_out, out_words * 4); }
+        /* (held for the call: pinning the second buffer may have to make room in the table, and must not drop the first) */
+        struct PinHold { avdsp_hip_prog *p; const void *a, *b; ~PinHold() { if (a) unpin_block(p, a); if (b) unpin_block(p, b); } } pin_hold{prog, nullptr, nullptr};
+        if (prog->host_pin) {
+            pin_in_place(prog, h_in, in_words * 4, true);   pin_hold.a = h_in;
+            pin_in_place(prog, h_out, out_words * 4, true); pin_hold.b = h_out;
+        }
         const bool whole = pl.stores_whole_window && out_io_base == pl.io_out_min && out_stride == pl.io_out_max - pl.io_out_min + 1;
         if (!whole) HIP_TRY(hipMemcpyAsync(prog->d_out, h_out, out_words * 4, hipMemcpyHostToDevice, prog->s_h2d));
         const int split = prog->host_split > 0 ? std::max(prog->host_split, 64) : nframes;
@@ -4070,6 +4215,7 @@ int avdsp_hip_prog_set_option(avdsp_hip_prog *prog, int key, int value)
     HIP_TRY(hipDeviceSynchronize());                    /* nothing in flight when the launch arrangement changes */
     switch (key) {
     case AVDSP_OPT_OVERLAP:  prog->overlap = value; for (bool &f : prog->ev_fir_set) f = false; return 0;
+    case AVDSP_OPT_READY_WORDS: prog->ready_words = value != 0; return 0;
     case AVDSP_OPT_FIR_ROWS: if (value != 0 && value != 1 && value != 2 && value != 4) return set_err("fir_tile row tiles: 0 (auto), 1, 2 or 4");
                              prog->fir_rows = value; return 0;
     case AVDSP_OPT_PROFILE_STRIDE: if (value < 1) return set_err("profile_stride: every n-th launch, n >= 1"); prog->profile_stride = value; return 0;
@@ -4085,6 +4231,15 @@ int avdsp_hip_prog_set_option(avdsp_hip_prog *prog, int key, int value)
     return set_err("unknown device option %d", key);
 }
 
+int avdsp_hip_ready_timeouts(avdsp_hip_prog *prog)
+{
+    unsigned n = 0;
+    if (!prog->d_ready_timeouts) return 0;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(&n, prog->d_ready_timeouts, sizeof n, hipMemcpyDeviceToHost));
+    return (int)std::min(n, 0x7FFFFFFFu);
+}
+
 int avdsp_hip_profile_enable(avdsp_hip_prog *prog, int on)
 {
     prog->profile = on == 1 ? ~0u : (unsigned)on >> 1;     /* 0 off, 1 every kind, otherwise 2 * (mask of kinds) */
@@ -4094,21 +4249,24 @@ int avdsp_hip_profile_enable(avdsp_hip_prog *prog, int on)
 int avdsp_hip_profile_read(avdsp_hip_prog *prog, int kind, double *total_ms, int *launches)
 {
     double sum = 0.0;
-    int n = 0;
+    int n = 0, pairs = 0;
     std::vector<avdsp_hip_prog::Span> keep;
     for (auto &sp : prog->spans) {
         if (sp.kind != kind) { keep.push_back(sp); continue; }
         HIP_TRY(hipEventSynchronize(sp.b));
         float ms = 0.0f;
         HIP_TRY(hipEventElapsedTime(&ms, sp.a, sp.b));
-        sum += ms; n++;
+        sum += ms; n++; pairs += sp.pair;
         prog->free_events.push_back(sp.a); prog->free_events.push_back(sp.b);
     }
+    prog->last_read_pairs[kind & 7] = pairs;
     prog->spans.swap(keep);
     if (total_ms) *total_ms = sum;
     if (launches) *launches = n;
     return 0;
 }
+
+int avdsp_hip_profile_last_pairs(avdsp_hip_prog *prog, int kind) { return prog->last_read_pairs[kind & 7]; }
 
 int avdsp_hip_synchronize(void *stream)
 {

@@ -259,9 +259,12 @@ class Runtime:
         """dspRuntimeBlockSubmit: the block is queued (copies and kernels of up to four blocks overlap); x and out
         (C-contiguous, the runtime's sample type) belong to the library until wait_blocks lets the block through -- keep
         them alive until then.  With set_option("host_pin", 1) their registrations are kept for reuse and the arrays must
-        stay alive until host_pin goes back to 0 (or release()).  A program with several cores queues them one after the
-        other: the cores share the output window, so core k+1 is submitted when core k's block is back.
-        Returns the number of blocks in flight."""
+        stay alive until host_pin goes back to 0 (or release()).
+        The queue overlaps blocks of SINGLE-core programs (the BASELINE chain programs).  A program with several cores shares
+        one output window between them, so core k+1 is only submitted after dspRuntimeBlockWait(0) for core k -- which drains
+        every block in flight, not just that core's: such a program runs through the queue synchronously (use run_block_all,
+        which arranges the cores on the device, for those).  Returns the number of blocks in flight after the last core's
+        submit (for a multi-core program: that core's block alone)."""
         dt = sample_dtype(self.fmt)
         if x.dtype != dt or out.dtype != dt or not x.flags.c_contiguous or not out.flags.c_contiguous:
             raise ValueError("submit_block takes C-contiguous arrays of the runtime's sample type (they are used in place)")

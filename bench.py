@@ -18,9 +18,13 @@ and the max-over-ranks time.
 Rank 0 prints ONE JSON line with, besides the contract fields:
   roofline     -- for the dominant kernel (the FIR on v_mfma_f64_16x16x4_f64 when the workload has
                   one, else the biquad cascade): algorithmic work per launch / average launch time
-                  measured with HIP events recorded by the library on the launch stream.
-  cpu_baseline -- the oracle (CPU restatement of the reference, bit-identical to it on the golden
-                  vectors) timed on this box's host cores on a bounded sample of the same workload.
+                  from the dispatches' own start / end stamps (hipExtLaunchKernel events on the launch
+                  stream; roofline.timing says which launches were sampled).
+  cpu_baseline -- the reference itself, compiled from /root/reference into oracle/_ref (kind
+                  "reference"; one process per core this job may use, plus one thread alone), timed
+                  on this box's host cores on a bounded sample of the same chain.  Only when those
+                  binaries did not travel: the oracle, the CPU restatement (kind "port").
+  verified / verified_ranks -- what every rank checked against the reference's pins before timing.
 """
 from __future__ import annotations
 
@@ -180,11 +184,16 @@ def cpu_baseline(fmt, S, T, B, budget_s=10.0):
 HEADLINE_CASE = {"north": "north_f6", "cfg3": "cfg3_f6", "cfg3i": "cfg3_f2", "cfg4": "cfg4_f6", "cfg5": "cfg5_f6"}
 
 
+class VerificationError(Exception):
+    pass
+
+
 def verify_against_reference_pins(args, make_runtime, workload, shard_rank, shard_world, torch):
     """Before anything is timed: the benchmarked workload's HEADLINE input (seed 20260104, several blocks so that FIR histories
     fill) through a fresh runtime on the same dspRuntimeBlockDevice path with the same options, this rank's columns against the
     reference's pins -- per-channel sums of the output words of every block of the case, and (whole program on one rank) the
-    SHA-256 of every block and of the final state.  Returns a description for the JSON line; raises SystemExit on a mismatch."""
+    SHA-256 of every block and of the final state.  Returns a description for the JSON line; raises VerificationError on a
+    mismatch (main() lets every rank know before any of them leaves, so that an N > 1 job ends as one)."""
     import hashlib
     from avdsp_amd import progbuilder as pb
     name = HEADLINE_CASE.get(workload)
@@ -215,15 +224,15 @@ def verify_against_reference_pins(args, make_runtime, workload, shard_rank, shar
     want = g["col_sum"][out_base:out_base + Cl]
     bad = np.nonzero(col != want)[0]
     if bad.size:
-        sys.exit(f"bench.py: VERIFICATION FAILED on shard {shard_rank}/{shard_world}: {bad.size} of {Cl} channels differ from the "
-                 f"reference's pins of {name} (first: channel {out_base + int(bad[0])})")
+        raise VerificationError(f"shard {shard_rank}/{shard_world}: {bad.size} of {Cl} channels differ from the "
+                                f"reference's pins of {name} (first: channel {out_base + int(bad[0])})")
     what = f"{name}: blocks 0..{frames // B - 1}, channels {out_base}..{out_base + Cl - 1}: per-channel word sums vs reference pins"
     if shard_world == 1:
         for k, sha_want in enumerate(case["block_sha"]):
             if hashlib.sha256(np.ascontiguousarray(out[k * B:(k + 1) * B]).tobytes()).hexdigest() != sha_want:
-                sys.exit(f"bench.py: VERIFICATION FAILED: block {k} of {name} differs from the reference (SHA-256)")
+                raise VerificationError(f"block {k} of {name} differs from the reference (SHA-256)")
         if hashlib.sha256(np.ascontiguousarray(r.sync_state()).tobytes()).hexdigest() != case["state_sha"]:
-            sys.exit(f"bench.py: VERIFICATION FAILED: final state of {name} differs from the reference (SHA-256)")
+            raise VerificationError(f"final state of {name} differs from the reference (SHA-256)")
         what += " + SHA-256 of every block and of the final state"
     r.release()
     return what
@@ -238,6 +247,7 @@ def main():
     ap.add_argument("--fir-impl", type=int, default=1)
     ap.add_argument("--biquad-impl", type=int, default=1)
     ap.add_argument("--overlap", type=int, default=1, help="cascade of the next block under the FIR of this one (the blocks are resident in HBM, which is that mode's contract): 0 off, 1 on, 2 also the FIRs of consecutive blocks on two streams in turn")
+    ap.add_argument("--ready-words", type=int, default=1, help="under --overlap: 1 the FIR waits for its cascades through per-chain ready words inside the kernel (default), 0 through an event between the two queues")
     ap.add_argument("--fir-rows", type=int, default=-1, help="fir_tile row tiles per wave: 0 auto, 1, 2, 4")
     ap.add_argument("--shard", default=None, help="RANK/WORLD: run that one shard of the program on this GPU alone (what one rank of a WORLD-GPU job does)")
     ap.add_argument("--host-buffers", action="store_true", help="also time dspRuntimeBlock_N with HOST buffers (PCIe inclusive), reported beside value")
@@ -245,10 +255,12 @@ def main():
     ap.add_argument("--host-pin", type=int, default=-1, help="pin the host buffers in place (bench.py keeps them allocated)")
     ap.add_argument("--settle", type=float, default=0.5, help="seconds of untimed steps in front of the warm-up: the chip raises its clock over the first ~0.1 s of load "
                     "(tools/fir_timeline.py: 2.15 GHz in-kernel after 6 blocks, 2.36 GHz after 200) and a short run would be timed on the ramp")
+    ap.add_argument("--profile-stride", type=int, default=0, help="time every n-th launch of the dominant kernel in the timed region with its dispatch stamps (0: the default below)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the pre-timing check of this rank's columns against the reference's pins")
-    ap.add_argument("--gather", action="store_true", help="N > 1: also time an RCCL all_gather of the ranks' [B][C/N] output blocks and an all_reduce of "
+    ap.add_argument("--gather", action="store_true", help="(the default for N > 1) also time an RCCL all_gather of the ranks' [B][C/N] output blocks and an all_reduce of "
                     "their checksums (SURVEY.md 8e: block-boundary collectives), reported BESIDE value, never inside it")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the block-boundary collectives leg")
     args = ap.parse_args()
 
     import torch                      # first: its bundled HIP runtime must be the process's only one
@@ -294,6 +306,7 @@ def main():
         rr.set_option("fir_impl", args.fir_impl)
         rr.set_option("biquad_impl", args.biquad_impl)
         rr.set_option("overlap", args.overlap)
+        rr.set_option("ready_words", args.ready_words)
         if args.fir_rows >= 0:
             rr.set_option("fir_rows", args.fir_rows)
         if args.host_split >= 0:
@@ -303,7 +316,32 @@ def main():
         return rr
 
     # What is about to be timed is checked first, on every rank: the same path, the same options, the reference's own bits
-    verified = None if args.no_verify else verify_against_reference_pins(args, make_runtime, args.workload, shard_rank, shard_world, torch)
+    # ... and the ranks of an N > 1 job leave TOGETHER when any of them fails: a rank that exited alone would leave the others in
+    # their next barrier until the launcher's timeout
+    verified, verify_error = None, None
+    if not args.no_verify:
+        try:
+            verified = verify_against_reference_pins(args, make_runtime, args.workload, shard_rank, shard_world, torch)
+            if os.environ.get("AVDSP_BENCH_FAIL_RANK") == str(rank):          # tests/: what the job does when one rank's check fails
+                raise VerificationError("forced by AVDSP_BENCH_FAIL_RANK")
+        except VerificationError as e:
+            verify_error = str(e)
+    verified_ranks = 1 if (verified is not None and not verify_error) else 0
+    if world > 1:
+        dev = "cuda" if backend == "nccl" else "cpu"
+        ok = torch.tensor([0 if verify_error else 1, 1 if (verified is not None and not verify_error) else 0], dtype=torch.int64, device=dev)
+        all_ok = ok.clone()
+        dist.all_reduce(all_ok[:1], op=dist.ReduceOp.MIN)
+        dist.all_reduce(ok[1:], op=dist.ReduceOp.SUM)
+        verified_ranks = int(ok[1].item())
+        if int(all_ok[0].item()) == 0:
+            if verify_error:
+                print(f"bench.py: VERIFICATION FAILED on rank {rank}: {verify_error}", file=sys.stderr, flush=True)
+            dist.barrier()
+            dist.destroy_process_group()
+            sys.exit(3)
+    elif verify_error:
+        sys.exit(f"bench.py: VERIFICATION FAILED: {verify_error}")
     r = make_runtime()
     r.set_option("profile", 1)
     r.set_shard(shard_rank, shard_world)
@@ -352,6 +390,7 @@ def main():
             step()
         torch.cuda.synchronize()
         bq_side = r.kernel_time(0)
+        bq_pairs = r.get_option("timing_pairs_0")
         fir_alone = r.kernel_time(1)
         r.set_option("profile", 2 * (1 << 1))              # AVDSP_KERNEL_FIR only
         r.set_option("overlap", args.overlap)
@@ -360,7 +399,11 @@ def main():
         torch.cuda.synchronize()
         r.kernel_time(1)
     # every timed launch of a short run carries its event pair (>= 16 samples); longer runs sample every n-th (a pair costs the stream ~5 us)
-    stride = 1 if args.steps <= 50 else max(1, args.steps // 32)
+    # (round 4: a launch that carries its stop event costs the stream ~5 us -- cfg3's step 39.8 us with every launch sampled, 35.8 with every
+    # fourth, 34.7 with none -- so the timed region samples every fourth launch of the dominant kernel; roofline.timing says how many that made)
+    stride = 4 if args.steps <= 64 else max(1, args.steps // 16)
+    if args.profile_stride > 0:
+        stride = args.profile_stride
     r.set_option("profile_stride", stride)
     if world > 1:
         dist.barrier()
@@ -383,7 +426,7 @@ def main():
         elapsed = float(t.item())
     # block-boundary collectives (opt-in, beside the metric): every rank's [B][C/N] output gathered on every rank, checksums summed
     gather = None
-    if args.gather and world > 1:
+    if world > 1 and not args.no_gather:
         # (shards differ by at most one chain: every rank hands over max(C/N) columns, the last one of a smaller shard unused)
         cmax = -(-C // world)
         ypad = y if Cl == cmax else torch.nn.functional.pad(y, (0, cmax - Cl))
@@ -407,8 +450,13 @@ def main():
         gather = {"all_gather_ms": t_gather * 1e3, "bytes_per_rank": int(dev_y.numel() * 4), "checksum_all_reduce_ms": t_reduce * 1e3,
                   "backend": backend}
 
-    bq_ms, bq_n = r.kernel_time(0) if bq_side is None else bq_side
+    if bq_side is None:
+        bq_ms, bq_n = r.kernel_time(0)
+        bq_pairs = r.get_option("timing_pairs_0")
+    else:
+        bq_ms, bq_n = bq_side
     fir_ms, fir_n = r.kernel_time(1)
+    fir_pairs = r.get_option("timing_pairs_1")
     # The timed kernels (fir_tile, biquad_row / biquad_pipe) carry their events in hipExtLaunchKernel's start / stop slots: the
     # dispatch's own start and end stamps, what rocprofv3's kernel trace reads, nothing on the stream -- no correction applies.
     # (Kernels launched the plain way are bracketed by two recorded events, which read ~5 us more than the kernel took:
@@ -420,11 +468,20 @@ def main():
         pairs.append((e0, e1))
     torch.cuda.synchronize()
     pair_ms = float(np.median([a.elapsed_time(b) for a, b in pairs[10:]]))
-    rides = args.fir_impl == 1 and args.biquad_impl != 0
+
+    def timing_label(n, npairs):
+        """how the library says it timed the launches it summed: by the dispatch's own stamps, or by an event pair around the launch"""
+        if n and not npairs:
+            return f"dispatch start/end stamps (hipExtLaunchKernel events) of {n} launches, every {stride}. launch of the timed region"
+        if n and npairs == n:
+            return f"event pairs recorded around {n} launches (each reads ~event_pair more than the kernel took)"
+        return f"{n - npairs} launches by dispatch stamps, {npairs} by event pairs (those read ~event_pair more)" if n else "not timed"
     fir_raw, bq_raw = fir_ms / max(fir_n, 1), bq_ms / max(bq_n, 1)
     checksum = float(y.double().abs().sum().item()) if fmt == 6 else float(y.to(torch.float64).abs().sum().item())
     if not np.isfinite(checksum) or checksum == 0.0:
         sys.exit("bench.py: output block is empty or not finite")
+    if r.get_option("ready_timeouts") != 0:
+        sys.exit("bench.py: a FIR wave gave up waiting for its cascade's ready word -- the timed region is not valid")
 
     host_rate = None
     if args.host_buffers and rank == 0:
@@ -476,7 +533,7 @@ def main():
             fir_bytes = (4.0 * Cl * B + 4.0 * (T - 1 + B) * Cl + 4.0 * T * Cl) / launches_per_step   # out, window, taps
             roof = dict(bound="mfma", kernel=kname, achieved=ach,
                         peak=PEAK_F64_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_F64_TFLOPS,
-                        timing="dispatch start/end stamps (hipExtLaunchKernel events), every timed launch" if rides else "event pairs recorded around the launch (read ~event_pair more)",
+                        timing=timing_label(fir_n, fir_pairs),
                         traffic=pmc_traffic(traffic_key, kname), traffic_source="profiles/traffic.json (committed rocprofv3 --pmc passes of this command, not this run)",
                         hbm_frac=fir_bytes / per_launch / 1e9 / PEAK_HBM_GBS,
                         launch_ms=per_launch * 1e3, launches=fir_n)
@@ -503,7 +560,7 @@ def main():
                 ops, peak, unit = 10.0 * S * Cl * B, PEAK_F64_TFLOPS, "TFLOP/s"
             ach = ops / per_launch / 1e12
             roof = dict(bound="valu", kernel=kname, achieved=ach, peak=peak, unit=unit, frac=ach / peak,
-                        timing="dispatch start/end stamps (hipExtLaunchKernel events), every timed launch" if rides else "event pairs recorded around the launch (read ~event_pair more)",
+                        timing=timing_label(bq_n, bq_pairs),
                         hbm=dict(achieved=hbm_ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=hbm_ach / PEAK_HBM_GBS),
                         hbm_frac=hbm_ach / PEAK_HBM_GBS,
                         traffic=pmc_traffic(traffic_key, kname) or pmc_traffic(traffic_key, "biquad_pipe"),
@@ -521,12 +578,14 @@ def main():
             "config": {"workload": f"{args.workload}: {C} ch x ({S} biquads + {T}-tap FIR), block {B} frames, "
                                    f"DSP_FORMAT {fmt}; {shard_txt}, no data-path collective",
                        "channels": C, "channels_per_gpu": Cl, "sections": S, "taps": T, "block": B, "format": fmt,
-                       "overlap": r.get_option("overlap"), "settle_s": args.settle, "profile_stride": stride},
+                       "overlap": r.get_option("overlap"), "ready_words": r.get_option("ready_words"), "settle_s": args.settle, "profile_stride": stride},
             "roofline": roof,
             "hbm_frac_step": step_bytes / step_s / 1e9 / PEAK_HBM_GBS,
-            "kernels_ms": {"biquad": bq_raw, "fir": fir_raw, "event_pair": pair_ms},
+            "kernels_ms": {"biquad": bq_raw, "fir": fir_raw, "event_pair": pair_ms,
+                           "biquad_timing": timing_label(bq_n, bq_pairs) + ("" if bq_side is None else "; ten untimed steps in front of the timed region, overlap off")},
         }
         line["verified"] = verified
+        line["verified_ranks"] = verified_ranks          # ranks whose own columns matched the reference's pins (every rank checks; any mismatch ends the job)
         if world > 1:
             line["ranks"] = world
             line["rank_ms_per_step"] = rank_ms

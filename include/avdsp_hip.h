@@ -168,6 +168,9 @@ int avdsp_hip_run_block_pcm_host(avdsp_hip_prog *prog, int plan, int pcm, const 
 enum { AVDSP_KERNEL_BIQUAD = 0, AVDSP_KERNEL_FIR = 1, AVDSP_KERNEL_PASS = 2, AVDSP_KERNEL_GENERIC = 3, AVDSP_KERNEL_UNPACK = 4, AVDSP_KERNEL_GENERIC_WAVE = 5, AVDSP_KERNEL_STRANDS = 6 };
 int avdsp_hip_profile_enable(avdsp_hip_prog *prog, int on);
 int avdsp_hip_profile_read(avdsp_hip_prog *prog, int kind, double *total_ms, int *launches);
+/* of the launches the latest avdsp_hip_profile_read of `kind` summed: how many were timed by an event pair recorded around the launch
+ * (which reads a few microseconds more than the kernel took) instead of the dispatch's own start / end stamps */
+int avdsp_hip_profile_last_pairs(avdsp_hip_prog *prog, int kind);
 
 /* Strand plans (round 3): a stretch of an interpreted core that is N repetitions of ONE opcode sequence with different operands
  * -- one strand per channel: LOAD[_GAIN] .. GAIN / DELAY / BIQUADS / X-Y moves .. SAT0DB[_TPDF][_GAIN] .. STORE, the shape of the
@@ -207,7 +210,11 @@ int avdsp_hip_plan_strands(const avdsp_hip_prog *prog, int plan);      /* strand
 /* Launch arrangement of the chain kernels.  AVDSP_OPT_OVERLAP 1: the cascade of block k+1 may run under the FIR of
  * block k (side stream; see launch_all in avdsp_kernels.hip) -- the caller then guarantees that a block's input is
  * complete in memory when the call is made.                                                                     */
-enum { AVDSP_OPT_OVERLAP = 0, AVDSP_OPT_PROFILE_STRIDE = 1, AVDSP_OPT_FIR_ROWS = 3, AVDSP_OPT_HOST_SPLIT = 4, AVDSP_OPT_HOST_PIN = 5 };
+enum { AVDSP_OPT_OVERLAP = 0, AVDSP_OPT_PROFILE_STRIDE = 1, AVDSP_OPT_FIR_ROWS = 3, AVDSP_OPT_HOST_SPLIT = 4, AVDSP_OPT_HOST_PIN = 5,
+       AVDSP_OPT_READY_WORDS = 6 };
+/* READY_WORDS 1 (default): under OVERLAP the FIR finds its cascades' blocks through per-chain ready words polled inside the kernel
+ * instead of an event between the two queues (0: the event, as in round 3). */
+int avdsp_hip_ready_timeouts(avdsp_hip_prog *prog);    /* waves whose bounded wait for a ready word ran out since the program was loaded (0 unless something is broken) */
 /* PROFILE_STRIDE n: with profiling on, only every n-th launch of a kind is bracketed by events */
 /* FIR_ROWS: row tiles per wave of fir_tile, 0 = auto.  HOST_SPLIT: frames per piece of a host-pointer block (copies and kernels pipelined), 0 = whole block.
  * HOST_PIN 1: pin the caller's host buffers in place and remember them (the caller keeps them allocated until it sets 0 again) */

@@ -77,10 +77,14 @@ int       dspQM32(double x, int m);         /* dsp_header.c:83-85 */
  * one frame for the next), and where the windows overlap the input is laid over the output.
  *
  * Two device paths sit behind these entry points.  A core that is a set of independent
- * LOAD|LOAD_GAIN -> BIQUADS* -> [FIR] -> [SAT0DB] -> STORE+ chains (formats 2, 4, 6) runs on the
- * parallel kernels (section-pipelined cascade, MFMA FIR).  Any other core -- X/Y arithmetic, TPDF
- * dither, delay lines, LOAD_MUX, RMS ..., and every core in formats 3 and 5 -- runs through the
- * general device interpreter.  Its frame-parallel kernel runs 64 frames of the block side by side (one
+ * LOAD|LOAD_GAIN -> BIQUADS* -> [FIR] -> [SAT0DB] -> STORE+ chains runs on parallel kernels in every
+ * format: 2, 4 and 6 on the section-pipelined cascade (biquad_row / biquad_row_i64 / biquad_pipe) and
+ * the MFMA FIR (fir_tile); 3 and 5 -- float accumulators and the truncating dspMulFloatFloat -- on
+ * chain_rows (a lane per chain and section) and fir_lane (a lane per chain and frame), with
+ * chain_lane for single frames and cascades longer than 16 sections.  Any other core -- X/Y
+ * arithmetic, TPDF dither, delay lines, LOAD_MUX, RMS ... -- runs through the general device
+ * interpreter (runs of identical strands on strand_lanes, a lane per strand).
+ * Its frame-parallel kernel runs 64 frames of the block side by side (one
  * per lane, opcode by opcode) whenever the core hands nothing from one frame to the next except
  * opcode-private state (delay lines, filter state, meters ...), which is the case for every program
  * shipped with the reference; a core that does (a frame slot or memory read before it is written, a

@@ -337,6 +337,42 @@ def test_pipelined_cascade_replays_chains_that_met_inf_or_nan(fmt, sections, tap
     assert (r.sync_state() == o.state).all()
 
 
+@pytest.mark.parametrize("fmt,sections", [(6, 16), (6, 24), (5, 8), (3, 5)])
+def test_in_place_blocks_with_inf_and_nan(fmt, sections):
+    """A device-resident block processed where it lies (input and output windows in the same memory, different IO numbers) with
+    Inf / NaN / exponent-255 samples in some channels: the cascades that replay their block after meeting such a value must
+    replay it from the INPUT, which the first pass has by then overwritten with outputs -- the library copies the input of an
+    in-place call aside first.  Against the oracle, bit for bit, outputs and state."""
+    import torch
+    C = 21
+    prog = pb.synth_program(fmt, C, sections, 0, gain=1.0)
+    blocks = [128, 300, 64]
+    n = sum(blocks)
+    flt = fmt in (5, 6)
+    x = pb.lcg_input(n, C, flt, seed=78)
+    if flt:
+        xi = x.view(np.uint32)
+        xi[5, 2] = 0x7F800000; xi[127, 4] = 0xFFC00000; xi[128, 7] = 0x7F7FFFFF; xi[129, 7] = 0x7F7FFFFF; xi[400, 11] = 0xFFFFFFFF
+        x[200:230, 15] = 3.0e38
+    else:
+        x[:, 3] = np.int32(0x7FFFFFFF); x[::2, 3] = np.int32(-0x7FFFFFFF)     # full scale through a cascade that amplifies
+    o = po.OracleProgram(fmt, prog)
+    r = rt.Runtime(fmt, prog)
+    st = torch.cuda.current_stream().cuda_stream
+    pos = 0
+    for b in blocks:
+        want = o.run_block(x[pos:pos + b], C, C)
+        buf = torch.from_numpy(x[pos:pos + b].copy()).cuda()
+        r.run_block_device(buf.data_ptr(), C, C, buf.data_ptr(), C, 0, b, st)
+        torch.cuda.synchronize()
+        got = buf.cpu().numpy()
+        bad = np.nonzero((got.view(np.uint32) != want.view(np.uint32)).any(axis=0))[0]
+        assert bad.size == 0, f"block at {pos}: channels {bad.tolist()} differ"
+        pos += b
+    assert (r.sync_state() == o.state).all()
+    r.release()
+
+
 def test_reset_keeps_store_mem_words_like_the_reference():
     """dspRuntimeReset zeroes the data area only (dsp_runtime.c:141): what DSP_STORE_MEM wrote into the
     program's parameter section is still there afterwards, also when the host never synced in between."""

@@ -303,11 +303,14 @@ def test_overlap_mode_is_bit_identical(fmt, C, S, T, fir_impl):
     x = pb.lcg_input(B * nb, C, fmt == 6, seed=5)
     o = po.OracleProgram(fmt, prog)
     want = o.run_block(x, C, C, block=B)
-    for overlap in (2, 1, 0):                                # 2: also the FIRs of consecutive blocks on two streams in turn
+    # overlap 2: also the FIRs of consecutive blocks on two streams in turn.  ready_words 1 (the default): fir_tile finds its cascades'
+    # blocks through the per-chain ready words, polled in the kernel; 0: through an event between the two queues (round 3's way)
+    for overlap, ready_words in ((2, 1), (2, 0), (1, 1), (1, 0), (0, 1)):
         r = rt.Runtime(fmt, prog)
         r.set_option("fir_impl", fir_impl)                    # fir_tile / fir_stream (the cascade then feeds the operand ring as well)
         r.set_option("overlap", overlap)
-        assert r.get_option("overlap") == overlap
+        r.set_option("ready_words", ready_words)
+        assert r.get_option("overlap") == overlap and r.get_option("ready_words") == ready_words
         xd = [torch.from_numpy(x[k * B:(k + 1) * B].copy()).cuda() for k in range(nb)]
         yd = [torch.zeros((B, C), dtype=xd[0].dtype, device="cuda") for _ in range(nb)]
         torch.cuda.synchronize()                             # the mode's contract: inputs complete when the call is made
@@ -316,8 +319,9 @@ def test_overlap_mode_is_bit_identical(fmt, C, S, T, fir_impl):
             r.run_block_device(xd[k].data_ptr(), C, C, yd[k].data_ptr(), C, 0, B, st)
         torch.cuda.synchronize()
         got = np.concatenate([y.cpu().numpy() for y in yd])
-        assert (words(got) == words(want)).all(), f"overlap={overlap}"
+        assert (words(got) == words(want)).all(), f"overlap={overlap} ready_words={ready_words}"
         assert (r.sync_state() == o.state).all()
+        assert r.get_option("ready_timeouts") == 0            # no wave ever gave up waiting for a ready word
         r.release()
         if overlap >= 2:                                      # (that mode's contract rules the next part out: an output block is not reused while in flight)
             continue
@@ -325,6 +329,7 @@ def test_overlap_mode_is_bit_identical(fmt, C, S, T, fir_impl):
         r = rt.Runtime(fmt, prog)
         r.set_option("fir_impl", fir_impl)
         r.set_option("overlap", overlap)
+        r.set_option("ready_words", ready_words)
         y1 = torch.zeros((B, C), dtype=xd[0].dtype, device="cuda")
         outs = []
         for k in range(nb):
@@ -332,32 +337,74 @@ def test_overlap_mode_is_bit_identical(fmt, C, S, T, fir_impl):
             outs.append(y1.clone())                           # (on the current stream: ordered behind the block)
         torch.cuda.synchronize()
         got = np.concatenate([y.cpu().numpy() for y in outs])
-        assert (words(got) == words(want)).all(), f"overlap={overlap}, one output buffer"
+        assert (words(got) == words(want)).all(), f"overlap={overlap} ready_words={ready_words}, one output buffer"
         r.set_option("overlap", 0)
+        r.set_option("ready_words", 1)
         r.set_option("fir_impl", 1)
         r.release()
 
 
-def test_bench_verifies_every_rank_and_reports_the_gather_leg():
-    """bench.py as the driver launches it for N = 2 (torch.distributed.run, one process per rank; both ranks share this box's one
-    GPU, so the process group is gloo): before anything is timed every rank pushes the headline input through the same
-    dspRuntimeBlockDevice path and compares ITS columns with the reference's pins (a mismatch ends the run non-zero); the JSON
-    line says so, carries the per-rank step times, and -- on request -- the timed block-boundary collectives beside the metric."""
-    import json
+def _bench_ranks(world, extra=(), env_extra=None, workload="cfg3"):
+    """bench.py as the driver launches it for N = world (torch.distributed.run, one fresh process per rank; the ranks share this
+    box's one GPU, so the process group is gloo -- RCCL refuses two ranks on one device)"""
     import subprocess
     import sys
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, AVDSP_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
-           "--settle", "0.05", "--workload", "cfg3", "--no-cpu-baseline", "--gather"]
-    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    env = dict(os.environ, AVDSP_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", **(env_extra or {}))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "4", "--warmup", "1",
+           "--settle", "0.05", "--workload", workload, "--no-cpu-baseline", *extra]
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+
+
+def test_bench_verifies_every_rank_and_reports_the_gather_leg():
+    """N = 2: before anything is timed every rank pushes the headline input through the same dspRuntimeBlockDevice path and compares
+    ITS columns with the reference's pins; the JSON line says so (verified, verified_ranks), carries the per-rank step times, and --
+    by default for N > 1 -- the timed block-boundary collectives beside the metric."""
+    import json
+    p = _bench_ranks(2)
     assert p.returncode == 0, p.stderr[-2000:]
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["ranks"] == 2 and len(line["rank_ms_per_step"]) == 2
     assert line["verified"] and "cfg3_f6" in line["verified"] and "channels 0..2047" in line["verified"]
+    assert line["verified_ranks"] == 2
     assert line["gather"]["all_gather_ms"] > 0 and line["gather"]["bytes_per_rank"] == 1024 * 2048 * 4
     assert line["config"]["channels_per_gpu"] == 2048 and line["scaling"] == "strong"
+
+
+# The GPU boxes of this pool allow at most six processes on the card at once (more and the run is killed: "process guard"), and the
+# test runner itself is one of them: five ranks is the widest rehearsal that may run here.  AVDSP_REHEARSAL_WORLD=8 runs the same
+# test at the 8-GPU node's rank count where no such limit applies (one rank per GPU there, or a box without the guard).
+REHEARSAL_WORLD = int(os.environ.get("AVDSP_REHEARSAL_WORLD", "5"))
+
+
+def test_bench_rehearsal_at_the_widest_world_this_box_allows():
+    """The north-star program's N > 1 bench line, ragged shards included (4096 chains over 5 ranks: 820 + 4 x 819): every rank
+    verifies its own columns against the reference's pins, all of them are counted, every rank's step time is listed and the
+    gather leg reports what a rank hands over."""
+    import json
+    w = REHEARSAL_WORLD
+    p = _bench_ranks(w, workload="north")
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == w and line["ranks"] == w and len(line["rank_ms_per_step"]) == w
+    assert line["verified_ranks"] == w and "north_f6" in line["verified"]
+    cmax = -(-4096 // w)
+    assert line["config"]["channels_per_gpu"] == cmax
+    assert line["gather"]["bytes_per_rank"] == 1024 * cmax * 4 and line["gather"]["all_gather_ms"] > 0
+    assert line["roofline"]["bound"] == "mfma" and line["value"] > 0
+
+
+def test_bench_ranks_leave_together_when_one_rank_fails_its_check():
+    """A rank whose columns differ from the pins must not exit alone (the others would sit in their next barrier until the
+    launcher's timeout): every rank learns of it through an all_reduce(MIN) and all leave non-zero, no JSON line."""
+    import time
+    t0 = time.time()
+    p = _bench_ranks(2, env_extra={"AVDSP_BENCH_FAIL_RANK": "1"})
+    assert p.returncode != 0
+    assert "VERIFICATION FAILED on rank 1" in p.stderr
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert time.time() - t0 < 300
