@@ -97,14 +97,14 @@ typedef struct avdsp_ctx {
     int             shard_rank, shard_world;               /* dspRuntimeSetShard: this process's slice of every chain core */
     int             numfreq_at_init;                       /* dspChangeFormat's view of the rate count (see dspRuntimeInit) */
     int             opt_profile_stride;
-    int             opt_overlap, opt_fir_rows, opt_host_split, opt_host_pin, opt_ready_words; /* launch arrangement of the chain kernels (avdsp_hip_prog_set_option) */
+    int             opt_overlap, opt_fir_rows, opt_host_split, opt_host_pin, opt_ready_words, opt_lane_hw; /* launch arrangement of the chain kernels (avdsp_hip_prog_set_option) */
     arrangement     arr[MAX_ARRANGEMENTS]; int arr_next;   /* how the cores / pieces go to the device: [0] whole program, [1..] single cores */
     int             biquad_freq_skip, mantissa;            /* this program's dspBiquadFreqSkip / dspMantissa */
     int             device_ordinal;                        /* the GPU its device copy lives on (-1: none yet) */
 } avdsp_ctx;
 
 /* no program loaded: options set now are the defaults every program starts from (and keeps following, see dspRuntimeSetOption) */
-static avdsp_ctx g_template = { .opt_ready_words = 1, .opt_fir_impl = 1, .opt_biquad_impl = 1, .opt_device = -1, .opt_interp_impl = 1, .opt_strand_split = 1, .opt_strand_lanes = 1, .shard_world = 1,
+static avdsp_ctx g_template = { .opt_lane_hw = 1, .opt_fir_impl = 1, .opt_biquad_impl = 1, .opt_device = -1, .opt_interp_impl = 1, .opt_strand_split = 1, .opt_strand_lanes = 1, .shard_world = 1,
                                 .mantissa = DSP_MANT, .device_ordinal = -1 };
 #define MAX_PROGRAMS 64
 static avdsp_ctx *g_ctx[MAX_PROGRAMS];
@@ -241,9 +241,9 @@ static int set_option_here(const char *key, int value)
     if (!strcmp(key, "interp_impl")) { G.opt_interp_impl = value; return replan(); }
     if (!strcmp(key, "strand_split")) { G.opt_strand_split = value; return replan(); }
     if (!strcmp(key, "strand_lanes")) { G.opt_strand_lanes = value; return replan(); }
-    if (!strcmp(key, "overlap") || !strcmp(key, "fir_rows") || !strcmp(key, "host_split") || !strcmp(key, "ready_words")) {
-        int *slot = key[0] == 'o' ? &G.opt_overlap : key[0] == 'f' ? &G.opt_fir_rows : key[0] == 'r' ? &G.opt_ready_words : &G.opt_host_split;
-        const int dev_key = key[0] == 'o' ? AVDSP_OPT_OVERLAP : key[0] == 'f' ? AVDSP_OPT_FIR_ROWS : key[0] == 'r' ? AVDSP_OPT_READY_WORDS : AVDSP_OPT_HOST_SPLIT;
+    if (!strcmp(key, "overlap") || !strcmp(key, "fir_rows") || !strcmp(key, "host_split") || !strcmp(key, "ready_words") || !strcmp(key, "lane_hw")) {
+        int *slot = key[0] == 'o' ? &G.opt_overlap : key[0] == 'f' ? &G.opt_fir_rows : key[0] == 'r' ? &G.opt_ready_words : key[0] == 'l' ? &G.opt_lane_hw : &G.opt_host_split;
+        const int dev_key = key[0] == 'o' ? AVDSP_OPT_OVERLAP : key[0] == 'f' ? AVDSP_OPT_FIR_ROWS : key[0] == 'r' ? AVDSP_OPT_READY_WORDS : key[0] == 'l' ? AVDSP_OPT_LANE_HW : AVDSP_OPT_HOST_SPLIT;
         if (G.dev && avdsp_hip_prog_set_option(G.dev, dev_key, value)) return fail(-10, "%s", avdsp_hip_last_error());
         *slot = value;
         return 0;
@@ -300,6 +300,7 @@ int dspRuntimeGetOption(const char *key)
     if (!strcmp(key, "strands"))     return G.last_strands;
     if (!strcmp(key, "overlap"))     return G.opt_overlap;
     if (!strcmp(key, "ready_words")) return G.opt_ready_words;
+    if (!strcmp(key, "lane_hw"))     return G.opt_lane_hw;
     if (!strncmp(key, "timing_pairs_", 13) && key[13] >= '0' && key[13] <= '7' && !key[14])      /* of the latest dspRuntimeKernelTime(kind) */
         return G.dev ? avdsp_hip_profile_last_pairs(G.dev, key[13] - '0') : 0;
     if (!strcmp(key, "ready_timeouts")) { device_current(); return G.dev ? avdsp_hip_ready_timeouts(G.dev) : 0; }
@@ -424,7 +425,7 @@ int dspRuntimeInit(opcode_t *codePtr, int maxSize, const int fs, int random, int
         const avdsp_ctx *o = &g_template;
         c->opt_fir_impl = o->opt_fir_impl; c->opt_biquad_impl = o->opt_biquad_impl; c->opt_device = o->opt_device; c->opt_profile = o->opt_profile;
         c->opt_generic = o->opt_generic; c->opt_interp_impl = o->opt_interp_impl; c->opt_strand_split = o->opt_strand_split; c->opt_strand_lanes = o->opt_strand_lanes;
-        c->opt_profile_stride = o->opt_profile_stride; c->opt_overlap = o->opt_overlap; c->opt_fir_rows = o->opt_fir_rows; c->opt_host_split = o->opt_host_split; c->opt_host_pin = o->opt_host_pin; c->opt_ready_words = o->opt_ready_words;
+        c->opt_profile_stride = o->opt_profile_stride; c->opt_overlap = o->opt_overlap; c->opt_fir_rows = o->opt_fir_rows; c->opt_host_split = o->opt_host_split; c->opt_host_pin = o->opt_host_pin; c->opt_ready_words = o->opt_ready_words; c->opt_lane_hw = o->opt_lane_hw;
         c->shard_rank = o->shard_rank; c->shard_world = o->shard_world;
         c->mantissa = DSP_MANT; c->device_ordinal = -1;
         c->code = codePtr;
@@ -1242,7 +1243,7 @@ static core_plan *get_plan_range(int format, opcode_t *core, int end_word)
         avdsp_hip_profile_enable(G.dev, G.opt_profile);
         if (avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_PROFILE_STRIDE, G.opt_profile_stride > 0 ? G.opt_profile_stride : 1) ||
             avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_OVERLAP, G.opt_overlap) || avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_FIR_ROWS, G.opt_fir_rows) ||
-            avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_READY_WORDS, G.opt_ready_words) ||
+            avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_READY_WORDS, G.opt_ready_words) || avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_LANE_HW, G.opt_lane_hw) ||
             avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_HOST_SPLIT, G.opt_host_split) || avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_HOST_PIN, G.opt_host_pin)) {
             fail(-10, "%s", avdsp_hip_last_error()); lowered_free(&L); drop_device(); return 0;
         }

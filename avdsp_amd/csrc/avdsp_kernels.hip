@@ -235,16 +235,22 @@ __device__ __forceinline__ float *ring_at(const Ring &r, int cid, int q)
     return r.base + (size_t)cid * r.R + ((r.wpos + q) & (r.R - 1));
 }
 /* every writer of the ring goes through here: the float (the reference's delay-line value) and the operand made of it */
-/* (write-through stores, `sc1`: what the cascade puts into the ring is handed to FIR waves of another launch through the ready words
- * below, and write-through payload stores are that hand-over's cheap form -- no release fence, which would write back the whole
- * XCD's L2 under the running FIR: MI355X_MICROARCH.md, "Valid forms", R1) */
-__device__ __forceinline__ void ring_put(const Ring &r, int cid, int q, unsigned bits)
+/* wt: write-through stores (`sc1`) -- what a cascade puts into the ring of a launch whose FIR waits for the chains' ready words
+ * (below) is handed to waves of ANOTHER launch, and write-through payload stores are that hand-over's cheap form: no release fence,
+ * which would write back the whole XCD's L2 under the running FIR (MI355X_MICROARCH.md, "Valid forms", R1).  Everything else stores
+ * the plain way (a write-through store drops its line from the L2: the FIR-only chains' own appends are read back at once). */
+__device__ __forceinline__ void ring_put(const Ring &r, int cid, int q, unsigned bits, bool wt = false)
 {
     const size_t row = (size_t)cid * r.R;
-    __hip_atomic_store(reinterpret_cast<unsigned *>(r.base) + row + ((r.wpos + q) & (r.R - 1)), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (r.wide)
-        __hip_atomic_store(reinterpret_cast<unsigned long long *>(r.wide) + row + ((r.wpos + q + 3) & (r.R - 1)),
-                           (unsigned long long)__double_as_longlong(mulop(__uint_as_float(bits))), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wt) {
+        __hip_atomic_store(reinterpret_cast<unsigned *>(r.base) + row + ((r.wpos + q) & (r.R - 1)), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (r.wide)
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(r.wide) + row + ((r.wpos + q + 3) & (r.R - 1)),
+                               (unsigned long long)__double_as_longlong(mulop(__uint_as_float(bits))), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    r.base[row + ((r.wpos + q) & (r.R - 1))] = __uint_as_float(bits);
+    if (r.wide) r.wide[row + ((r.wpos + q + 3) & (r.R - 1))] = mulop(__uint_as_float(bits));
 }
 
 /* Cascade -> FIR inside the device, without an event between two queues ("ready words"): the cascade of launch n
@@ -418,7 +424,7 @@ __device__ void cascade_in_reference_order(const BiquadArgs &a, int cid, const a
             st[2] = (int)xin; st[3] = (int)x1; st[4] = (int)yn; st[5] = (int)y1;
             xin = yn;
         }
-        if (c.fir_taps) ring_put(a.ring, cid, n, narrow_stage<FMT>(X));
+        if (c.fir_taps) ring_put(a.ring, cid, n, narrow_stage<FMT>(X), a.ready != nullptr);
         else emit_out(a.io, c, n, store_stage<FMT>(X, c.sat, a.io.store_mask));
     }
 }
@@ -663,7 +669,7 @@ __global__ __launch_bounds__(kBlock) void biquad_pipe(const BiquadArgs a)
         /* flush the output batch: this lane holds the result of step tb + ostep of chain `ocid` */
         const int n = tb + ostep - 1 - 2 * (nsec - 1);
         if (owner && n >= 0 && n < B) {
-            if (FMT != 2 && oc.fir_taps) ring_put(ring_l, ocid, n, flush_word(true));
+            if (FMT != 2 && oc.fir_taps) ring_put(ring_l, ocid, n, flush_word(true), a.ready != nullptr);
             else emit_out(io_l, oc, n, flush_word(false));
         }
     };
@@ -688,6 +694,7 @@ __global__ __launch_bounds__(kBlock) void biquad_pipe(const BiquadArgs a)
         double *wrow = ring_l.wide ? ring_l.wide + (size_t)ocid * ring_l.R : nullptr;
         unsigned *out_run = io_l.out + (size_t)n0 * io_l.out_stride + (oc.out_io[0] - io_l.out_base);
         const bool more_stores = owner && !to_ring && oc.n_out > 1;
+        const bool wt = a.ready != nullptr;
         int n_run = n0;
         auto batch_steady = [&](auto jc) __attribute__((always_inline)) {
             constexpr int j = decltype(jc)::value;
@@ -698,10 +705,14 @@ __global__ __launch_bounds__(kBlock) void biquad_pipe(const BiquadArgs a)
             if (owner) {
                 if (to_ring) {
                     const unsigned w = flush_word(true);
-                    /* (write-through, like ring_put) */
-                    __hip_atomic_store(reinterpret_cast<unsigned *>(rrow) + ridx, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (wrow) __hip_atomic_store(reinterpret_cast<unsigned long long *>(wrow) + ((ridx + 3u) & rmask),
-                                                 (unsigned long long)__double_as_longlong(mulop(__uint_as_float(w))), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (wt) {                             /* (write-through, like ring_put) */
+                        __hip_atomic_store(reinterpret_cast<unsigned *>(rrow) + ridx, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (wrow) __hip_atomic_store(reinterpret_cast<unsigned long long *>(wrow) + ((ridx + 3u) & rmask),
+                                                     (unsigned long long)__double_as_longlong(mulop(__uint_as_float(w))), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+                        rrow[ridx] = __uint_as_float(w);
+                        if (wrow) wrow[(ridx + 3u) & rmask] = mulop(__uint_as_float(w));
+                    }
                 } else {
                     const unsigned w = flush_word(false);
                     if (more_stores) emit_out(io_l, oc, n_run, w);      /* (several STOREs of the same value: the general way) */
@@ -865,7 +876,7 @@ __global__ __launch_bounds__(kBlock) void biquad_row(const BiquadArgs a)
     auto flush = [&](int u0, unsigned w) __attribute__((always_inline)) {
         const int n = u0 + rp - (1 + 2 * L);
         if (have_chain && n >= 0 && n < B) {
-            if (to_ring) ring_put(ring_l, cid, n, w);
+            if (to_ring) ring_put(ring_l, cid, n, w, a.ready != nullptr);
             else {
                 const unsigned v = c_sat ? __float_as_uint(saturate_f32_0db(__uint_as_float(w))) : w;
                 if (one_store) io_l.out[(size_t)n * io_l.out_stride + (rr.out_io - io_l.out_base)] = v;     /* (the record has the column: no look at the chain) */
@@ -2271,6 +2282,7 @@ struct LaneArgs {
      * tap on the mirror's delay line (single frames) */
     unsigned *seq; int pitch, hist;
     int rows_take;                   /* chains of 1 .. 16 sections run on chain_rows */
+    int lane_hw;                     /* chain_rows: the hardware's toward-zero products where the exponents allow (AVDSP_OPT_LANE_HW) */
 };
 
 template <int FMT>
@@ -2424,8 +2436,135 @@ __global__ __launch_bounds__(64) void chain_rows(const LaneArgs a, const int *id
         }
         if constexpr (!exact) { q.acc = FF(acc); q.x1 = (int)whole(x1); q.x2 = (int)whole(x2); q.y1 = (int)whole(y1); q.y2 = (int)whole(y2); }
     };
-    run(std::false_type{});
-    if (__builtin_expect(__ballot(emax >= 254) != 0, 0)) { q = q0; run(std::true_type{}); }
+    /* Round 4: the same steps with the HARDWARE's products (fir_lane_hw has the why and the probe): v_mul_f32 under round-toward-zero
+     * is dspMulFloatFloat bit for bit while both exponent fields are 1 .. 254 and sum to 128 .. 380, and the five products of a step
+     * do not wait for its sums, so a step is one switch to toward-zero, five products, one switch back, five adds -- 12 instructions
+     * where macc() above takes ~75.  What may go that way is decided by exponents again, with the wave's coefficients' range
+     * (cmin .. cmax over the non-zero exponent fields) taken once and every VALUE that is ever multiplied -- the first section's
+     * inputs as they are staged, every section's outputs as they are made, the state the block starts from -- held against
+     *     0 or an exponent field >= 153 - cmin   (products >= 2^-101: IEEE's, and every partial sum a multiple of 2^-124, so no sum is
+     *                                            ever flushed to -0.0 -- x + (+-0) is x for every x but -0.0, and a product with a zero
+     *                                            operand is +-0 here where the reference leaves the accumulator alone)
+     *     and an exponent field <= min(254, 380 - cmax);
+     * the accumulator a lane starts from must itself be +0 or >= 2^-101.  A wave that sees anything else -- before the block or
+     * in it: the look is four instructions a step -- runs the block (again) the integer way from the untouched state. */
+    auto run_hw = [&](unsigned lo_bits, unsigned hi_bits) -> bool {
+        float acc = q.acc.v;
+        float x1 = __int_as_float(q.x1), x2 = __int_as_float(q.x2), y1 = __int_as_float(q.y1), y2 = __int_as_float(q.y2);
+        const float c0 = __int_as_float(cw[0]), c1 = __int_as_float(cw[1]), c2 = __int_as_float(cw[2]), c3 = __int_as_float(cw[3]), c4 = __int_as_float(cw[4]);
+        auto out_of_band = [&](unsigned w) { const unsigned mag = w & 0x7FFFFFFFu; return (mag - 1u < lo_bits - 1u) | (mag >= hi_bits); };
+        bool bad = false;
+        const int first = fetch(s);
+        bad |= out_of_band((unsigned)first);
+        xin[0][row][s] = first;
+        __syncthreads();
+        int y = 0;
+        const int steps = B + 15;
+        /* where the last section's lane leaves frame f = t - s: the FIR's sequence buffer, or (one STORE, no FIR on the delay line) the
+         * output column -- both as a pointer that every lane advances by a frame per step; anything else the general way */
+        const bool is_last = mine && s == S - 1;
+        const bool to_seq = c.fir_taps && a.seq;
+        const bool plain_out = !c.fir_taps && c.n_out == 1;
+        unsigned *op = to_seq ? a.seq + (size_t)cid * a.pitch + a.hist - s
+                              : a.io.out + (c.out_io[0] - a.io.out_base) - (ptrdiff_t)s * a.io.out_stride;
+        const size_t ostep = to_seq ? 1 : (size_t)a.io.out_stride;
+        auto leave = [&](int f) __attribute__((always_inline)) {
+            alu_t X = FF(acc);
+            if (to_seq) *op = __float_as_uint(to_sp<FMT>(X));
+            else {
+                if (c.fir_taps) X = fir<FMT>(to_sp<FMT>(X), a.buf + c.fir_coef_word, a.buf + c.fir_state_word, c.fir_taps);
+                if (c.sat) X = sat0db<FMT>(X);
+                unsigned word;
+                if constexpr (M<FMT>::smp_int) word = (unsigned)(s31_from_float(X.v) & a.io.store_mask);
+                else word = __float_as_uint(to_sp<FMT>(X));
+                if (plain_out) *op = word; else emit_out(a.io, c, f, word);
+            }
+        };
+        /* one section update: five products toward zero, five sums to nearest (dsp_biquadSTD.h:84-119 with a float accumulator) */
+        auto update = [&](int x) __attribute__((always_inline)) {
+            const float xn = __int_as_float(x);
+            float p0, p1, p2, p3, p4;
+            asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
+                         "v_mul_f32 %[p0], %[x], %[c0]\n\t" "v_mul_f32 %[p1], %[x1], %[c1]\n\t" "v_mul_f32 %[p2], %[x2], %[c2]\n\t"
+                         "v_mul_f32 %[p3], %[y1], %[c3]\n\t" "v_mul_f32 %[p4], %[y2], %[c4]\n\t"
+                         "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0\n\t"
+                         "v_add_f32 %[acc], %[acc], %[p0]\n\t" "v_add_f32 %[acc], %[acc], %[p1]\n\t" "v_add_f32 %[acc], %[acc], %[p2]\n\t"
+                         "v_add_f32 %[acc], %[acc], %[p3]\n\t" "v_add_f32 %[acc], %[acc], %[p4]\n\t"
+                         : [acc] "+v"(acc), [p0] "=&v"(p0), [p1] "=&v"(p1), [p2] "=&v"(p2), [p3] "=&v"(p3), [p4] "=&v"(p4)
+                         : [x] "v"(xn), [x1] "v"(x1), [x2] "v"(x2), [y1] "v"(y1), [y2] "v"(y2),
+                           [c0] "v"(c0), [c1] "v"(c1), [c2] "v"(c2), [c3] "v"(c3), [c4] "v"(c4));
+            x2 = x1; x1 = xn; y2 = y1; y1 = acc;
+            y = __float_as_int(acc);
+            bad |= out_of_band((unsigned)y);
+        };
+        for (int t0 = 0; t0 < steps; t0 += 16) {
+            const int cur = (t0 >> 4) & 1;
+            const int ahead = fetch(t0 + 16 + s);
+            bad |= out_of_band((unsigned)ahead);
+            /* the row's sixteen inputs of this batch, in registers (no LDS round trip in front of a step's products) */
+            int xa[16];
+            {
+                typedef int i4 __attribute__((ext_vector_type(4)));
+                const i4 *xp = reinterpret_cast<const i4 *>(&xin[cur][row][0]);
+#pragma unroll
+                for (int j = 0; j < 4; j++) { const i4 v = xp[j]; xa[4 * j] = v[0]; xa[4 * j + 1] = v[1]; xa[4 * j + 2] = v[2]; xa[4 * j + 3] = v[3]; }
+            }
+            if (t0 >= 16 && t0 + 15 < B) {
+                /* every section of every row is busy in all sixteen steps: nothing to ask.  (Lanes without a section run along on zeros.) */
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    int x = __builtin_amdgcn_update_dpp(0, y, kRowShr1, 0xF, 0xF, false);
+                    if (s == 0) x = xa[k];
+                    update(x);
+                    if (is_last) leave(t0 + k - s);
+                    op += ostep;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    int x = __builtin_amdgcn_update_dpp(0, y, kRowShr1, 0xF, 0xF, false);
+                    if (s == 0) x = xa[k];
+                    const int f = t0 + k - s;
+                    if (mine && f >= 0 && f < B) {
+                        update(x);
+                        if (is_last) leave(f);
+                    }
+                    op += ostep;
+                }
+            }
+            xin[cur ^ 1][row][s] = ahead;
+            __syncthreads();
+        }
+        if (__ballot(bad) != 0) return false;
+        q.acc = FF(acc); q.x1 = __float_as_int(x1); q.x2 = __float_as_int(x2); q.y1 = __float_as_int(y1); q.y2 = __float_as_int(y2);
+        return true;
+    };
+    bool done = false;
+    if (a.lane_hw) {
+        /* the wave's coefficient range (non-zero exponent fields), and the state the block starts from against the band it gives */
+        unsigned cmin1 = 0xFFFFFFFFu, cmax = 0;
+        if (mine)
+            for (int k = 0; k < 5; k++) { const unsigned e = (unsigned)cw[k] >> 23 & 255u; cmin1 = min(cmin1, e - 1u); cmax = max(cmax, e); }
+        for (int d = 1; d < 64; d <<= 1) { cmin1 = min(cmin1, (unsigned)__shfl_xor((int)cmin1, d, 64)); cmax = max(cmax, (unsigned)__shfl_xor((int)cmax, d, 64)); }
+        if (cmax <= 254u) {
+            const unsigned cmin = cmin1 == 0xFFFFFFFFu ? 255u : cmin1 + 1u;       /* no non-zero coefficient: every product is a zero */
+            const unsigned lo_e = cmin >= 152u ? 1u : 153u - cmin, hi_e = min(254u, 380u - cmax);
+            const unsigned lo_bits = lo_e << 23, hi_bits = (hi_e + 1u) << 23;
+            bool bad0 = false;
+            if (mine) {
+                auto oob = [&](unsigned w) { const unsigned mag = w & 0x7FFFFFFFu; return (mag - 1u < lo_bits - 1u) | (mag >= hi_bits); };
+                const unsigned ab = __float_as_uint(q.acc.v);
+                bad0 = oob((unsigned)q.x1) | oob((unsigned)q.x2) | oob((unsigned)q.y1) | oob((unsigned)q.y2) |
+                       (ab != 0u && ((ab & 0x7FFFFFFFu) < (26u << 23) || (ab & 0x7F800000u) == 0x7F800000u));
+            }
+            if (lo_e <= hi_e && __ballot(bad0) == 0) done = run_hw(lo_bits, hi_bits);
+            if (!done) q = q0;
+        }
+    }
+    if (!done) {
+        run(std::false_type{});
+        if (__builtin_expect(__ballot(emax >= 254) != 0, 0)) { q = q0; run(std::true_type{}); }
+    }
     if (mine) bq_store<FMT>(q, stw);
 }
 
@@ -2546,6 +2685,144 @@ __global__ __launch_bounds__(kFirLaneFrames) void fir_lane(const LaneArgs a)
     emit_out(a.io, c, n, word);
 }
 
+/* fir_lane_hw<FMT> (round 4): fir_lane with the HARDWARE's product wherever the hardware gives the reference's bits.
+ *
+ * dspMulFloatFloat (dsp_ieee754.h:335-375) is the exact 24 x 24-bit mantissa product cut to 24 bits: for operands with biased
+ * exponents 1 .. 254 whose exponents sum to 128 .. 380 that IS v_mul_f32 under MODE.FP_ROUND = toward zero, bit for bit
+ * (tools/rtz_mul_probe.hip: 0 of 535 747 pairs on every boundary of mantissa and carry differ; what differs is everything the
+ * reference does not treat the IEEE way -- exponent sums of 127 and less (the reference looks before the carry and returns +0, the
+ * hardware returns a signed zero or, on a carry at 127, the smallest normal number), exponent fields that overflow, an exponent of
+ * 255 read as 2^128, +0 for a zero operand whatever the other is).  The adds stay at round-to-nearest: the mode is switched by
+ * s_setreg_imm32_b32 around groups of products (the switch is taken at once and costs 2 % at two per 32 instructions, same probe;
+ * a v_mul_f64 + v_cvt_f32_f64 pair under the DOUBLE round field does not work: the conversion obeys the single field).  Every
+ * floating-point instruction of the tap loop sits inside asm statements between its two switches -- the compiler knows nothing of
+ * the mode and must not find an add to move across one.
+ *
+ * Which chunks may take that path is decided from the OPERANDS' exponents, once per chunk and workgroup, while they are staged:
+ * with xmin / xmax the smallest non-zero and the largest exponent field among the chunk's inputs and hmin / hmax the taps',
+ *     xmin + hmin >= 153   every product of two non-zero-exponent operands has an exponent field >= 26: it is IEEE's (>= 128 is what
+ *                          that takes), and every partial sum is a multiple of 2^-124 -- never subnormal, so never flushed to -0.0,
+ *                          which matters because a product with a zero-exponent operand is +-0 here and "the accumulator stays" in
+ *                          the reference (interp::fmacc): x + (+-0) is x for every x but -0.0;
+ *     xmax + hmax <= 380, xmax, hmax <= 254   no exponent field fills up, no Inf / NaN operand.
+ * Audio passes (a 24-bit LSB is exponent 103, taps down to 1e-15 are 77); a chunk that does not -- decays into the last few
+ * hundred dB, Inf / NaN, huge values -- is summed by the interpreter's own fmacc, tap by tap, as fir_lane's replay does.
+ *
+ * A lane sums TWO adjacent frames (2 t, 2 t + 1 of the workgroup's 512): their inputs at taps (e, e + 1) are one aligned pair of
+ * words P(e) = (x[f - e], x[f + 1 - e]) and the neighbours' halves -- x_A(e + 1) = P(e + 2).hi, x_B(e + 1) = P(e).lo -- so one
+ * ds_read_b64 serves four products; the taps are wave-uniform and come by scalar loads.  Per tap and frame: one v_mul_f32 and one
+ * v_add_f32 (fir_lane: 17 instructions). */
+constexpr int kFirHwFrames = 512;
+template <int FMT>
+__global__ __launch_bounds__(256) void fir_lane_hw(const LaneArgs a)
+{
+    using namespace interp;
+    using alu_t = typename M<FMT>::alu;
+    flush_f32_subnormals_like_the_reference();
+    constexpr int kFront = 40;                           /* zeros below ws[0]: the chunk's taps are padded to a multiple of 16 with zeros, whose inputs are read from there */
+    __shared__ __attribute__((aligned(16))) unsigned wsbuf[kFront + kFirLaneChunk + kFirHwFrames + 8];
+    __shared__ __attribute__((aligned(16))) unsigned hs[kFirLaneChunk + 16];
+    unsigned *ws = wsbuf + kFront;
+    __shared__ int rng[5];                               /* xmin - 1 (unsigned: a zero exponent counts as 2^32 - 1), xmax, hmin - 1, hmax; [4]: a lane's sum so far is -0.0 or under 2^-101 */
+    const int cid = blockIdx.x, t = threadIdx.x, n0 = blockIdx.y * kFirHwFrames;
+    const avdsp_chain c = a.chains[cid];
+    const int T = c.fir_taps;
+    if (T == 0) return;                                  /* (uniform: the whole workgroup is one chain's) */
+    const unsigned *x = a.seq + (size_t)cid * a.pitch + a.hist;          /* x[m], m = -(T-1) .. nframes-1 */
+    const unsigned *taps = reinterpret_cast<const unsigned *>(a.buf + c.fir_coef_word);
+    float accA = 0.0f, accB = 0.0f;                      /* frames n0 + 2 t and n0 + 2 t + 1 */
+    for (int i0 = 0; i0 < T; i0 += kFirLaneChunk) {
+        const int tc = min(kFirLaneChunk, T - i0);
+        /* ws[k] = x[base + k]; E = tc - 1 + pad is even, so that lane t's pair at an even tap e, (ws[2 t + E - e], ws[2 t + E - e + 1]),
+         * is 8-byte aligned: base = n0 - i0 - E */
+        const int E = (tc - 1 + 1) & ~1;
+        const int base = n0 - i0 - E, nws = E + kFirHwFrames + 2;
+        __syncthreads();
+        if (t < 5) rng[t] = (t & 1) || t == 4 ? 0 : -1;  /* (min slots start at the unsigned maximum) */
+        if (t < kFront) wsbuf[t] = 0u;
+        __syncthreads();
+        unsigned lo = 0xFFFFFFFFu, hi = 0, hlo = 0xFFFFFFFFu, hhi = 0;
+        for (int k = t; k < nws; k += 256) {
+            const int m = base + k;
+            const unsigned w = (m < a.io.nframes && m >= n0 - i0 - (tc - 1)) ? x[m] : 0u;      /* (below: the padding word no tap reads) */
+            ws[k] = w;
+            const unsigned e = w >> 23 & 255u;
+            lo = min(lo, e - 1u); hi = max(hi, e);
+        }
+        for (int k = t; k < ((tc + 15) & ~15); k += 256) {
+            const unsigned w = k < tc ? taps[i0 + k] : 0u;
+            hs[k] = w;
+            const unsigned e = w >> 23 & 255u;
+            hlo = min(hlo, e - 1u); hhi = max(hhi, e);
+        }
+        atomicMin(reinterpret_cast<unsigned *>(&rng[0]), lo); atomicMax(reinterpret_cast<unsigned *>(&rng[1]), hi);
+        atomicMin(reinterpret_cast<unsigned *>(&rng[2]), hlo); atomicMax(reinterpret_cast<unsigned *>(&rng[3]), hhi);
+        {   /* what an earlier chunk left (a chunk summed the integer way may leave anything): the multiple-of-2^-124 argument needs
+             * sums that are +0 or at least 2^-101 to start from */
+            const unsigned ba = __float_as_uint(accA), bb = __float_as_uint(accB);
+            if ((ba != 0u && (ba & 0x7FFFFFFFu) < (26u << 23)) || (bb != 0u && (bb & 0x7FFFFFFFu) < (26u << 23))) rng[4] = 1;
+        }
+        __syncthreads();
+        const unsigned xmin1 = (unsigned)rng[0], xmax = (unsigned)rng[1], hmin1 = (unsigned)rng[2], hmax = (unsigned)rng[3];
+        /* (no non-zero exponent on one side: every product is a zero) */
+        const bool hw_ok = rng[4] == 0 && xmax <= 254u && hmax <= 254u && xmax + hmax <= 380u &&
+                           (xmin1 == 0xFFFFFFFFu || hmin1 == 0xFFFFFFFFu || xmin1 + hmin1 + 2u >= 153u);
+        const unsigned *wl = ws + 2 * t + E;             /* lane t: x_A(e) = wl[-e], x_B(e) = wl[1 - e] */
+        if (__builtin_expect(!hw_ok, 0)) {
+            alu_t A = FF(accA), Bv = FF(accB);
+            for (int e = 0; e < tc; e++) {
+                const float h = __uint_as_float(taps[i0 + e]);
+                A = fmacc<FMT>(A, __uint_as_float(wl[-e]), h);
+                Bv = fmacc<FMT>(Bv, __uint_as_float(wl[1 - e]), h);
+            }
+            accA = A.v; accB = Bv.v;
+            continue;
+        }
+        /* four taps per statement: pairs P(e), P(e + 2), P(e + 4); products toward zero, sums to nearest, tap order per frame.  The
+         * taps are wave-uniform: four of them per broadcast read of the LDS image. */
+#define AVDSP_FIRHW_4(P0L, P0H, P1L, P1H, P2H, H) \
+        asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t" \
+                     "v_mul_f32 %[a0], %[h0], %[p0l]\n\t" "v_mul_f32 %[b0], %[h0], %[p0h]\n\t" \
+                     "v_mul_f32 %[a1], %[h1], %[p1h]\n\t" "v_mul_f32 %[b1], %[h1], %[p0l]\n\t" \
+                     "v_mul_f32 %[a2], %[h2], %[p1l]\n\t" "v_mul_f32 %[b2], %[h2], %[p1h]\n\t" \
+                     "v_mul_f32 %[a3], %[h3], %[p2h]\n\t" "v_mul_f32 %[b3], %[h3], %[p1l]\n\t" \
+                     "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0\n\t" \
+                     "v_add_f32 %[A], %[A], %[a0]\n\t" "v_add_f32 %[B], %[B], %[b0]\n\t" \
+                     "v_add_f32 %[A], %[A], %[a1]\n\t" "v_add_f32 %[B], %[B], %[b1]\n\t" \
+                     "v_add_f32 %[A], %[A], %[a2]\n\t" "v_add_f32 %[B], %[B], %[b2]\n\t" \
+                     "v_add_f32 %[A], %[A], %[a3]\n\t" "v_add_f32 %[B], %[B], %[b3]\n\t" \
+                     : [A] "+v"(accA), [B] "+v"(accB), [a0] "=&v"(q0), [b0] "=&v"(q1), [a1] "=&v"(q2), [b1] "=&v"(q3), \
+                       [a2] "=&v"(q4), [b2] "=&v"(q5), [a3] "=&v"(q6), [b3] "=&v"(q7) \
+                     : [p0l] "v"(P0L), [p0h] "v"(P0H), [p1l] "v"(P1L), [p1h] "v"(P1H), [p2h] "v"(P2H), \
+                       [h0] "v"(H.x), [h1] "v"(H.y), [h2] "v"(H.z), [h3] "v"(H.w))
+        for (int e = 0; e < tc; e += 16) {               /* (the image's taps beyond tc are zeros; their inputs come from the zeros below ws[0]) */
+            uint2 P[9];
+#pragma unroll
+            for (int j = 0; j < 9; j++) P[j] = *reinterpret_cast<const uint2 *>(wl - e - 2 * j);
+            uint4 H[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) H[j] = *reinterpret_cast<const uint4 *>(hs + e + 4 * j);
+            float q0, q1, q2, q3, q4, q5, q6, q7;
+            AVDSP_FIRHW_4(P[0].x, P[0].y, P[1].x, P[1].y, P[2].y, H[0]);
+            AVDSP_FIRHW_4(P[2].x, P[2].y, P[3].x, P[3].y, P[4].y, H[1]);
+            AVDSP_FIRHW_4(P[4].x, P[4].y, P[5].x, P[5].y, P[6].y, H[2]);
+            AVDSP_FIRHW_4(P[6].x, P[6].y, P[7].x, P[7].y, P[8].y, H[3]);
+        }
+#undef AVDSP_FIRHW_4
+    }
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        const int n = n0 + 2 * t + half;
+        if (n >= a.io.nframes) break;
+        alu_t X = FF(half ? accB : accA);
+        if (c.sat) X = sat0db<FMT>(X);                                          /* :464-475 */
+        unsigned word;                                                          /* :610-633 */
+        if constexpr (M<FMT>::smp_int) word = (unsigned)(s31_from_float(X.v) & a.io.store_mask);
+        else word = __float_as_uint(to_sp<FMT>(X));
+        emit_out(a.io, c, n, word);
+    }
+}
+
 /* ------------------------------------------------------------------------------------------
  * host side of the thin ABI
  * ---------------------------------------------------------------------------------------- */
@@ -2624,7 +2901,8 @@ struct avdsp_hip_prog {
     hipStream_t s_fir[2] = {nullptr, nullptr};           /* "overlap" 2: the FIRs of consecutive blocks in turn */
     static constexpr int kAhead = 3;     /* cascade k waits for FIR k - kAhead: it may run under FIR k - 2 and be done before FIR k - 1 ends */
     hipEvent_t ev_bq[kAhead] = {nullptr, nullptr, nullptr}, ev_fir[kAhead] = {nullptr, nullptr, nullptr};
-    int ready_words = 1;                 /* "overlap": the FIR waits for its cascades through the plans' ready words (in the kernel) instead of an event between the two queues */
+    int lane_hw = 1;                     /* formats 3 / 5: the hardware's toward-zero product where it is the reference's (fir_lane_hw, chain_rows' fast steps); 0: the integer products throughout */
+    int ready_words = 0;                 /* "overlap": the FIR waits for its cascades through the plans' ready words (in the kernel) instead of an event between the two queues: measured slower, off by default */
     unsigned *d_ready_timeouts = nullptr;        /* waves whose bounded wait for a ready word ran out (never, see chain_ready_wait) */
     int *d_tag_prev = nullptr;           /* tagoutput: the plugin's `previoussample` */
     /* host-pointer block calls: the caller's buffers pinned in place (cache), copies and kernels on three streams */
@@ -2760,13 +3038,13 @@ extern "C" int avdsp_hip_debug_bq_stamps(unsigned long long *host_out, int max_w
 
 template <int FMT>
 int launch_biquad(avdsp_hip_prog *prog, Plan &pl, const Plan::Group &g, const int *ids, int n, BlockIO io,
-                  int biquad_impl, hipStream_t stream, hipEvent_t stop = nullptr)
+                  int biquad_impl, hipStream_t stream, hipEvent_t stop = nullptr, bool with_ready = false)
 {
     ProfileScope scope(prog, stream, AVDSP_KERNEL_BIQUAD);
     BiquadArgs a{};
     a.buf = prog->d_buf; a.chains = pl.d_chains; a.sec_coef = pl.d_sec_coef; a.sec_state = pl.d_sec_state;
     a.group = ids; a.ngroup = n; a.nsec = g.nsec; a.ring = plan_ring(pl); a.io = io;
-    a.ready = pl.d_ready; a.seq = pl.seq;               /* (plans whose cascades all feed FIRs; kept up in every mode, so the modes may alternate) */
+    a.ready = with_ready ? pl.d_ready : nullptr; a.seq = pl.seq;      /* (a launch whose FIR waits for the words; its ring stores are then write-through) */
 #ifdef AVDSP_BQ_STAMPS
     {
         static unsigned long long *d_stamps = nullptr;
@@ -2970,7 +3248,7 @@ int launch_all(avdsp_hip_prog *prog, Plan &pl, BlockIO io, int fir_impl, int biq
         if (prog->input_ready) HIP_TRY(hipStreamWaitEvent(prog->s_bq, prog->input_ready, 0));           /* (queued host blocks: the copy of this block) */
         for (size_t gi = 0; gi < pl.bq.size(); gi++) {        /* (the last group's kernel carries the event: the stream is in order) */
             auto &g = pl.bq[gi];
-            if (launch_biquad<FMT>(prog, pl, g, g.d_ids, g.n, io, biquad_impl, prog->s_bq, !words && gi + 1 == pl.bq.size() ? prog->ev_bq[slot] : nullptr)) return -1;
+            if (launch_biquad<FMT>(prog, pl, g, g.d_ids, g.n, io, biquad_impl, prog->s_bq, !words && gi + 1 == pl.bq.size() ? prog->ev_bq[slot] : nullptr, words)) return -1;
         }
         if (prog->overlap >= 2) {
             /* the FIRs of consecutive blocks on two streams of the library's own, in turn: FIR k+1 needs nothing of FIR k, and on one
@@ -3700,6 +3978,7 @@ int avdsp_hip_run_block(avdsp_hip_prog *prog, int plan, const void *d_in, int in
         /* blocks: cascades of up to 16 sections with a lane per section (chain_rows); the rest, and single frames, a lane per chain */
         const bool rows = pl.n_lane_rows > 0 && nframes > 1;
         a.rows_take = rows ? 1 : 0;
+        a.lane_hw = prog->lane_hw;
         if (rows) {
             const dim3 rgrid((pl.n_lane_rows + 3) / 4);
             if (pl.format == 3) hipLaunchKernelGGL(chain_rows<3>, rgrid, block, 0, st, a, (const int *)pl.d_lane_rows, pl.n_lane_rows);
@@ -3714,7 +3993,13 @@ int avdsp_hip_run_block(avdsp_hip_prog *prog, int plan, const void *d_in, int in
             if (pl.format == 3) hipLaunchKernelGGL(chain_lane<3>, grid, block, 0, st, a);
             else                hipLaunchKernelGGL(chain_lane<5>, grid, block, 0, st, a);
         }
-        if (tiles) {
+        if (tiles && prog->lane_hw) {
+            /* the hardware's toward-zero product where it is the reference's (fir_lane_hw), two frames per lane */
+            const dim3 fgrid(pl.nchains, (nframes + kFirHwFrames - 1) / kFirHwFrames), fblock(256);
+            if (pl.format == 3) hipLaunchKernelGGL(fir_lane_hw<3>, fgrid, fblock, 0, st, a);
+            else                hipLaunchKernelGGL(fir_lane_hw<5>, fgrid, fblock, 0, st, a);
+            hipLaunchKernelGGL(fir_lane_state, dim3(pl.nchains, (pl.max_taps + 255) / 256), dim3(256), 0, st, a);
+        } else if (tiles) {
             const dim3 fgrid(pl.nchains, (nframes + kFirLaneFrames - 1) / kFirLaneFrames), fblock(kFirLaneFrames);
             if (pl.format == 3) hipLaunchKernelGGL(fir_lane<3>, fgrid, fblock, 0, st, a);
             else                hipLaunchKernelGGL(fir_lane<5>, fgrid, fblock, 0, st, a);
@@ -4216,6 +4501,7 @@ int avdsp_hip_prog_set_option(avdsp_hip_prog *prog, int key, int value)
     switch (key) {
     case AVDSP_OPT_OVERLAP:  prog->overlap = value; for (bool &f : prog->ev_fir_set) f = false; return 0;
     case AVDSP_OPT_READY_WORDS: prog->ready_words = value != 0; return 0;
+    case AVDSP_OPT_LANE_HW: prog->lane_hw = value != 0; return 0;
     case AVDSP_OPT_FIR_ROWS: if (value != 0 && value != 1 && value != 2 && value != 4) return set_err("fir_tile row tiles: 0 (auto), 1, 2 or 4");
                              prog->fir_rows = value; return 0;
     case AVDSP_OPT_PROFILE_STRIDE: if (value < 1) return set_err("profile_stride: every n-th launch, n >= 1"); prog->profile_stride = value; return 0;

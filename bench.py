@@ -247,7 +247,7 @@ def main():
     ap.add_argument("--fir-impl", type=int, default=1)
     ap.add_argument("--biquad-impl", type=int, default=1)
     ap.add_argument("--overlap", type=int, default=1, help="cascade of the next block under the FIR of this one (the blocks are resident in HBM, which is that mode's contract): 0 off, 1 on, 2 also the FIRs of consecutive blocks on two streams in turn")
-    ap.add_argument("--ready-words", type=int, default=1, help="under --overlap: 1 the FIR waits for its cascades through per-chain ready words inside the kernel (default), 0 through an event between the two queues")
+    ap.add_argument("--ready-words", type=int, default=0, help="under --overlap: 1 the FIR waits for its cascades through per-chain ready words inside the kernel, 0 (default) through an event between the two queues")
     ap.add_argument("--fir-rows", type=int, default=-1, help="fir_tile row tiles per wave: 0 auto, 1, 2, 4")
     ap.add_argument("--shard", default=None, help="RANK/WORLD: run that one shard of the program on this GPU alone (what one rank of a WORLD-GPU job does)")
     ap.add_argument("--host-buffers", action="store_true", help="also time dspRuntimeBlock_N with HOST buffers (PCIe inclusive), reported beside value")

@@ -211,9 +211,11 @@ int avdsp_hip_plan_strands(const avdsp_hip_prog *prog, int plan);      /* strand
  * block k (side stream; see launch_all in avdsp_kernels.hip) -- the caller then guarantees that a block's input is
  * complete in memory when the call is made.                                                                     */
 enum { AVDSP_OPT_OVERLAP = 0, AVDSP_OPT_PROFILE_STRIDE = 1, AVDSP_OPT_FIR_ROWS = 3, AVDSP_OPT_HOST_SPLIT = 4, AVDSP_OPT_HOST_PIN = 5,
-       AVDSP_OPT_READY_WORDS = 6 };
-/* READY_WORDS 1 (default): under OVERLAP the FIR finds its cascades' blocks through per-chain ready words polled inside the kernel
- * instead of an event between the two queues (0: the event, as in round 3). */
+       AVDSP_OPT_READY_WORDS = 6, AVDSP_OPT_LANE_HW = 7 };
+/* LANE_HW 1 (default): formats 3 and 5 multiply with v_mul_f32 under round-toward-zero wherever the operands' exponents make that the
+ * reference's dspMulFloatFloat bit for bit (fir_lane_hw, chain_rows); 0: the integer restatement of the product throughout. */
+/* READY_WORDS 1: under OVERLAP the FIR finds its cascades' blocks through per-chain ready words polled inside the kernel instead of
+ * an event between the two queues (0, the default: the event -- the words measured slower on every configuration). */
 int avdsp_hip_ready_timeouts(avdsp_hip_prog *prog);    /* waves whose bounded wait for a ready word ran out since the program was loaded (0 unless something is broken) */
 /* PROFILE_STRIDE n: with profiling on, only every n-th launch of a kind is bracketed by events */
 /* FIR_ROWS: row tiles per wave of fir_tile, 0 = auto.  HOST_SPLIT: frames per piece of a host-pointer block (copies and kernels pipelined), 0 = whole block.

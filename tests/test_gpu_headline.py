@@ -303,8 +303,8 @@ def test_overlap_mode_is_bit_identical(fmt, C, S, T, fir_impl):
     x = pb.lcg_input(B * nb, C, fmt == 6, seed=5)
     o = po.OracleProgram(fmt, prog)
     want = o.run_block(x, C, C, block=B)
-    # overlap 2: also the FIRs of consecutive blocks on two streams in turn.  ready_words 1 (the default): fir_tile finds its cascades'
-    # blocks through the per-chain ready words, polled in the kernel; 0: through an event between the two queues (round 3's way)
+    # overlap 2: also the FIRs of consecutive blocks on two streams in turn.  ready_words 1: fir_tile finds its cascades' blocks through
+    # the per-chain ready words, polled in the kernel; 0 (the default): through an event between the two queues
     for overlap, ready_words in ((2, 1), (2, 0), (1, 1), (1, 0), (0, 1)):
         r = rt.Runtime(fmt, prog)
         r.set_option("fir_impl", fir_impl)                    # fir_tile / fir_stream (the cascade then feeds the operand ring as well)
@@ -339,7 +339,7 @@ def test_overlap_mode_is_bit_identical(fmt, C, S, T, fir_impl):
         got = np.concatenate([y.cpu().numpy() for y in outs])
         assert (words(got) == words(want)).all(), f"overlap={overlap} ready_words={ready_words}, one output buffer"
         r.set_option("overlap", 0)
-        r.set_option("ready_words", 1)
+        r.set_option("ready_words", 0)
         r.set_option("fir_impl", 1)
         r.release()
 
@@ -375,14 +375,16 @@ def test_bench_verifies_every_rank_and_reports_the_gather_leg():
     assert line["config"]["channels_per_gpu"] == 2048 and line["scaling"] == "strong"
 
 
-# The GPU boxes of this pool allow at most six processes on the card at once (more and the run is killed: "process guard"), and the
-# test runner itself is one of them: five ranks is the widest rehearsal that may run here.  AVDSP_REHEARSAL_WORLD=8 runs the same
-# test at the 8-GPU node's rank count where no such limit applies (one rank per GPU there, or a box without the guard).
-REHEARSAL_WORLD = int(os.environ.get("AVDSP_REHEARSAL_WORLD", "5"))
+# The GPU boxes of this pool allow at most six processes on the card at once (more and the run is killed: "process guard"; five ranks
+# under the test runner were counted as seven), the test runner itself being one of them: four ranks is the widest rehearsal that may
+# run here.  AVDSP_REHEARSAL_WORLD=8 runs the same test at the 8-GPU node's rank count where no such limit applies (one rank per GPU
+# there, or a box without the guard).
+REHEARSAL_WORLD = int(os.environ.get("AVDSP_REHEARSAL_WORLD", "4"))
 
 
 def test_bench_rehearsal_at_the_widest_world_this_box_allows():
-    """The north-star program's N > 1 bench line, ragged shards included (4096 chains over 5 ranks: 820 + 4 x 819): every rank
+    """The north-star program's N > 1 bench line at the widest world the box allows (4 ranks x 1024 chains; ragged shards -- 4096
+    chains over 3 ranks -- are test_bench_ragged_shards'): every rank
     verifies its own columns against the reference's pins, all of them are counted, every rank's step time is listed and the
     gather leg reports what a rank hands over."""
     import json
@@ -396,6 +398,16 @@ def test_bench_rehearsal_at_the_widest_world_this_box_allows():
     assert line["config"]["channels_per_gpu"] == cmax
     assert line["gather"]["bytes_per_rank"] == 1024 * cmax * 4 and line["gather"]["all_gather_ms"] > 0
     assert line["roofline"]["bound"] == "mfma" and line["value"] > 0
+
+
+def test_bench_ragged_shards():
+    """4096 chains over 3 ranks (1366 + 1365 + 1365): the pins are checked per rank on its own ragged range, the gather leg pads."""
+    import json
+    p = _bench_ranks(3, workload="cfg3")
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["ranks"] == 3 and line["verified_ranks"] == 3 and line["config"]["channels_per_gpu"] == 1366
+    assert line["gather"]["bytes_per_rank"] == 1024 * 1366 * 4
 
 
 def test_bench_ranks_leave_together_when_one_rank_fails_its_check():

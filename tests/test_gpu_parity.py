@@ -494,6 +494,67 @@ def test_float_accumulator_models_with_nan_inf_and_huge_samples(sections, taps):
     _oracle_vs_device(5, prog, x, C, C, blocks).release()
 
 
+def _hw_boundary_input(n, C, seed):
+    """float samples that walk the limits of the hardware-product path of formats 3 / 5 (fir_lane_hw, chain_rows): channels of ordinary
+    noise; noise at 1e-12, 1e-22, 1e-30 and 1e-37 (the last ones under the band: the integer products take over, and sums are flushed
+    to signed zeros); bursts between runs of +0 and -0; +a / -a pairs that cancel exactly; single impulses that decay into silence."""
+    x = pb.lcg_input(n, C, True, seed=seed)
+    rng = np.random.default_rng(seed)
+    scale = [1.0, 1e-12, 1e-22, 1e-30, 1e-37, 1.0, 1.0, 1.0]
+    for c in range(C):
+        x[:, c] *= np.float32(scale[c % len(scale)])
+    xv = x.view(np.uint32)
+    if C > 5:
+        x[:, 5] = 0.0
+        x[::97, 5] = np.float32(0.25)                            # impulses, a decay behind each
+        xv[3::97, 5] = 0x80000000                                # ... and -0 samples
+    if C > 6:
+        a = rng.standard_normal(n).astype(np.float32)
+        x[0::2, 6] = a[0::2][: len(x[0::2, 6])]
+        x[1::2, 6] = -x[0::2, 6][: len(x[1::2, 6])]             # pairs that cancel
+    if C > 7:
+        x[:, 7] = 0.0
+        x[n // 3: n // 3 + 40, 7] = rng.standard_normal(40).astype(np.float32) * np.float32(1e-33)
+    return x
+
+
+@pytest.mark.parametrize("lane_hw", [1, 0])
+@pytest.mark.parametrize("sections,taps", [(0, 300), (0, 2500), (4, 0), (16, 0), (3, 700)])
+def test_float_accumulator_models_on_the_limits_of_the_hardware_product(sections, taps, lane_hw):
+    """DSP_FORMAT 5 with the products of the tap loop and of the section update made by v_mul_f32 under round-toward-zero where the
+    operands' exponents make that dspMulFloatFloat bit for bit (dsp_ieee754.h:335-375; tools/rtz_mul_probe.hip), by the integer
+    restatement elsewhere -- inputs on both sides of every condition of that choice, taps over thirty orders of magnitude; the same
+    with the option off.  Against the oracle bit for bit, outputs and state."""
+    C = 8
+    blocks = [700, 1, 64, 1024, 300]
+    n = sum(blocks)
+    tp = None
+    if taps:
+        rng = np.random.default_rng(99)
+        tp = pb.lcg_taps_all(C, taps).astype(np.float32)
+        tp[1] *= np.float32(1e-12)
+        tp[2] *= (10.0 ** rng.uniform(-30, 0, taps)).astype(np.float32)
+        tp[3] *= (10.0 ** rng.uniform(-38, -20, taps)).astype(np.float32)
+        tp[4, ::3] = 0.0
+        tp[6] = np.float32(1.0)                                   # equal taps: the cancelling pairs sum to exact zeros
+    prog = pb.synth_program(5, C, sections, taps, taps=tp)
+    x = _hw_boundary_input(n, C, seed=31 + sections + taps)
+    _oracle_vs_device(5, prog, x, C, C, blocks, opts={"lane_hw": lane_hw}).release()
+    rt.Runtime.set_global_option("lane_hw", 1)
+
+
+@pytest.mark.parametrize("gain", [1.0, 1e-9, 3e-31])
+def test_int_sample_float_accumulator_model_with_small_gains(gain):
+    """DSP_FORMAT 3 (int samples, float accumulator): LOAD_GAIN with gains that put the cascade's and the FIR's operands in the
+    band, at its edge and under it"""
+    C = 5
+    prog = pb.synth_program(3, C, 6, 500, gain=gain)
+    blocks = [600, 1, 1024, 77]
+    x = pb.lcg_input(sum(blocks), C, False, seed=5)
+    x[100:400, 2] = 0
+    _oracle_vs_device(3, prog, x, C, C, blocks).release()
+
+
 @pytest.mark.parametrize("fmt", [4, 6])
 @pytest.mark.parametrize("sections", [1, 3, 16])
 def test_signed_zeros_in_the_state_across_one_frame_blocks(fmt, sections):

@@ -18,6 +18,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--blocks", type=int, default=3)
 ap.add_argument("--frames", type=int, default=1024)
 ap.add_argument("--cases", nargs="*", default=["bq", "fir", "north"])
+ap.add_argument("--lane-hw", type=int, default=1, help="1: v_mul_f32 under round-toward-zero where it is the reference's product (round 4); 0: the integer products throughout")
 args = ap.parse_args()
 CASES = {"bq": (4096, 16, 0), "fir": (256, 0, 4096), "north": (512, 16, 4096)}
 B = args.frames
@@ -25,6 +26,7 @@ for fmt in (3, 5):
     for case in args.cases:
         C, S, T = CASES[case]
         r = rt.Runtime(fmt, pb.synth_program(fmt, C, S, T))
+        r.set_option("lane_hw", args.lane_hw)
         info = r.shard_info()
         x = torch.from_numpy(np.ascontiguousarray(pb.lcg_input(B, C, fmt == 5))).cuda()
         y = torch.zeros((B, C), dtype=x.dtype, device="cuda")
@@ -35,5 +37,5 @@ for fmt in (3, 5):
         for _ in range(args.blocks): run()
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / args.blocks
-        print(f"fmt {fmt} {case:5s}: {C} ch x ({S} sections + {T} taps), block {B}: {ms:9.3f} ms per block = {C * B / ms / 1e6:8.3f} Gsamples/s", flush=True)
+        print(f"lane_hw {args.lane_hw} fmt {fmt} {case:5s}: {C} ch x ({S} sections + {T} taps), block {B}: {ms:9.3f} ms per block = {C * B / ms / 1e6:8.3f} Gsamples/s", flush=True)
         r.release()

@@ -12,4 +12,5 @@ done
 python3 bench.py --steps 48 --workload cfg3 --no-cpu-baseline > $O/cfg3.json 2> $O/cfg3.err
 python3 bench.py --steps 48 --workload cfg5 --shard 0/8 --no-cpu-baseline > $O/cfg5s.json 2> $O/cfg5s.err
 python3 bench.py --steps 48 --workload cfg5 --shard 0/8 --no-cpu-baseline --ready-words 0 > $O/cfg5s_rw0.json 2> $O/cfg5s_rw0.err
+/opt/rocm/bin/hipcc -O2 --offload-arch=gfx950 tools/rtz_mul_probe.hip -o /tmp/rtzprobe && timeout -k 5 120 /tmp/rtzprobe > $O/rtz_probe.txt 2>&1
 echo done
