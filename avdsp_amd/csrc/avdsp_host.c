@@ -97,10 +97,11 @@ typedef struct avdsp_ctx {
     int             shard_rank, shard_world;               /* dspRuntimeSetShard: this process's slice of every chain core */
     int             numfreq_at_init;                       /* dspChangeFormat's view of the rate count (see dspRuntimeInit) */
     int             opt_profile_stride;
-    int             opt_overlap, opt_fir_rows, opt_host_split, opt_host_pin, opt_ready_words, opt_lane_hw; /* launch arrangement of the chain kernels (avdsp_hip_prog_set_option) */
+    int             opt_overlap, opt_fir_rows, opt_host_split, opt_host_pin, opt_ready_words, opt_lane_hw, opt_fir_split; /* launch arrangement of the chain kernels (avdsp_hip_prog_set_option) */
     arrangement     arr[MAX_ARRANGEMENTS]; int arr_next;   /* how the cores / pieces go to the device: [0] whole program, [1..] single cores */
     int             biquad_freq_skip, mantissa;            /* this program's dspBiquadFreqSkip / dspMantissa */
     int             device_ordinal;                        /* the GPU its device copy lives on (-1: none yet) */
+    int             ninst;                                 /* dspRuntimeSetInstances */
 } avdsp_ctx;
 
 /* no program loaded: options set now are the defaults every program starts from (and keeps following, see dspRuntimeSetOption) */
@@ -241,9 +242,10 @@ static int set_option_here(const char *key, int value)
     if (!strcmp(key, "interp_impl")) { G.opt_interp_impl = value; return replan(); }
     if (!strcmp(key, "strand_split")) { G.opt_strand_split = value; return replan(); }
     if (!strcmp(key, "strand_lanes")) { G.opt_strand_lanes = value; return replan(); }
-    if (!strcmp(key, "overlap") || !strcmp(key, "fir_rows") || !strcmp(key, "host_split") || !strcmp(key, "ready_words") || !strcmp(key, "lane_hw")) {
-        int *slot = key[0] == 'o' ? &G.opt_overlap : key[0] == 'f' ? &G.opt_fir_rows : key[0] == 'r' ? &G.opt_ready_words : key[0] == 'l' ? &G.opt_lane_hw : &G.opt_host_split;
-        const int dev_key = key[0] == 'o' ? AVDSP_OPT_OVERLAP : key[0] == 'f' ? AVDSP_OPT_FIR_ROWS : key[0] == 'r' ? AVDSP_OPT_READY_WORDS : key[0] == 'l' ? AVDSP_OPT_LANE_HW : AVDSP_OPT_HOST_SPLIT;
+    if (!strcmp(key, "overlap") || !strcmp(key, "fir_rows") || !strcmp(key, "host_split") || !strcmp(key, "ready_words") || !strcmp(key, "lane_hw") || !strcmp(key, "fir_split")) {
+        const int split = !strcmp(key, "fir_split");
+        int *slot = split ? &G.opt_fir_split : key[0] == 'o' ? &G.opt_overlap : key[0] == 'f' ? &G.opt_fir_rows : key[0] == 'r' ? &G.opt_ready_words : key[0] == 'l' ? &G.opt_lane_hw : &G.opt_host_split;
+        const int dev_key = split ? AVDSP_OPT_FIR_SPLIT : key[0] == 'o' ? AVDSP_OPT_OVERLAP : key[0] == 'f' ? AVDSP_OPT_FIR_ROWS : key[0] == 'r' ? AVDSP_OPT_READY_WORDS : key[0] == 'l' ? AVDSP_OPT_LANE_HW : AVDSP_OPT_HOST_SPLIT;
         if (G.dev && avdsp_hip_prog_set_option(G.dev, dev_key, value)) return fail(-10, "%s", avdsp_hip_last_error());
         *slot = value;
         return 0;
@@ -301,6 +303,7 @@ int dspRuntimeGetOption(const char *key)
     if (!strcmp(key, "overlap"))     return G.opt_overlap;
     if (!strcmp(key, "ready_words")) return G.opt_ready_words;
     if (!strcmp(key, "lane_hw"))     return G.opt_lane_hw;
+    if (!strcmp(key, "fir_split"))   return G.opt_fir_split;
     if (!strncmp(key, "timing_pairs_", 13) && key[13] >= '0' && key[13] <= '7' && !key[14])      /* of the latest dspRuntimeKernelTime(kind) */
         return G.dev ? avdsp_hip_profile_last_pairs(G.dev, key[13] - '0') : 0;
     if (!strcmp(key, "ready_timeouts")) { device_current(); return G.dev ? avdsp_hip_ready_timeouts(G.dev) : 0; }
@@ -425,7 +428,7 @@ int dspRuntimeInit(opcode_t *codePtr, int maxSize, const int fs, int random, int
         const avdsp_ctx *o = &g_template;
         c->opt_fir_impl = o->opt_fir_impl; c->opt_biquad_impl = o->opt_biquad_impl; c->opt_device = o->opt_device; c->opt_profile = o->opt_profile;
         c->opt_generic = o->opt_generic; c->opt_interp_impl = o->opt_interp_impl; c->opt_strand_split = o->opt_strand_split; c->opt_strand_lanes = o->opt_strand_lanes;
-        c->opt_profile_stride = o->opt_profile_stride; c->opt_overlap = o->opt_overlap; c->opt_fir_rows = o->opt_fir_rows; c->opt_host_split = o->opt_host_split; c->opt_host_pin = o->opt_host_pin; c->opt_ready_words = o->opt_ready_words; c->opt_lane_hw = o->opt_lane_hw;
+        c->opt_profile_stride = o->opt_profile_stride; c->opt_overlap = o->opt_overlap; c->opt_fir_rows = o->opt_fir_rows; c->opt_host_split = o->opt_host_split; c->opt_host_pin = o->opt_host_pin; c->opt_ready_words = o->opt_ready_words; c->opt_lane_hw = o->opt_lane_hw; c->opt_fir_split = o->opt_fir_split;
         c->shard_rank = o->shard_rank; c->shard_world = o->shard_world;
         c->mantissa = DSP_MANT; c->device_ordinal = -1;
         c->code = codePtr;
@@ -1243,8 +1246,9 @@ static core_plan *get_plan_range(int format, opcode_t *core, int end_word)
         avdsp_hip_profile_enable(G.dev, G.opt_profile);
         if (avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_PROFILE_STRIDE, G.opt_profile_stride > 0 ? G.opt_profile_stride : 1) ||
             avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_OVERLAP, G.opt_overlap) || avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_FIR_ROWS, G.opt_fir_rows) ||
-            avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_READY_WORDS, G.opt_ready_words) || avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_LANE_HW, G.opt_lane_hw) ||
-            avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_HOST_SPLIT, G.opt_host_split) || avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_HOST_PIN, G.opt_host_pin)) {
+            avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_READY_WORDS, G.opt_ready_words) || avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_LANE_HW, G.opt_lane_hw) || avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_FIR_SPLIT, G.opt_fir_split) ||
+            avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_HOST_SPLIT, G.opt_host_split) || avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_HOST_PIN, G.opt_host_pin) ||
+            (G.ninst > 1 && avdsp_hip_set_instances(G.dev, G.ninst))) {
             fail(-10, "%s", avdsp_hip_last_error()); lowered_free(&L); drop_device(); return 0;
         }
     }
@@ -2041,6 +2045,11 @@ static int expand_core(int format, opcode_t *c, core_plan **cp, int *pn)
     return 0;
 }
 
+/* dspRuntimeBlockAllInstancesDevice hands its per-instance strides to block_all through these (one call at a time per thread of control,
+ * like everything else here) */
+static int g_inst_call;
+static size_t g_inst_in_words, g_inst_out_words;
+
 /* only == 0: every core of the program in program order; else that one core (its strand groups side by side) */
 static int block_all(int format, int *rundata, const void *in, int in_stride, int in_io_base,
                      void *out, int out_stride, int out_io_base, int nframes, int on_device, void *stream, int pcm,
@@ -2105,7 +2114,10 @@ static int block_all(int format, int *rundata, const void *in, int in_stride, in
     if (A->n == 0) return 0;                                     /* every core's shard is empty on this rank */
     const int *plans = A->plans, *size = A->size;
     const int nlevels = A->nlevels;
-    int rc = on_device
+    int rc = g_inst_call
+        ? avdsp_hip_run_levels_instances(G.dev, plans, size, nlevels, in, in_stride, in_io_base, g_inst_in_words, out, out_stride, out_io_base,
+                                         g_inst_out_words, nframes, stream)
+        : on_device
         ? avdsp_hip_run_levels(G.dev, plans, size, nlevels, in, in_stride, in_io_base, out, out_stride, out_io_base,
                                nframes, G.opt_fir_impl, G.opt_biquad_impl, stream)
         : avdsp_hip_run_levels_pcm_host(G.dev, plans, size, nlevels, pcm, in, in_stride, in_io_base, out, out_stride, out_io_base,
@@ -2123,6 +2135,45 @@ int dspRuntimeBlockAllDevice(int format, int *rundata, const void *d_in, int in_
                              void *d_out, int out_stride, int out_io_base, int nframes, void *stream)
 {
     (void)ctx_of(rundata); return block_all(format, rundata, d_in, in_stride, in_io_base, d_out, out_stride, out_io_base, nframes, 1, stream, AVDSP_PCM_S32, 0); }
+
+/* ---- instances: N copies of the loaded program side by side (extension) ----
+ * The reference runs ONE program per process on one core; a host that has many independent streams for the same program -- a
+ * thousand stereo crossovers -- loads it once, asks for N instances and hands over N sample blocks per call.  Instance i starts
+ * from a copy of the program's device state (parameters, data area, dither generator, samples[] frame) as it is at the first
+ * dspRuntimeBlockAllInstancesDevice call after dspRuntimeSetInstances, and keeps its own from then on; dspRuntimeReset /
+ * dspRuntimeUploadState / ...UploadParams afterwards reach instance 0 only -- set the instances again to hand them on.
+ * Every core must run on the frame-parallel interpreter (the reference's programs do); a block is 2 .. 65536 frames. */
+int dspRuntimeSetInstances(int n)
+{
+    if (!dspHeaderPtr || !G.code) return fail(-1, "no program loaded");
+    if (n < 1 || n > 65536) return fail(-1, "instances: 1 .. 65536");
+    device_current();
+    if (G.dev && avdsp_hip_set_instances(G.dev, n)) return fail(-10, "%s", avdsp_hip_last_error());      /* (else: when the device copy is made) */
+    G.ninst = n;
+    return 0;
+}
+
+int dspRuntimeBlockAllInstancesDevice(int format, int *rundata, const void *d_in, int in_stride, int in_io_base, size_t in_inst_words,
+                                      void *d_out, int out_stride, int out_io_base, size_t out_inst_words, int nframes, void *stream)
+{
+    (void)ctx_of(rundata);
+    if (G.ninst < 1) return fail(-1, "dspRuntimeSetInstances first");
+    /* the strand plans and the chain kernels know nothing of instances: the interpreter's pieces throughout */
+    if (G.opt_strand_lanes != 0) { const int rc0 = set_option_here("strand_lanes", 0); if (rc0) return rc0; }
+    g_inst_call = 1; g_inst_in_words = in_inst_words; g_inst_out_words = out_inst_words;
+    const int rc = block_all(format, rundata, d_in, in_stride, in_io_base, d_out, out_stride, out_io_base, nframes, 1, stream, AVDSP_PCM_S32, 0);
+    g_inst_call = 0;
+    return rc;
+}
+
+/* the data area of instance i (dataSize words), as dspRuntimeSyncState brings back instance 0's into the caller's buffer */
+int dspRuntimeInstanceState(int inst, int *dst)
+{
+    if (!dspHeaderPtr || !G.dev) return fail(-1, "no program loaded, or no block has run yet");
+    device_current();
+    if (avdsp_hip_download_instance_words(G.dev, inst, dst, (int)dspHeaderPtr->totalLength, (int)dspHeaderPtr->dataSize)) return fail(-10, "%s", avdsp_hip_last_error());
+    return 0;
+}
 
 /* linux/avdsp_plugin.c:95-142 whole: packed PCM in (:109-121), every core, S32 out */
 int dspRuntimeBlockAllPcm(int format, int *rundata, int pcm, const void *src, int in_stride, int in_io_base,

@@ -1609,9 +1609,14 @@ template <int R, bool BIG = false> __device__ __forceinline__ constexpr int win_
     return ((NR - (4 * j) % NR) % NR) * TileGeom<R, BIG>::ROW - (4 * j + NR - 1) / NR + (64 / NR - 1);
 }
 
-template <int FMT, int R, bool BIG = false>
+/* SPLIT (R = 1, opt-in "fir_split"): a tile's k-steps cut in two, one wave each, the two partial sums added at the end -- NOT the
+ * reference's summation order any more (results within north_star's 1e-6, not its bits), which is why it is an option: a launch
+ * of at most one tile per SIMD (cfg4: 256 chains x 4 tiles) then has two waves per SIMD, whose MFMAs interleave and whose chunk
+ * boundaries hide under each other.  The two halves of a tile are neighbouring waves of one workgroup and meet through LDS. */
+template <int FMT, int R, bool BIG = false, bool SPLIT = false>
 __global__ __launch_bounds__(kBlock, 2) void fir_tile(const FirTileArgs a)
 {
+    static_assert(!SPLIT || (R == 1 && !BIG), "the tap split: one row tile, ordinary chunks");
     using G = TileGeom<R, BIG>;
     constexpr int NR = G::NR;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -1623,8 +1628,8 @@ __global__ __launch_bounds__(kBlock, 2) void fir_tile(const FirTileArgs a)
     {
         FirArgs fa{};
         fa.ring = a.ring; fa.io = a.io;
-        for (int q = 0; q < 4 / G::WPC; q++) {
-            const int sl = blk * (4 / G::WPC) + q;
+        for (int q = 0; q < (SPLIT ? 1 : 4 / G::WPC); q++) {
+            const int sl = SPLIT ? blk >> 1 : blk * (4 / G::WPC) + q;      /* (SPLIT: the workgroup is two tiles of one chain) */
             if (sl < a.ngroup) {
                 const int ci = a.group[sl];
                 const avdsp_chain cc = a.chains[ci];
@@ -1633,7 +1638,8 @@ __global__ __launch_bounds__(kBlock, 2) void fir_tile(const FirTileArgs a)
         }
         __syncthreads();
     }
-    const int unit = blk * 4 + wv;
+    const int unit = SPLIT ? (blk * 4 + wv) >> 1 : blk * 4 + wv;
+    [[maybe_unused]] const int half = (blk * 4 + wv) & 1;
     const int slot = unit / G::WPC, F0 = (unit % G::WPC) * G::FW;
     /* R = 4: the workgroup's four waves are four chains over the same frames, and their tiles leave together (one barrier, at
      * the very end); a wave without a unit only attends that barrier */
@@ -1643,6 +1649,7 @@ __global__ __launch_bounds__(kBlock, 2) void fir_tile(const FirTileArgs a)
             if (lane == 0) xchg[wv] = -1;
             __syncthreads();
         }
+        if constexpr (SPLIT) __syncthreads();
         return;
     }
     /* from here on a wave is on its own: no barrier in the tap loop */
@@ -1665,9 +1672,12 @@ __global__ __launch_bounds__(kBlock, 2) void fir_tile(const FirTileArgs a)
 
     const int i16 = lane & 15, k = lane >> 4;
     /* k-steps: m_s = -NR + 4 s, s = 0 .. S-1, S a multiple of 16; chunks of ck <= CKMAX of them */
-    const int S = (((T + NR + 3) >> 2) + 15) & ~15;
-    const int nch = (S + G::CKMAX - 1) / G::CKMAX;
-    const int ck = (((S + nch - 1) / nch) + 15) & ~15;
+    const int Sall = (((T + NR + 3) >> 2) + 15) & ~15;
+    /* this wave's k-steps [Sb, S): all of them, or (SPLIT) the first or the second half, cut at a multiple of 16 */
+    const int Sb = SPLIT && half ? ((Sall >> 1) + 15) & ~15 : 0;
+    const int S = SPLIT && !half ? ((Sall >> 1) + 15) & ~15 : Sall;
+    const int nch = max(1, (S - Sb + G::CKMAX - 1) / G::CKMAX);
+    const int ck = max(16, (((S - Sb + nch - 1) / nch) + 15) & ~15);
 
     v4f64 acc[R];
 #pragma unroll
@@ -1757,27 +1767,27 @@ __global__ __launch_bounds__(kBlock, 2) void fir_tile(const FirTileArgs a)
      * taps image, run the k-steps.  While a wave is at a boundary the other wave of its SIMD has the matrix pipe to itself.
      * (Tried and dropped, measured slower: a second WINDOW image filled in slices between the MFMAs -- the slices' address
      * arithmetic and conversions cost the f64 matrix pipe more than the stop they replace, 83 -> 95 us on a 512-chain shard.) */
-    win_fetch(0, min(ck, S));
-    taps_dma(hs, 0, min(ck, S));
+    win_fetch(Sb, min(ck, S - Sb));
+    taps_dma(hs, Sb, min(ck, S - Sb));
     [[maybe_unused]] int stamp_i = 1;
     int cur = 0;
-    for (int s0 = 0; s0 < S; s0 += ck, cur ^= 1) {
+    for (int s0 = Sb; s0 < S; s0 += ck, cur ^= 1) {
         const int ckc = min(ck, S - s0);
         const int JT = (4 * (ckc - 1) + NR - 1) / NR;
         __builtin_amdgcn_wave_barrier();
         FIR_STAMP_CHUNK();
         win_store(ws);                                      /* (waits for the window samples requested a chunk ago) */
-        if (s0 == ck) FIR_STAMP(24);
+        if (s0 == Sb + ck) FIR_STAMP(24);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    /* ... and for this chunk's taps image, in flight since then */
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (s0 == ck) FIR_STAMP(25);
+        if (s0 == Sb + ck) FIR_STAMP(25);
         if (s0 + ckc < S) {
             win_fetch(s0 + ckc, min(ck, S - s0 - ckc));
-            if (s0 == ck) FIR_STAMP(26);
+            if (s0 == Sb + ck) FIR_STAMP(26);
             taps_dma(hs + (cur ^ 1) * G::HLEN, s0 + ckc, min(ck, S - s0 - ckc));
         }
-        if (s0 == ck) FIR_STAMP(27);
+        if (s0 == Sb + ck) FIR_STAMP(27);
         const double *hp = hs + cur * G::HLEN + k + i16;                       /* oldest operand of step sc at hp[4 sc] */
         const double *wp = ws + (3 - k) * G::ROW + i16 + JT - (64 / NR - 1);   /* group g: wp - g * (64 / NR) + win_off(j) */
         chunk_begin(hp, wp);
@@ -1840,6 +1850,15 @@ __global__ __launch_bounds__(kBlock, 2) void fir_tile(const FirTileArgs a)
                 }
         }
     } else {
+        if constexpr (SPLIT) {
+            /* the second half's sums reach the first half's wave through the second's own (idle) LDS region; the first adds them to
+             * its own -- (taps 0 .. S/2) + (taps S/2 ..), not the reference's order -- and stores */
+            v4f64 *park = reinterpret_cast<v4f64 *>(lds + (size_t)(wv | 1) * G::LDS_DOUBLES);
+            if (half) park[lane] = acc[0];
+            __syncthreads();
+            if (half) return;
+            acc[0] += park[lane];
+        }
 #pragma unroll
         for (int r = 0; r < R; r++)
 #pragma unroll
@@ -2874,6 +2893,10 @@ struct avdsp_hip_prog {
     std::vector<Plan> plans;
     unsigned *d_in = nullptr, *d_out = nullptr; size_t in_cap = 0, out_cap = 0;   /* host-call staging */
     unsigned *d_alias = nullptr; size_t alias_cap = 0;    /* copy of the input block of an in-place device call (avdsp_hip_run_block) */
+    /* N instances of the program (avdsp_hip_run_levels_instances): copies 1 .. N-1 of the device state; instance 0 is the program's own */
+    int inst_n = 1; bool inst_valid = false;
+    int *d_inst_buf = nullptr; TpdfGlobals *d_inst_tpdf = nullptr; unsigned *d_inst_frame = nullptr; int *d_inst_seq = nullptr;
+    int inst_frame_words = 0, inst_seq_frames = 0;
     static constexpr int kSmallWords = 4096;             /* host calls of up to that many sample words (dspRuntime_N) ... */
     unsigned *h_small = nullptr, *d_small = nullptr;     /* ... go through a pinned area the kernels access in place */
     /* optional per-kernel timing with HIP events on the launch stream (avdsp_hip_profile_*) */
@@ -2897,6 +2920,7 @@ struct avdsp_hip_prog {
     /* cascade of block k+1 under the FIR of block k ("overlap"): the cascades run on a stream of their own */
     int overlap = 0;
     int fir_rows = 0;                    /* fir_tile: row tiles per wave (1, 2, 4), 0 = by the number of chains */
+    int fir_split = 0;                   /* fir_tile: launches of at most a tile per SIMD cut every tile's taps over two waves (sums within 1e-6, not the reference's bits) */
     hipStream_t s_bq = nullptr;
     hipStream_t s_fir[2] = {nullptr, nullptr};           /* "overlap" 2: the FIRs of consecutive blocks in turn */
     static constexpr int kAhead = 3;     /* cascade k waits for FIR k - kAhead: it may run under FIR k - 2 and be done before FIR k - 1 ends */
@@ -3098,14 +3122,14 @@ extern "C" int avdsp_hip_debug_fir_stamps(unsigned long long *host_out, int max_
 }
 #endif
 
-template <int FMT, int R, bool BIG = false>
+template <int FMT, int R, bool BIG = false, bool SPLIT = false>
 int launch_fir_tile(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, BlockIO io, hipStream_t stream, ProfileScope &scope, bool wait_ready)
 {
     FirTileArgs a{};
     a.buf = prog->d_buf; a.chains = pl.d_chains; a.group = ids; a.ngroup = n;
     a.ring = plan_ring(pl); a.io = io; a.taps64 = pl.d_taps64; a.pitch64 = pl.pitch64;
     if (wait_ready) { a.ready = pl.d_ready; a.seq = pl.seq; a.timeouts = prog->d_ready_timeouts; }
-    const int nwg = (n * TileGeom<R, BIG>::WPC + 3) / 4;
+    const int nwg = (n * TileGeom<R, BIG>::WPC * (SPLIT ? 2 : 1) + 3) / 4;
     a.per_xcd = (nwg + 7) / 8;
     const size_t lds = (size_t)4 * TileGeom<R, BIG>::LDS_DOUBLES * sizeof(double) + 64;      /* + the four words the waves exchange at the end */
 #ifdef AVDSP_FIR_STAMPS
@@ -3115,7 +3139,7 @@ int launch_fir_tile(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, Block
     a.stamps = d_stamps;
     g_fir_stamps = d_stamps; g_fir_stamp_waves = a.per_xcd * 8 * 4;
 #endif
-    return launch_timed(scope, (const void *)fir_tile<FMT, R, BIG>, dim3(a.per_xcd * 8), dim3(kBlock), lds, stream, a);
+    return launch_timed(scope, (const void *)fir_tile<FMT, R, BIG, SPLIT>, dim3(a.per_xcd * 8), dim3(kBlock), lds, stream, a);
 }
 
 
@@ -3180,6 +3204,8 @@ int launch_fir(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, BlockIO io
             while (rows > 1 && 128 * rows >= io.nframes) rows >>= 1;       /* a tile twice the block would multiply zeros */
             /* one row tile and at most a wave per SIMD (1024): chunks twice as long -- nothing hides a boundary there */
             const long long waves1 = (long long)n * ((io.nframes + 255) / 256);
+            /* "fir_split" (opt-in, not the reference's summation order): such a launch with two waves per tile instead */
+            if (rows == 1 && waves1 <= 1024 && prog->fir_split) return launch_fir_tile<FMT, 1, false, true>(prog, pl, ids, n, io, stream, scope, wait_ready);
             if (rows == 1 && waves1 <= 1024 && prog->fir_rows != 1) return launch_fir_tile<FMT, 1, true>(prog, pl, ids, n, io, stream, scope, wait_ready);
             return rows == 4 ? launch_fir_tile<FMT, 4>(prog, pl, ids, n, io, stream, scope, wait_ready)
                  : rows == 2 ? launch_fir_tile<FMT, 2>(prog, pl, ids, n, io, stream, scope, wait_ready)
@@ -3349,6 +3375,7 @@ void avdsp_hip_prog_destroy(avdsp_hip_prog *p)
     (void)hipFree(p->d_buf); (void)hipFree(p->d_in); (void)hipFree(p->d_out); (void)hipFree(p->d_tpdf); (void)hipFree(p->d_frame);
     (void)hipHostFree(p->h_small);
     (void)hipFree(p->d_tpdf_seq); (void)hipFree(p->d_ready_timeouts); (void)hipFree(p->d_alias);
+    (void)hipFree(p->d_inst_buf); (void)hipFree(p->d_inst_tpdf); (void)hipFree(p->d_inst_frame); (void)hipFree(p->d_inst_seq);
     delete p;
 }
 
@@ -3457,6 +3484,11 @@ int avdsp_hip_prog_add_plan(avdsp_hip_prog *prog, const avdsp_plan_desc *d)
             }
         }
         {   /* fir_tile: LDS opt-in per variant, and the taps as doubles */
+            {
+                const void *sp = d->format == 4 ? (const void *)fir_tile<4, 1, false, true> : (const void *)fir_tile<6, 1, false, true>;
+                hipError_t e3 = hipFuncSetAttribute(sp, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TileGeom<1>::LDS_DOUBLES * 8 + 64);
+                if (e3 != hipSuccess) { free_plan(pl); return set_err("hipFuncSetAttribute(fir_tile split LDS): %s", hipGetErrorString(e3)); }
+            }
             const void *tiles[4] = { d->format == 4 ? (const void *)fir_tile<4, 1> : (const void *)fir_tile<6, 1>,
                                      d->format == 4 ? (const void *)fir_tile<4, 2> : (const void *)fir_tile<6, 2>,
                                      d->format == 4 ? (const void *)fir_tile<4, 4> : (const void *)fir_tile<6, 4>,
@@ -3583,6 +3615,11 @@ int avdsp_hip_prog_add_generic(avdsp_hip_prog *prog, const avdsp_generic_desc *d
                         : d->format == 4 ? (const void *)interp_wave_grid<4> : d->format == 5 ? (const void *)interp_wave_grid<5>
                                                                                           : (const void *)interp_wave_grid<6>;
         e = hipFuncSetAttribute(gfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGenericLdsMax);
+        if (e != hipSuccess) { (void)hipFree(pl.d_own); return set_err("hipFuncSetAttribute(frame-parallel LDS): %s", hipGetErrorString(e)); }
+        const void *ifn = d->format == 2 ? (const void *)interp_wave_instances<2> : d->format == 3 ? (const void *)interp_wave_instances<3>
+                        : d->format == 4 ? (const void *)interp_wave_instances<4> : d->format == 5 ? (const void *)interp_wave_instances<5>
+                                                                                          : (const void *)interp_wave_instances<6>;
+        e = hipFuncSetAttribute(ifn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGenericLdsMax);
         if (e != hipSuccess) { (void)hipFree(pl.d_own); return set_err("hipFuncSetAttribute(frame-parallel LDS): %s", hipGetErrorString(e)); }
     }
     if (pl.ga_staged) {   /* per plan creation, like the FIR: nothing in the launch path may touch function attributes */
@@ -4348,6 +4385,147 @@ int avdsp_hip_run_levels(avdsp_hip_prog *prog, const int *plans, const int *leve
     return 0;
 }
 
+/* N instances of the program over one block each (include/avdsp_hip.h).  Every level must be frame-parallel interpreter pieces (the
+ * programs this is for -- the reference's crossovers -- are); the instances' states are made on the first call after
+ * avdsp_hip_set_instances as copies of the program's device state as it then is. */
+int avdsp_hip_set_instances(avdsp_hip_prog *prog, int n)
+{
+    if (n < 1 || n > 65536) return set_err("instances: 1 .. 65536");
+    HIP_TRY(hipDeviceSynchronize());
+    prog->inst_n = n; prog->inst_valid = false;
+    return 0;
+}
+
+static int instances_ready(avdsp_hip_prog *prog, int nframes)
+{
+    const int n = prog->inst_n;
+    const size_t bw = (size_t)prog->total_words + 2;
+    const int seqf = std::max(prog->tpdf_seq_frames, std::max(nframes, 4096));
+    if (prog->inst_valid && prog->inst_frame_words == prog->frame_words && prog->inst_seq_frames >= nframes) return 0;
+    HIP_TRY(hipDeviceSynchronize());
+    const bool fresh = !prog->inst_valid;
+    if (fresh || prog->inst_frame_words != prog->frame_words) {
+        if (!fresh) return set_err("instances: the program's frame grew after the instances were made (run every core once before dspRuntimeSetInstances, or set them again)");
+        (void)hipFree(prog->d_inst_buf); (void)hipFree(prog->d_inst_tpdf); (void)hipFree(prog->d_inst_frame);
+        prog->d_inst_buf = nullptr; prog->d_inst_tpdf = nullptr; prog->d_inst_frame = nullptr;
+        if (n > 1) {
+            if (!prog->d_tpdf) return set_err("instances: the program has no dither state (dspRuntimeReset first)");
+            HIP_TRY(hipMalloc((void **)&prog->d_inst_buf, (size_t)(n - 1) * bw * sizeof(int)));
+            HIP_TRY(hipMalloc((void **)&prog->d_inst_tpdf, (size_t)(n - 1) * sizeof(TpdfGlobals)));
+            HIP_TRY(hipMalloc((void **)&prog->d_inst_frame, (size_t)(n - 1) * std::max(prog->frame_words, 1) * sizeof(unsigned)));
+            for (int i = 0; i < n - 1; i++) {
+                HIP_TRY(hipMemcpyAsync(prog->d_inst_buf + (size_t)i * bw, prog->d_buf, bw * sizeof(int), hipMemcpyDeviceToDevice, nullptr));
+                HIP_TRY(hipMemcpyAsync(prog->d_inst_tpdf + i, prog->d_tpdf, sizeof(TpdfGlobals), hipMemcpyDeviceToDevice, nullptr));
+                if (prog->frame_words)
+                    HIP_TRY(hipMemcpyAsync(prog->d_inst_frame + (size_t)i * prog->frame_words, prog->d_frame, (size_t)prog->frame_words * 4, hipMemcpyDeviceToDevice, nullptr));
+            }
+        }
+        prog->inst_frame_words = prog->frame_words;
+        prog->inst_seq_frames = 0;
+    }
+    if (prog->inst_seq_frames < nframes) {
+        (void)hipFree(prog->d_inst_seq); prog->d_inst_seq = nullptr;
+        if (n > 1) {
+            HIP_TRY(hipMalloc((void **)&prog->d_inst_seq, (size_t)(n - 1) * seqf * 2 * sizeof(int)));
+            HIP_TRY(hipMemset(prog->d_inst_seq, 0, (size_t)(n - 1) * seqf * 2 * sizeof(int)));
+        }
+        prog->inst_seq_frames = seqf;
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    prog->inst_valid = true;
+    return 0;
+}
+
+int avdsp_hip_run_levels_instances(avdsp_hip_prog *prog, const int *plans, const int *level_size, int nlevels,
+                                   const void *d_in, int in_stride, int in_io_base, size_t in_inst_words,
+                                   void *d_out, int out_stride, int out_io_base, size_t out_inst_words, int nframes, void *stream)
+{
+    hipStream_t main = (hipStream_t)stream;
+    const int ninst = prog->inst_n;
+    if (nframes < 2 || nframes > kFirChunk * 64) return set_err("instances: blocks of 2 .. %d frames", kFirChunk * 64);
+    /* (the dither-pair buffers and the frame exist once the pieces have been looked at: a first pass over the table) */
+    constexpr int K = avdsp_hip_prog::kTableSlots;
+    int at = 0;
+    for (int l = 0; l < nlevels; l++) {
+        const int n = level_size[l];
+        if (prog->table_cap < n) {
+            HIP_TRY(hipDeviceSynchronize());
+            (void)hipFree(prog->d_table); (void)hipHostFree(prog->h_table);
+            prog->d_table = nullptr; prog->h_table = nullptr; prog->table_cap = 0;
+            const int cap = std::max(n, 16);
+            HIP_TRY(hipMalloc((void **)&prog->d_table, (size_t)K * cap * sizeof(GenericArgs)));
+            HIP_TRY(hipHostMalloc((void **)&prog->h_table, (size_t)K * cap * sizeof(GenericArgs), hipHostMallocDefault));
+            prog->table_cap = cap;
+            for (auto &ev : prog->table_done) if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        }
+        const int slot = prog->table_next;
+        GenericArgs *table = prog->h_table + (size_t)slot * prog->table_cap;
+        GenericArgs *d_slot = prog->d_table + (size_t)slot * prog->table_cap;
+        HIP_TRY(hipEventSynchronize(prog->table_done[slot]));
+        size_t lds = 0;
+        BlockIO gio{};
+        gio.in_stride = in_stride; gio.in_base = in_io_base; gio.out_stride = out_stride; gio.out_base = out_io_base;
+        gio.in = (const unsigned *)d_in; gio.out = (unsigned *)d_out; gio.nframes = nframes; gio.store_mask = -1;
+        int fmt = 0;
+        for (int i = 0; i < n; i++) {
+            const int id = plans[at + i];
+            if (id < 0 || id >= (int)prog->plans.size()) return set_err("bad plan id %d", id);
+            Plan &pl = prog->plans[id];
+            GenericArgs a = pl.ga;
+            a.io = gio;
+            a.rows_whole = 0;
+            if (!pl.generic || !pl.ga_staged || rows_whole(pl, gio))
+                return set_err("instances: every core must run on the frame-parallel interpreter with windows that do not share IO numbers (plan %d does not)", id);
+            if (tpdf_seq_for(prog, a, nframes)) return -1;
+            if (in_stride < 0 || out_stride < 0 || in_io_base < 0 || out_io_base < 0 ||
+                (in_stride && in_io_base + in_stride > pl.ga.scratch_len) || (out_stride && out_io_base + out_stride > pl.ga.scratch_len) ||
+                (fmt && pl.format != fmt) || !wave_plan_fits(prog, pl, gio, a))
+                return set_err("instances: plan %d does not fit the frame-parallel interpreter for these windows", id);
+            fmt = pl.format;
+            lds = std::max(lds, ((size_t)a.batch_lds + 128 + (size_t)a.nvm * 128 + a.seq_words) * 4);
+            table[i] = a;
+        }
+        if (instances_ready(prog, nframes)) return -1;
+        InstanceStrides st{};
+        st.n = n; st.buf = prog->d_inst_buf; st.buf_words = (size_t)prog->total_words + 2; st.tpdf = prog->d_inst_tpdf;
+        st.scratch = prog->d_inst_frame; st.frame_words = (size_t)prog->frame_words;
+        st.tpdf_seq = prog->d_inst_seq; st.seq_words = (size_t)prog->inst_seq_frames * 2;
+        st.in_words = in_inst_words; st.out_words = out_inst_words;
+        HIP_TRY(hipMemcpyAsync(d_slot, table, (size_t)n * sizeof(GenericArgs), hipMemcpyHostToDevice, main));
+        {
+            ProfileScope scope(prog, main, AVDSP_KERNEL_GENERIC_WAVE); scope.begin();
+            const dim3 grid((unsigned)n * (unsigned)ninst), block(64);
+            switch (fmt) {
+            case 2:  hipLaunchKernelGGL((interp_wave_instances<2>), grid, block, lds, main, d_slot, st); break;
+            case 3:  hipLaunchKernelGGL((interp_wave_instances<3>), grid, block, lds, main, d_slot, st); break;
+            case 4:  hipLaunchKernelGGL((interp_wave_instances<4>), grid, block, lds, main, d_slot, st); break;
+            case 5:  hipLaunchKernelGGL((interp_wave_instances<5>), grid, block, lds, main, d_slot, st); break;
+            default: hipLaunchKernelGGL((interp_wave_instances<6>), grid, block, lds, main, d_slot, st); break;
+            }
+            HIP_TRY(hipGetLastError());
+        }
+        HIP_TRY(hipEventRecord(prog->table_done[slot], main));
+        prog->table_next = (slot + 1) % K;
+        at += n;
+    }
+    return 0;
+}
+
+/* the data area (or any word range) of one instance's mirror, for the host */
+int avdsp_hip_download_instance_words(avdsp_hip_prog *p, int inst, int32_t *host_buf, int first, int n)
+{
+    if (inst < 0 || inst >= p->inst_n) return set_err("instance %d of %d", inst, p->inst_n);
+    if (check_range(p, first, n)) return -1;
+    HIP_TRY(hipDeviceSynchronize());
+    const int *src = p->d_buf;
+    if (inst > 0) {
+        if (!p->inst_valid || !p->d_inst_buf) return set_err("the instances have not run yet");
+        src = p->d_inst_buf + (size_t)(inst - 1) * ((size_t)p->total_words + 2);
+    }
+    HIP_TRY(hipMemcpy(host_buf, src + first, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int avdsp_hip_run_levels_host(avdsp_hip_prog *prog, const int *plans, const int *level_size, int nlevels,
                               const void *h_in, int in_stride, int in_io_base, void *h_out, int out_stride, int out_io_base,
                               int nframes, int fir_impl, int biquad_impl)
@@ -4502,6 +4680,7 @@ int avdsp_hip_prog_set_option(avdsp_hip_prog *prog, int key, int value)
     case AVDSP_OPT_OVERLAP:  prog->overlap = value; for (bool &f : prog->ev_fir_set) f = false; return 0;
     case AVDSP_OPT_READY_WORDS: prog->ready_words = value != 0; return 0;
     case AVDSP_OPT_LANE_HW: prog->lane_hw = value != 0; return 0;
+    case AVDSP_OPT_FIR_SPLIT: prog->fir_split = value != 0; return 0;
     case AVDSP_OPT_FIR_ROWS: if (value != 0 && value != 1 && value != 2 && value != 4) return set_err("fir_tile row tiles: 0 (auto), 1, 2 or 4");
                              prog->fir_rows = value; return 0;
     case AVDSP_OPT_PROFILE_STRIDE: if (value < 1) return set_err("profile_stride: every n-th launch, n >= 1"); prog->profile_stride = value; return 0;

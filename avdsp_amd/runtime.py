@@ -31,6 +31,7 @@ EXPORTED = [
     "dspRuntimeSyncState", "dspRuntimeUploadState", "dspRuntimeUploadParams", "dspRuntimeSetOption", "dspRuntimeGetOption",
     "dspRuntimeCoreInfo", "dspRuntimeKernelTime", "dspRuntimeLastError", "dspRuntimeRelease", "dspRuntimeReleaseProgram", "dspRuntimeSelect",
     "dspRuntimeSetShard", "dspRuntimeShardInfo", "dspRuntimeTagOutput", "dspRuntimeTagOutputDevice", "dspRuntimeTagOutputReset",
+    "dspRuntimeSetInstances", "dspRuntimeBlockAllInstancesDevice", "dspRuntimeInstanceState",
     # thin HIP ABI (include/avdsp_hip.h)
     "avdsp_hip_device_count", "avdsp_hip_set_device", "avdsp_hip_prog_create", "avdsp_hip_prog_destroy",
     "avdsp_hip_prog_add_plan", "avdsp_hip_prog_add_generic", "avdsp_hip_prog_clear_plans", "avdsp_hip_tpdf_reset", "avdsp_hip_upload_words", "avdsp_hip_download_words", "avdsp_hip_zero_words",
@@ -103,6 +104,10 @@ def lib() -> C.CDLL:
         L.dspRuntimeBlockAllDevice.argtypes = [i32, vp, vp, i32, i32, vp, i32, i32, i32, vp]
         L.dspRuntimeBlockAllPcm.restype = i32
         L.dspRuntimeBlockAllPcm.argtypes = [i32, vp, i32, vp, i32, i32, vp, i32, i32, i32]
+        L.dspRuntimeSetInstances.restype = i32; L.dspRuntimeSetInstances.argtypes = [i32]
+        L.dspRuntimeBlockAllInstancesDevice.restype = i32
+        L.dspRuntimeBlockAllInstancesDevice.argtypes = [i32, vp, vp, i32, i32, C.c_size_t, vp, i32, i32, C.c_size_t, i32, vp]
+        L.dspRuntimeInstanceState.restype = i32; L.dspRuntimeInstanceState.argtypes = [i32, vp]
         L.dspRuntimeBlockPcm.restype = i32
         L.dspRuntimeBlockPcm.argtypes = [i32, vp, vp, i32, vp, i32, i32, vp, i32, i32, i32]
         L.dspRuntimeUnpackPcmDevice.restype = i32
@@ -297,6 +302,26 @@ class Runtime:
             b1 = min(b0 + block, nframes)
             self._check(self.L.dspRuntimeBlockAll(self.fmt, self.rundata, x[b0:b1].ctypes.data, in_stride, in_io_base,
                                                   out[b0:b1].ctypes.data, out_stride, out_io_base, b1 - b0))
+        return out
+
+    def set_instances(self, n: int):
+        """dspRuntimeSetInstances: n copies of the program side by side (instance i: its own state and sample blocks)."""
+        self._select()
+        self._check(self.L.dspRuntimeSetInstances(n))
+
+    def run_block_all_instances_device(self, d_in_ptr: int, in_stride: int, in_io_base: int, in_inst_words: int,
+                                       d_out_ptr: int, out_stride: int, out_io_base: int, out_inst_words: int,
+                                       nframes: int, stream: int = 0) -> int:
+        """dspRuntimeBlockAllInstancesDevice: every core of every instance over one block each, resident in HBM."""
+        return self._check(self.L.dspRuntimeBlockAllInstancesDevice(
+            self.fmt, self.rundata, d_in_ptr, in_stride, in_io_base, in_inst_words,
+            d_out_ptr, out_stride, out_io_base, out_inst_words, nframes, stream))
+
+    def instance_state(self, inst: int) -> np.ndarray:
+        """the data area of instance `inst` (what sync_state() brings back for instance 0)"""
+        self._select()
+        out = np.zeros(len(self.state), dtype=self.state.dtype)
+        self._check(self.L.dspRuntimeInstanceState(inst, out.ctypes.data))
         return out
 
     def run_block_all_pcm(self, pcm: int, raw: np.ndarray, nframes: int, in_stride: int, out_stride: int,

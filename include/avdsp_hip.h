@@ -166,6 +166,13 @@ int avdsp_hip_run_block_pcm_host(avdsp_hip_prog *prog, int plan, int pcm, const 
  * 2 * mask = only the kinds whose bit is set in mask (an event pair costs a few microseconds of stream
  * time: a benchmark times the kernel it reports and nothing else).                               */
 enum { AVDSP_KERNEL_BIQUAD = 0, AVDSP_KERNEL_FIR = 1, AVDSP_KERNEL_PASS = 2, AVDSP_KERNEL_GENERIC = 3, AVDSP_KERNEL_UNPACK = 4, AVDSP_KERNEL_GENERIC_WAVE = 5, AVDSP_KERNEL_STRANDS = 6 };
+/* N instances of the loaded program side by side (dspRuntimeSetInstances / dspRuntimeBlockAllInstancesDevice): instance i has a copy of
+ * the whole device state of its own and its sample blocks at d_in + i * in_inst_words, d_out + i * out_inst_words (32-bit words). */
+int avdsp_hip_set_instances(avdsp_hip_prog *prog, int n);
+int avdsp_hip_run_levels_instances(avdsp_hip_prog *prog, const int *plans, const int *level_size, int nlevels,
+                                   const void *d_in, int in_stride, int in_io_base, size_t in_inst_words,
+                                   void *d_out, int out_stride, int out_io_base, size_t out_inst_words, int nframes, void *stream);
+int avdsp_hip_download_instance_words(avdsp_hip_prog *p, int inst, int32_t *host_buf, int first, int n);
 int avdsp_hip_profile_enable(avdsp_hip_prog *prog, int on);
 int avdsp_hip_profile_read(avdsp_hip_prog *prog, int kind, double *total_ms, int *launches);
 /* of the launches the latest avdsp_hip_profile_read of `kind` summed: how many were timed by an event pair recorded around the launch
@@ -211,7 +218,9 @@ int avdsp_hip_plan_strands(const avdsp_hip_prog *prog, int plan);      /* strand
  * block k (side stream; see launch_all in avdsp_kernels.hip) -- the caller then guarantees that a block's input is
  * complete in memory when the call is made.                                                                     */
 enum { AVDSP_OPT_OVERLAP = 0, AVDSP_OPT_PROFILE_STRIDE = 1, AVDSP_OPT_FIR_ROWS = 3, AVDSP_OPT_HOST_SPLIT = 4, AVDSP_OPT_HOST_PIN = 5,
-       AVDSP_OPT_READY_WORDS = 6, AVDSP_OPT_LANE_HW = 7 };
+       AVDSP_OPT_READY_WORDS = 6, AVDSP_OPT_LANE_HW = 7, AVDSP_OPT_FIR_SPLIT = 8 };
+/* FIR_SPLIT 1 (opt-in; default 0): a fir_tile launch that leaves a SIMD one wave at most (256 chains x 4096 taps) cuts every tile's taps
+ * over two waves and adds the two partial sums -- within BASELINE's 1e-6 of the reference, not its bits any more. */
 /* LANE_HW 1 (default): formats 3 and 5 multiply with v_mul_f32 under round-toward-zero wherever the operands' exponents make that the
  * reference's dspMulFloatFloat bit for bit (fir_lane_hw, chain_rows); 0: the integer restatement of the product throughout. */
 /* READY_WORDS 1: under OVERLAP the FIR finds its cascades' blocks through per-chain ready words polled inside the kernel instead of

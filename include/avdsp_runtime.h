@@ -22,6 +22,8 @@
 #ifndef AVDSP_RUNTIME_H_
 #define AVDSP_RUNTIME_H_
 
+#include <stddef.h>
+
 #include "avdsp_format.h"
 
 #ifdef __cplusplus
@@ -129,6 +131,16 @@ int dspRuntimeBlockDevice(int format, opcode_t *core, int *rundata,
  * strands (LOAD ... STORE runs) that hand nothing to each other, which run side by side as well ("strand_split",
  * default 1).  dspRuntimeGetOption("levels") / ("cores") / ("pieces") tell how the latest call was arranged.  format = DSP_FORMAT 2..6;
  * in/out: int32 or float samples as in dspRuntimeBlock_N (host pointers) / device pointers + stream.       */
+/* N instances of the loaded program side by side (extension; avdsp_host.c has the semantics): the reference is one program on one
+ * core per process -- a host with many independent streams of the same program (a thousand stereo crossovers) loads it once.
+ * Instance i: sample blocks at d_in + i * in_inst_words and d_out + i * out_inst_words (32-bit words), state of its own, copied
+ * from the program's at the first block call after dspRuntimeSetInstances.  dspRuntimeInstanceState(i, dst) brings back instance
+ * i's data area (dataSize words).  Every core must be one the frame-parallel interpreter takes. */
+int dspRuntimeSetInstances(int n);
+int dspRuntimeBlockAllInstancesDevice(int format, int *rundata, const void *d_in, int in_stride, int in_io_base, size_t in_inst_words,
+                                      void *d_out, int out_stride, int out_io_base, size_t out_inst_words, int nframes, void *stream);
+int dspRuntimeInstanceState(int inst, int *dst);
+
 int dspRuntimeBlockAll(int format, int *rundata, const void *in, int in_stride, int in_io_base,
                        void *out, int out_stride, int out_io_base, int nframes);
 int dspRuntimeBlockAllDevice(int format, int *rundata, const void *d_in, int in_stride, int in_io_base,

@@ -16,6 +16,7 @@ pytestmark = pytest.mark.gpu
 def _release():
     yield
     rt.lib().dspRuntimeSetOption(b"fir_rows", 0)
+    rt.lib().dspRuntimeSetOption(b"fir_split", 0)
     rt.lib().dspRuntimeRelease()
 
 
@@ -141,3 +142,33 @@ def test_four_row_tiles_store_together_only_when_the_columns_allow(layout):
         got = r.run_block(x, C, C)
         assert (words(got) == words(want)).all()
     assert (r.sync_state() == o.state).all()
+
+
+@pytest.mark.parametrize("fmt,C,S,T", [(6, 5, 0, 4096), (6, 3, 0, 1), (6, 4, 0, 37), (6, 6, 2, 4100), (4, 4, 0, 2560), (6, 5, 0, 641)])
+def test_opt_in_tap_split_is_within_the_stated_tolerance(fmt, C, S, T):
+    """dspRuntimeSetOption("fir_split", 1), off by default: a fir_tile launch that leaves a SIMD one wave at most (here: always)
+    cuts every tile's taps over two waves and adds the two partial sums -- (taps 0 .. S/2) + (taps S/2 ..), NOT the reference's
+    summation order, so the check is BASELINE's float-mode tolerance (1e-6 of the block's peak), not bit equality; the delay lines
+    (the state) are the reference's bits all the same, and the option off gives the reference's bits again."""
+    prog = pb.synth_program(fmt, C, S, T)
+    blocks = [1024, 300, 1, 1024, 513]
+    x = pb.lcg_input(sum(blocks), C, fmt == 6, seed=C + T)
+    o = po.OracleProgram(fmt, prog)
+    want = np.concatenate([o.run_block(x[p:p + b], C, C) for p, b in zip(np.cumsum([0] + blocks[:-1]), blocks)])
+    r = rt.Runtime(fmt, prog)
+    r.set_option("fir_split", 1)
+    assert r.get_option("fir_split") == 1
+    got = np.concatenate([r.run_block(x[p:p + b], C, C) for p, b in zip(np.cumsum([0] + blocks[:-1]), blocks)])
+    if fmt == 6:
+        err = np.abs(got.astype(np.float64) - want.astype(np.float64)).max()
+        peak = np.abs(want.astype(np.float64)).max()
+    else:
+        err = np.abs(got.astype(np.int64) - want.astype(np.int64)).max()
+        peak = np.abs(want.astype(np.int64)).max()
+    assert err <= 1e-6 * peak, f"max abs error {err} against a peak of {peak}"
+    assert (r.sync_state() == o.state).all(), "the delay lines do not depend on the summation order"
+    r.set_option("fir_split", 0)
+    r.release()
+    r = rt.Runtime(fmt, prog)
+    got = np.concatenate([r.run_block(x[p:p + b], C, C) for p, b in zip(np.cumsum([0] + blocks[:-1]), blocks)])
+    assert (words(got) == words(want)).all()

@@ -17,6 +17,7 @@ ap.add_argument("workload", nargs="?", default="north")
 ap.add_argument("--shard", default=None)
 ap.add_argument("--fir-rows", type=int, default=0)
 ap.add_argument("--fir-impl", type=int, default=3)
+ap.add_argument("--fir-split", type=int, default=0)
 ap.add_argument("--blocks", type=int, default=6, help="blocks run before the one that is summarised")
 args = ap.parse_args()
 
@@ -36,6 +37,7 @@ fmt, Cn, S, T, B = bench.WORKLOADS[args.workload]
 r = rt.Runtime(fmt, pb.synth_program(fmt, Cn, S, T))
 r.set_option("fir_rows", args.fir_rows)
 r.set_option("fir_impl", args.fir_impl)
+r.set_option("fir_split", args.fir_split)
 if args.shard:
     a, b = (int(v) for v in args.shard.split("/"))
     r.set_shard(a, b)
