@@ -98,35 +98,43 @@ def program(nch, fmt, ops, rng):
     return enc.encode(build, 2 if fmt == 2 else 6, F48000, F48000, max_io=IN0 + nch + 8, capacity=1 << 18), nstore
 
 
-bad = n = lowered = 0
-for seed in range(int(sys.argv[1]), int(sys.argv[2])):
-    rng = np.random.default_rng(seed)
-    ops = shape_of(rng)
-    nch = int(rng.choice([2, 3, 5, 16, 64, 65, 100]))
-    for fmt in (2, 3, 4, 5, 6):
-        rs = np.random.default_rng(seed * 7 + 1)
-        try:
-            prog, nstore = program(nch, fmt, ops, rs)
-        except Exception as e:                              # (a shape the encoder refuses)
-            print("seed", seed, "fmt", fmt, "encoder:", str(e)[:80]); break
-        blocks = [int(b) for b in rs.choice([1, 7, 16, 33, 64, 100, 200], 3)]
-        x = pb.lcg_input(sum(blocks), nch, fmt in (5, 6), seed=seed)
-        nout = max(nstore * nch, 1)
-        o = po.OracleProgram(fmt, prog, fs=48000, random=seed, dither=24)
-        if o.rc < 0: break
-        want = np.concatenate([o.run_block(x[a:a + b], nout, IN0) for a, b in zip(np.cumsum([0] + blocks[:-1]), blocks)])
-        for lanes in (2, 0):
-            r = rt.Runtime(fmt, prog, fs=48000, random=seed, dither=24)
-            r.set_option("strand_lanes", lanes)
+def run(lo, hi, formats=(2, 3, 4, 5, 6)):
+    """seeds lo .. hi-1; returns (runs, list of mismatch descriptions, cases lowered to strand plans)"""
+    bad, n, lowered = [], 0, 0
+    for seed in range(lo, hi):
+        rng = np.random.default_rng(seed)
+        ops = shape_of(rng)
+        nch = int(rng.choice([2, 3, 5, 16, 64, 65, 100]))
+        for fmt in formats:
+            rs = np.random.default_rng(seed * 7 + 1)
             try:
-                got = np.concatenate([r.run_block_all(x[a:a + b], nout, IN0) for a, b in zip(np.cumsum([0] + blocks[:-1]), blocks)])
-                ok = bool((got.view(np.uint32) == want.view(np.uint32)).all()) and bool((r.sync_state() == o.state).all())
-                if lanes == 2: lowered += r.get_option("strands") > 0
-            except rt.AvdspError as e:
-                ok = False; print("   error:", e)
-            n += 1
-            if not ok:
-                bad += 1; print("MISMATCH seed", seed, "fmt", fmt, "lanes", lanes, "strands", nch, "ops", ops)
-            r.set_option("strand_lanes", 1)
-            r.release()
-print("runs", n, "bad", bad, "cases lowered to strand plans", lowered)
+                prog, nstore = program(nch, fmt, ops, rs)
+            except Exception as e:                              # (a shape the encoder refuses)
+                print("seed", seed, "fmt", fmt, "encoder:", str(e)[:80]); break
+            blocks = [int(b) for b in rs.choice([1, 7, 16, 33, 64, 100, 200], 3)]
+            x = pb.lcg_input(sum(blocks), nch, fmt in (5, 6), seed=seed)
+            nout = max(nstore * nch, 1)
+            o = po.OracleProgram(fmt, prog, fs=48000, random=seed, dither=24)
+            if o.rc < 0: break
+            want = np.concatenate([o.run_block(x[a:a + b], nout, IN0) for a, b in zip(np.cumsum([0] + blocks[:-1]), blocks)])
+            for lanes in (2, 0):
+                r = rt.Runtime(fmt, prog, fs=48000, random=seed, dither=24)
+                r.set_option("strand_lanes", lanes)
+                try:
+                    got = np.concatenate([r.run_block_all(x[a:a + b], nout, IN0) for a, b in zip(np.cumsum([0] + blocks[:-1]), blocks)])
+                    ok = bool((got.view(np.uint32) == want.view(np.uint32)).all()) and bool((r.sync_state() == o.state).all())
+                    if lanes == 2: lowered += r.get_option("strands") > 0
+                except rt.AvdspError as e:
+                    ok = False; print("   error:", e)
+                n += 1
+                if not ok:
+                    bad.append(f"seed {seed} fmt {fmt} lanes {lanes} strands {nch} ops {ops}")
+                r.set_option("strand_lanes", 1)
+                r.release()
+    return n, bad, lowered
+
+
+if __name__ == "__main__":
+    n, bad, lowered = run(int(sys.argv[1]), int(sys.argv[2]))
+    for b in bad: print("MISMATCH", b)
+    print("runs", n, "bad", len(bad), "cases lowered to strand plans", lowered)
