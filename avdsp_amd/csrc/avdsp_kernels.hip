@@ -2925,6 +2925,18 @@ struct avdsp_hip_prog {
     hipStream_t s_fir[2] = {nullptr, nullptr};           /* "overlap" 2: the FIRs of consecutive blocks in turn */
     static constexpr int kAhead = 3;     /* cascade k waits for FIR k - kAhead: it may run under FIR k - 2 and be done before FIR k - 1 ends */
     hipEvent_t ev_bq[kAhead] = {nullptr, nullptr, nullptr}, ev_fir[kAhead] = {nullptr, nullptr, nullptr};
+    /* How an un-timed FIR launch of the overlap mode is enqueued (launch_all), by what was measured:
+     *   1  the event the next cascades wait for rides on the dispatch's own completion signal (hipExtLaunchKernel's stop slot) instead
+     *      of a marker packet behind it: 4096 chains 0.5110 -> 0.5078 ms per step, 2048 chains 0.2592 -> 0.2572;
+     *   2  the dispatch carries a start and a stop event (a marker in front of it, a completion signal of its own): where the
+     *      cascade of the next blocks is what the step waits for -- FIR launches under ~0.2 ms: 512 chains 0.0971 -> 0.0868 ms,
+     *      1024 chains 0.1559 -> 0.1464, cfg5's 2048-chain shard 0.1575 -> 0.1477 -- the few microseconds the queue spends on the
+     *      marker are microseconds the starved cascade has the chip to itself; on the long launches it only costs (0.5078 -> 0.5202);
+     *   0  a plain launch and a recorded event (round 3).
+     * -1 (default): 2 for plans of at most 6 M taps in all (chains x taps), else 1.  AVDSP_OPT_FIR_LAUNCH / AVDSP_FIR_LAUNCH_MODE. */
+    int fir_launch_mode = -1, fir_mode_now = 0;
+    hipEvent_t launch_ev[16] = {};       /* ... mode 2: a small ring of start / stop event pairs */
+    unsigned launch_ev_next = 0;
     int lane_hw = 1;                     /* formats 3 / 5: the hardware's toward-zero product where it is the reference's (fir_lane_hw, chain_rows' fast steps); 0: the integer products throughout */
     int ready_words = 0;                 /* "overlap": the FIR waits for its cascades through the plans' ready words (in the kernel) instead of an event between the two queues: measured slower, off by default */
     unsigned *d_ready_timeouts = nullptr;        /* waves whose bounded wait for a ready word ran out (never, see chain_ready_wait) */
@@ -3044,6 +3056,13 @@ int launch_timed(ProfileScope &scope, const void *fn, dim3 grid, dim3 block, siz
     hipEvent_t s = nullptr, e = nullptr;
     if (stop) { scope.begin(); HIP_TRY(hipExtLaunchKernel(fn, grid, block, kargs, lds, stream, nullptr, stop, 0)); return 0; }
     if (scope.ride(s, e)) { HIP_TRY(hipExtLaunchKernel(fn, grid, block, kargs, lds, stream, s, e, 0)); return 0; }
+    if (scope.kind == AVDSP_KERNEL_FIR && scope.prog->fir_mode_now == 2) {
+        avdsp_hip_prog *pg = scope.prog;
+        const unsigned k = (pg->launch_ev_next++ & 7u) * 2;
+        for (unsigned j = k; j < k + 2; j++) if (!pg->launch_ev[j]) HIP_TRY(hipEventCreate(&pg->launch_ev[j]));
+        HIP_TRY(hipExtLaunchKernel(fn, grid, block, kargs, lds, stream, pg->launch_ev[k], pg->launch_ev[k + 1], 0));
+        return 0;
+    }
     HIP_TRY(hipLaunchKernel(fn, grid, block, kargs, lds, stream));
     return 0;
 }
@@ -3123,7 +3142,7 @@ extern "C" int avdsp_hip_debug_fir_stamps(unsigned long long *host_out, int max_
 #endif
 
 template <int FMT, int R, bool BIG = false, bool SPLIT = false>
-int launch_fir_tile(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, BlockIO io, hipStream_t stream, ProfileScope &scope, bool wait_ready)
+int launch_fir_tile(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, BlockIO io, hipStream_t stream, ProfileScope &scope, bool wait_ready, hipEvent_t stop = nullptr)
 {
     FirTileArgs a{};
     a.buf = prog->d_buf; a.chains = pl.d_chains; a.group = ids; a.ngroup = n;
@@ -3139,7 +3158,7 @@ int launch_fir_tile(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, Block
     a.stamps = d_stamps;
     g_fir_stamps = d_stamps; g_fir_stamp_waves = a.per_xcd * 8 * 4;
 #endif
-    return launch_timed(scope, (const void *)fir_tile<FMT, R, BIG, SPLIT>, dim3(a.per_xcd * 8), dim3(kBlock), lds, stream, a);
+    return launch_timed(scope, (const void *)fir_tile<FMT, R, BIG, SPLIT>, dim3(a.per_xcd * 8), dim3(kBlock), lds, stream, a, stop);
 }
 
 
@@ -3181,9 +3200,9 @@ int launch_fir_stream(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, Blo
 
 /* fir_impl: 0 = fir_plain (the reference's loop), 1 = fir_tile (default), 2 = fir_mfma (round 1's workgroup-per-channel kernel) */
 template <int FMT>
-int launch_fir(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, BlockIO io, int fir_impl, hipStream_t stream, bool wait_ready = false)
+int launch_fir(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, BlockIO io, int fir_impl, hipStream_t stream, bool wait_ready = false, hipEvent_t stop = nullptr)
 {
-    if constexpr (FMT == 2) { (void)prog; (void)pl; (void)ids; (void)n; (void)io; (void)fir_impl; (void)stream; (void)wait_ready; return 0; }
+    if constexpr (FMT == 2) { (void)prog; (void)pl; (void)ids; (void)n; (void)io; (void)fir_impl; (void)stream; (void)wait_ready; (void)stop; return 0; }
     else {
         ProfileScope scope(prog, stream, AVDSP_KERNEL_FIR);
         if (fir_impl != 1) scope.begin();
@@ -3205,11 +3224,11 @@ int launch_fir(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, BlockIO io
             /* one row tile and at most a wave per SIMD (1024): chunks twice as long -- nothing hides a boundary there */
             const long long waves1 = (long long)n * ((io.nframes + 255) / 256);
             /* "fir_split" (opt-in, not the reference's summation order): such a launch with two waves per tile instead */
-            if (rows == 1 && waves1 <= 1024 && prog->fir_split) return launch_fir_tile<FMT, 1, false, true>(prog, pl, ids, n, io, stream, scope, wait_ready);
-            if (rows == 1 && waves1 <= 1024 && prog->fir_rows != 1) return launch_fir_tile<FMT, 1, true>(prog, pl, ids, n, io, stream, scope, wait_ready);
-            return rows == 4 ? launch_fir_tile<FMT, 4>(prog, pl, ids, n, io, stream, scope, wait_ready)
-                 : rows == 2 ? launch_fir_tile<FMT, 2>(prog, pl, ids, n, io, stream, scope, wait_ready)
-                             : launch_fir_tile<FMT, 1>(prog, pl, ids, n, io, stream, scope, wait_ready);
+            if (rows == 1 && waves1 <= 1024 && prog->fir_split) return launch_fir_tile<FMT, 1, false, true>(prog, pl, ids, n, io, stream, scope, wait_ready, stop);
+            if (rows == 1 && waves1 <= 1024 && prog->fir_rows != 1) return launch_fir_tile<FMT, 1, true>(prog, pl, ids, n, io, stream, scope, wait_ready, stop);
+            return rows == 4 ? launch_fir_tile<FMT, 4>(prog, pl, ids, n, io, stream, scope, wait_ready, stop)
+                 : rows == 2 ? launch_fir_tile<FMT, 2>(prog, pl, ids, n, io, stream, scope, wait_ready, stop)
+                             : launch_fir_tile<FMT, 1>(prog, pl, ids, n, io, stream, scope, wait_ready, stop);
         }
         FirArgs a{};
         a.buf = prog->d_buf; a.chains = pl.d_chains; a.group = ids; a.ngroup = n;
@@ -3291,8 +3310,15 @@ int launch_all(avdsp_hip_prog *prog, Plan &pl, BlockIO io, int fir_impl, int biq
              * packet on another queue's signal -- holds the next dispatch back by ~9 us even when the signal is long down
              * (tools/step_gaps.py: 10.7 us between two FIRs of the 4096-chain program, 1.5-2 us between two kernels of one queue). */
             if (!words) HIP_TRY(hipStreamWaitEvent(stream, prog->ev_bq[slot], 0));
-            if (launch_fir<FMT>(prog, pl, pl.d_fir_ids, pl.n_fir, io, fir_impl, stream, words)) return -1;
-            HIP_TRY(hipEventRecord(prog->ev_fir[slot], stream));
+            const int mode = fir_impl != 1 ? 0 : prog->fir_launch_mode >= 0 ? prog->fir_launch_mode
+                           : (long long)pl.n_fir * pl.max_taps <= 6000000ll ? 2 : 1;
+            /* (a launch whose kernel timer is sampled carries the timer's events instead; its event is then recorded behind it) */
+            const bool rides = mode == 1 && !((prog->profile >> AVDSP_KERNEL_FIR & 1u) && prog->profile_seen[AVDSP_KERNEL_FIR & 7] % (unsigned)prog->profile_stride == 0);
+            prog->fir_mode_now = mode;
+            const int rc_fir = launch_fir<FMT>(prog, pl, pl.d_fir_ids, pl.n_fir, io, fir_impl, stream, words, rides ? prog->ev_fir[slot] : nullptr);
+            prog->fir_mode_now = 0;
+            if (rc_fir) return -1;
+            if (!rides) HIP_TRY(hipEventRecord(prog->ev_fir[slot], stream));
         }
         prog->ev_fir_set[slot] = true;
         prog->blk++;
@@ -3343,6 +3369,7 @@ avdsp_hip_prog *avdsp_hip_prog_create(int total_words)
     /* + 2 words: the interpreter fetches the two words behind every head word, also behind the last one */
     hipError_t e = hipMalloc((void **)&p->d_buf, ((size_t)(total_words > 0 ? total_words : 1) + 2) * sizeof(int));
     if (e != hipSuccess) { set_err("hipMalloc(mirror, %d words): %s", total_words, hipGetErrorString(e)); delete p; return nullptr; }
+    if (const char *m = getenv("AVDSP_FIR_LAUNCH_MODE")) p->fir_launch_mode = atoi(m);
     if (hipMalloc((void **)&p->d_ready_timeouts, 16) != hipSuccess || hipMemset(p->d_ready_timeouts, 0, 16) != hipSuccess) p->d_ready_timeouts = nullptr;   /* (without it the FIR waits for events) */
     return p;
 }
@@ -4681,6 +4708,7 @@ int avdsp_hip_prog_set_option(avdsp_hip_prog *prog, int key, int value)
     case AVDSP_OPT_READY_WORDS: prog->ready_words = value != 0; return 0;
     case AVDSP_OPT_LANE_HW: prog->lane_hw = value != 0; return 0;
     case AVDSP_OPT_FIR_SPLIT: prog->fir_split = value != 0; return 0;
+    case AVDSP_OPT_FIR_LAUNCH: if (value < -1 || value > 2) return set_err("fir_launch: -1 (auto), 0, 1 or 2"); prog->fir_launch_mode = value; return 0;
     case AVDSP_OPT_FIR_ROWS: if (value != 0 && value != 1 && value != 2 && value != 4) return set_err("fir_tile row tiles: 0 (auto), 1, 2 or 4");
                              prog->fir_rows = value; return 0;
     case AVDSP_OPT_PROFILE_STRIDE: if (value < 1) return set_err("profile_stride: every n-th launch, n >= 1"); prog->profile_stride = value; return 0;
