@@ -2353,13 +2353,17 @@ __global__ __launch_bounds__(64) void chain_rows(const LaneArgs a, const int *id
     using alu_t = typename M<FMT>::alu;
     flush_f32_subnormals_like_the_reference();
     __shared__ int xin[2][4][16];
-    const int lane = threadIdx.x, row = lane >> 4, s = lane & 15;
+    const int lane = threadIdx.x, row = lane >> 4, rp = lane & 15;
     const int gi = blockIdx.x * 4 + row;
     const bool valid = gi < nids;
     const int cid = ids[valid ? gi : nids - 1];
     const avdsp_chain c = a.chains[cid];
     const int S = c.nsec, B = a.io.nframes;
-    const bool mine = valid && s < S;
+    /* rows are RIGHT-aligned (round 4): the chain's last section sits in lane 15 of its row whatever the section count, so that its
+     * results reach the row's lanes with one dpp (row_newbcast:15) and leave sixteen frames at a time; rp is the lane's place in the
+     * row -- the slot of the input batch it fetches -- and s its section (negative: none) */
+    const int s = rp - (16 - S);
+    const bool mine = valid && s >= 0;
     BqState<FMT> q; q.acc = 0; q.x1 = q.x2 = q.y1 = q.y2 = 0;
     int cw[5] = {0, 0, 0, 0, 0};
     int *stw = a.buf;
@@ -2414,13 +2418,13 @@ __global__ __launch_bounds__(64) void chain_rows(const LaneArgs a, const int *id
         constexpr bool exact = decltype(exact_c)::value;
         float acc = q.acc.v;
         Apart x1 = apart((unsigned)q.x1, 0), x2 = apart((unsigned)q.x2, 0), y1 = apart((unsigned)q.y1, 0), y2 = apart((unsigned)q.y2, 0);
-        xin[0][row][s] = fetch(s);
+        xin[0][row][rp] = fetch(rp);
         __syncthreads();
         int y = 0;
         const int steps = B + 15;                        /* the longest row's last frame leaves its 16th section at step B - 1 + 15 */
         for (int t0 = 0; t0 < steps; t0 += 16) {
             const int cur = (t0 >> 4) & 1;
-            const int ahead = fetch(t0 + 16 + s);        /* (in flight under the batch's steps) */
+            const int ahead = fetch(t0 + 16 + rp);       /* (in flight under the batch's steps) */
             for (int k = 0; k < 16; k++) {
                 const int t = t0 + k;
                 int x = __builtin_amdgcn_update_dpp(0, y, kRowShr1, 0xF, 0xF, false);      /* the section before, one step ago */
@@ -2450,7 +2454,7 @@ __global__ __launch_bounds__(64) void chain_rows(const LaneArgs a, const int *id
                     }
                 }
             }
-            xin[cur ^ 1][row][s] = ahead;
+            xin[cur ^ 1][row][rp] = ahead;
             __syncthreads();                             /* (one wave: orders the row's writes against the section-0 lane's reads) */
         }
         if constexpr (!exact) { q.acc = FF(acc); q.x1 = (int)whole(x1); q.x2 = (int)whole(x2); q.y1 = (int)whole(y1); q.y2 = (int)whole(y2); }
@@ -2473,9 +2477,9 @@ __global__ __launch_bounds__(64) void chain_rows(const LaneArgs a, const int *id
         const float c0 = __int_as_float(cw[0]), c1 = __int_as_float(cw[1]), c2 = __int_as_float(cw[2]), c3 = __int_as_float(cw[3]), c4 = __int_as_float(cw[4]);
         auto out_of_band = [&](unsigned w) { const unsigned mag = w & 0x7FFFFFFFu; return (mag - 1u < lo_bits - 1u) | (mag >= hi_bits); };
         bool bad = false;
-        const int first = fetch(s);
+        const int first = fetch(rp);
         bad |= out_of_band((unsigned)first);
-        xin[0][row][s] = first;
+        xin[0][row][rp] = first;
         __syncthreads();
         int y = 0;
         const int steps = B + 15;
@@ -2487,6 +2491,22 @@ __global__ __launch_bounds__(64) void chain_rows(const LaneArgs a, const int *id
         unsigned *op = to_seq ? a.seq + (size_t)cid * a.pitch + a.hist - s
                               : a.io.out + (c.out_io[0] - a.io.out_base) - (ptrdiff_t)s * a.io.out_stride;
         const size_t ostep = to_seq ? 1 : (size_t)a.io.out_stride;
+        /* ... and, in the batches where every lane is busy, sixteen frames at a time: lane rp of the row takes the last section's result
+         * of the batch's step rp (row_newbcast:15) and converts and stores frame t0 + rp - (S - 1) when the batch is through */
+        unsigned *bp = to_seq ? a.seq + (size_t)cid * a.pitch + a.hist + (rp - (S - 1))
+                              : a.io.out + (c.out_io[0] - a.io.out_base) + (ptrdiff_t)(rp - (S - 1)) * a.io.out_stride;
+        auto leave_word = [&](float v, int f, unsigned *at) __attribute__((always_inline)) {
+            alu_t X = FF(v);
+            if (to_seq) *at = __float_as_uint(to_sp<FMT>(X));
+            else {
+                if (c.sat) X = sat0db<FMT>(X);
+                unsigned word;
+                if constexpr (M<FMT>::smp_int) word = (unsigned)(s31_from_float(X.v) & a.io.store_mask);
+                else word = __float_as_uint(to_sp<FMT>(X));
+                if (plain_out) *at = word; else emit_out(a.io, c, f, word);
+            }
+        };
+        const bool batch_out = to_seq || !c.fir_taps;    /* (a FIR on the delay line -- single frames only -- keeps the frame-by-frame way) */
         auto leave = [&](int f) __attribute__((always_inline)) {
             alu_t X = FF(acc);
             if (to_seq) *op = __float_as_uint(to_sp<FMT>(X));
@@ -2518,7 +2538,7 @@ __global__ __launch_bounds__(64) void chain_rows(const LaneArgs a, const int *id
         };
         for (int t0 = 0; t0 < steps; t0 += 16) {
             const int cur = (t0 >> 4) & 1;
-            const int ahead = fetch(t0 + 16 + s);
+            const int ahead = fetch(t0 + 16 + rp);
             bad |= out_of_band((unsigned)ahead);
             /* the row's sixteen inputs of this batch, in registers (no LDS round trip in front of a step's products) */
             int xa[16];
@@ -2530,14 +2550,20 @@ __global__ __launch_bounds__(64) void chain_rows(const LaneArgs a, const int *id
             }
             if (t0 >= 16 && t0 + 15 < B) {
                 /* every section of every row is busy in all sixteen steps: nothing to ask.  (Lanes without a section run along on zeros.) */
+                int mine_out = 0;
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
                     int x = __builtin_amdgcn_update_dpp(0, y, kRowShr1, 0xF, 0xF, false);
                     if (s == 0) x = xa[k];
                     update(x);
-                    if (is_last) leave(t0 + k - s);
+                    if (batch_out) {
+                        int yb;
+                        asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_newbcast:15 row_mask:0xf bank_mask:0xf" : "=v"(yb) : "v"(y));
+                        mine_out = rp == k ? yb : mine_out;
+                    } else if (is_last) leave(t0 + k - s);
                     op += ostep;
                 }
+                if (batch_out && valid) leave_word(__int_as_float(mine_out), t0 + rp - (S - 1), bp + (size_t)t0 * ostep);
             } else {
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
@@ -2551,7 +2577,7 @@ __global__ __launch_bounds__(64) void chain_rows(const LaneArgs a, const int *id
                     op += ostep;
                 }
             }
-            xin[cur ^ 1][row][s] = ahead;
+            xin[cur ^ 1][row][rp] = ahead;
             __syncthreads();
         }
         if (__ballot(bad) != 0) return false;
