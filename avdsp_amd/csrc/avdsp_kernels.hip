@@ -2764,9 +2764,9 @@ __global__ __launch_bounds__(256) void fir_lane_hw(const LaneArgs a)
     using namespace interp;
     using alu_t = typename M<FMT>::alu;
     flush_f32_subnormals_like_the_reference();
-    constexpr int kFront = 40;                           /* zeros below ws[0]: the chunk's taps are padded to a multiple of 16 with zeros, whose inputs are read from there */
+    constexpr int kFront = 56;                           /* zeros below ws[0]: the chunk's taps are padded to a multiple of 32 with zeros, whose inputs are read from there */
     __shared__ __attribute__((aligned(16))) unsigned wsbuf[kFront + kFirLaneChunk + kFirHwFrames + 8];
-    __shared__ __attribute__((aligned(16))) unsigned hs[kFirLaneChunk + 16];
+    __shared__ __attribute__((aligned(16))) unsigned hs[kFirLaneChunk + 32];
     unsigned *ws = wsbuf + kFront;
     __shared__ int rng[5];                               /* xmin - 1 (unsigned: a zero exponent counts as 2^32 - 1), xmax, hmin - 1, hmax; [4]: a lane's sum so far is -0.0 or under 2^-101 */
     const int cid = blockIdx.x, t = threadIdx.x, n0 = blockIdx.y * kFirHwFrames;
@@ -2794,7 +2794,7 @@ __global__ __launch_bounds__(256) void fir_lane_hw(const LaneArgs a)
             const unsigned e = w >> 23 & 255u;
             lo = min(lo, e - 1u); hi = max(hi, e);
         }
-        for (int k = t; k < ((tc + 15) & ~15); k += 256) {
+        for (int k = t; k < ((tc + 31) & ~31); k += 256) {
             const unsigned w = k < tc ? taps[i0 + k] : 0u;
             hs[k] = w;
             const unsigned e = w >> 23 & 255u;
@@ -2840,18 +2840,30 @@ __global__ __launch_bounds__(256) void fir_lane_hw(const LaneArgs a)
                        [a2] "=&v"(q4), [b2] "=&v"(q5), [a3] "=&v"(q6), [b3] "=&v"(q7) \
                      : [p0l] "v"(P0L), [p0h] "v"(P0H), [p1l] "v"(P1L), [p1h] "v"(P1H), [p2h] "v"(P2H), \
                        [h0] "v"(H.x), [h1] "v"(H.y), [h2] "v"(H.z), [h3] "v"(H.w))
-        for (int e = 0; e < tc; e += 16) {               /* (the image's taps beyond tc are zeros; their inputs come from the zeros below ws[0]) */
-            uint2 P[9];
+        /* (the image's taps beyond tc are zeros -- up to a multiple of 32 -- and their inputs come from the zeros below ws[0].)  The next
+         * group's operands are read while this group's products and sums run (with two waves per SIMD nothing else hides an LDS round
+         * trip); two groups per turn, so that the two register sets swap roles instead of being copied. */
+        uint2 P[9], Pn[9];
+        uint4 H[4], Hn[4];
+        auto read16 = [&](uint2 (&p)[9], uint4 (&h)[4], int e) __attribute__((always_inline)) {
 #pragma unroll
-            for (int j = 0; j < 9; j++) P[j] = *reinterpret_cast<const uint2 *>(wl - e - 2 * j);
-            uint4 H[4];
+            for (int j = 0; j < 9; j++) p[j] = *reinterpret_cast<const uint2 *>(wl - e - 2 * j);
 #pragma unroll
-            for (int j = 0; j < 4; j++) H[j] = *reinterpret_cast<const uint4 *>(hs + e + 4 * j);
+            for (int j = 0; j < 4; j++) h[j] = *reinterpret_cast<const uint4 *>(hs + e + 4 * j);
+        };
+        auto sum16 = [&](const uint2 (&p)[9], const uint4 (&h)[4]) __attribute__((always_inline)) {
             float q0, q1, q2, q3, q4, q5, q6, q7;
-            AVDSP_FIRHW_4(P[0].x, P[0].y, P[1].x, P[1].y, P[2].y, H[0]);
-            AVDSP_FIRHW_4(P[2].x, P[2].y, P[3].x, P[3].y, P[4].y, H[1]);
-            AVDSP_FIRHW_4(P[4].x, P[4].y, P[5].x, P[5].y, P[6].y, H[2]);
-            AVDSP_FIRHW_4(P[6].x, P[6].y, P[7].x, P[7].y, P[8].y, H[3]);
+            AVDSP_FIRHW_4(p[0].x, p[0].y, p[1].x, p[1].y, p[2].y, h[0]);
+            AVDSP_FIRHW_4(p[2].x, p[2].y, p[3].x, p[3].y, p[4].y, h[1]);
+            AVDSP_FIRHW_4(p[4].x, p[4].y, p[5].x, p[5].y, p[6].y, h[2]);
+            AVDSP_FIRHW_4(p[6].x, p[6].y, p[7].x, p[7].y, p[8].y, h[3]);
+        };
+        read16(P, H, 0);
+        for (int e = 0; e < tc; e += 32) {
+            read16(Pn, Hn, e + 16);
+            sum16(P, H);
+            read16(P, H, e + 32 < tc ? e + 32 : e);           /* (behind the last pair: anything inside the images) */
+            sum16(Pn, Hn);
         }
 #undef AVDSP_FIRHW_4
     }

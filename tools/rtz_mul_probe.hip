@@ -73,6 +73,26 @@ __global__ void k_loop(const float *x, const float *h, float *out, int groups)
     out[lane] = acc;
 }
 
+// what a pair of mode switches costs a wave: registers only, NPER products + NPER dependent sums per pair of s_setreg
+template <int SWITCHES, int NPER>
+__global__ void k_regs(float *out, int iters, float seed)
+{
+    float acc0 = seed, acc1 = seed * 0.5f, x = seed + threadIdx.x * 1e-3f, h = 0.99f;
+    for (int it = 0; it < iters; it++) {
+        float p[NPER];
+        if (SWITCHES) asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3");
+#pragma unroll
+        for (int j = 0; j < NPER; j++) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(p[j]) : "v"(h), "v"(x));
+        if (SWITCHES) asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0");
+#pragma unroll
+        for (int j = 0; j < NPER; j += 2) {
+            asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc0) : "v"(p[j]));
+            asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc1) : "v"(p[j + 1]));
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc0 + acc1;
+}
+
 static unsigned ref_mul(unsigned A, unsigned B)        // dsp_ieee754.h:335-375, restated
 {
     const int ea = (A >> 23) & 255, eb = (B >> 23) & 255;
@@ -174,6 +194,30 @@ int main()
             if (rep == 2) printf("loop of %d lanes x %d taps (4 waves per SIMD), 16 v_mul_f32 + 16 dependent v_add_f32 per group, %s: %.1f us = %.2f cycles per tap and wave at 2.4 GHz\n",
                                  lanes, taps, sw ? "two s_setreg per group" : "no mode switches", us, us * 2400.0 / taps / 4.0);
         }
+    }
+    // (5) the switches' own price, registers only: 1024 SIMDs x W waves, NPER products + NPER sums per pair of switches
+    {
+        float *dreg; CHECK(hipMalloc(&dreg, 4096 * 256 * 4));
+        auto time_it = [&](auto kern, int blocks, const char *what) {
+            for (int rep = 0; rep < 3; rep++) {
+                (void)hipDeviceSynchronize();
+                auto t0 = std::chrono::steady_clock::now();
+                hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, dreg, 20000, 0.25f);
+                (void)hipDeviceSynchronize();
+                const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+                if (rep == 2) printf("  %-58s %8.1f us\n", what, us);
+            }
+        };
+        printf("registers only, 20000 turns per wave (2.4 GHz: 1 us = 2400 cycles):\n");
+        time_it(k_regs<0, 8>, 256, "1 wave/SIMD,  8 mul +  8 add per turn, no switches");
+        time_it(k_regs<1, 8>, 256, "1 wave/SIMD,  8 mul +  8 add per turn, two s_setreg");
+        time_it(k_regs<0, 16>, 256, "1 wave/SIMD, 16 mul + 16 add per turn, no switches");
+        time_it(k_regs<1, 16>, 256, "1 wave/SIMD, 16 mul + 16 add per turn, two s_setreg");
+        time_it(k_regs<0, 8>, 512, "2 waves/SIMD, 8 mul +  8 add per turn, no switches");
+        time_it(k_regs<1, 8>, 512, "2 waves/SIMD, 8 mul +  8 add per turn, two s_setreg");
+        time_it(k_regs<0, 8>, 1024, "4 waves/SIMD, 8 mul +  8 add per turn, no switches");
+        time_it(k_regs<1, 8>, 1024, "4 waves/SIMD, 8 mul +  8 add per turn, two s_setreg");
+        time_it(k_regs<1, 16>, 1024, "4 waves/SIMD, 16 mul + 16 add per turn, two s_setreg");
     }
     // the same sums on the host (toward-zero products by the reference's formula, nearest adds): lanes 0, 1, 77
     {

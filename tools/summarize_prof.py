@@ -10,7 +10,7 @@ import sys
 
 
 def short(name):
-    m = re.search(r"(fir_stream|fir_tile|fir_mfma|fir_plain|biquad_row_i64|biquad_row|biquad_pipe|biquad_simple|strand_lanes|tpdf_walk|interp_wave_grid|interp_wave|interp_core|chain_lane|chain_rows|fir_lane_history|fir_lane_state|fir_lane_feed|fir_lane|passthrough)(<[^>]*>)?", name)
+    m = re.search(r"(fir_stream|fir_tile|fir_mfma|fir_plain|biquad_row_i64|biquad_row|biquad_pipe|biquad_simple|strand_lanes|tpdf_walk|interp_wave_instances|interp_wave_grid|interp_wave|interp_core|chain_lane|chain_rows|fir_lane_history|fir_lane_state|fir_lane_feed|fir_lane_hw|fir_lane|interp_wave_instances|passthrough)(<[^>]*>)?", name)
     return m.group(0) if m else None
 
 
