@@ -225,14 +225,17 @@ __device__ __forceinline__ int xcd_remap(int b, int per_xcd) { return (b & 7) * 
  * the delay line (st[i] = x[n-1-i], dsp_firSTD.h:45-50) is produced from the ring only when the
  * host asks for the state (ring_to_state) and loaded back by state_to_ring.                     */
 struct Ring {
-    float *base;
+    float *base;        /* rows of 2 R floats: every sample is stored TWICE, at p and at p + R (round 4), so that a reader may run up to R
+                         * floats on from any position without wrapping -- fir_tile requests a chunk's window with ONE masked offset per
+                         * lane and immediates from there (a masked offset per sample was a third of a chunk boundary's instructions) */
     int    R;
     int    wpos;
-    double *wide;       /* the same ring as the FIR's window operand: mulop(sample), doubles, frame n at (wpos + n + 3) & (R-1) */
+    double *wide;       /* the same ring as the FIR's window operand: mulop(sample), doubles, frame n at (wpos + n + 3) & (R-1); rows of R */
 };
+__device__ __forceinline__ float *ring_row(const Ring &r, int cid) { return r.base + (size_t)cid * 2 * r.R; }
 __device__ __forceinline__ float *ring_at(const Ring &r, int cid, int q)
 {
-    return r.base + (size_t)cid * r.R + ((r.wpos + q) & (r.R - 1));
+    return ring_row(r, cid) + ((r.wpos + q) & (r.R - 1));
 }
 /* every writer of the ring goes through here: the float (the reference's delay-line value) and the operand made of it */
 /* wt: write-through stores (`sc1`) -- what a cascade puts into the ring of a launch whose FIR waits for the chains' ready words
@@ -242,14 +245,16 @@ __device__ __forceinline__ float *ring_at(const Ring &r, int cid, int q)
 __device__ __forceinline__ void ring_put(const Ring &r, int cid, int q, unsigned bits, bool wt = false)
 {
     const size_t row = (size_t)cid * r.R;
+    float *at = ring_at(r, cid, q);
     if (wt) {
-        __hip_atomic_store(reinterpret_cast<unsigned *>(r.base) + row + ((r.wpos + q) & (r.R - 1)), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(reinterpret_cast<unsigned *>(at), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(reinterpret_cast<unsigned *>(at + r.R), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (r.wide)
             __hip_atomic_store(reinterpret_cast<unsigned long long *>(r.wide) + row + ((r.wpos + q + 3) & (r.R - 1)),
                                (unsigned long long)__double_as_longlong(mulop(__uint_as_float(bits))), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
-    r.base[row + ((r.wpos + q) & (r.R - 1))] = __uint_as_float(bits);
+    at[0] = __uint_as_float(bits); at[r.R] = __uint_as_float(bits);
     if (r.wide) r.wide[row + ((r.wpos + q + 3) & (r.R - 1))] = mulop(__uint_as_float(bits));
 }
 
@@ -690,7 +695,7 @@ __global__ __launch_bounds__(kBlock) void biquad_pipe(const BiquadArgs a)
         const bool to_ring = FMT != 2 && oc.fir_taps != 0;
         const unsigned rmask = (unsigned)ring_l.R - 1u;
         unsigned ridx = ((unsigned)(ring_l.wpos + n0)) & rmask;
-        float *rrow = ring_l.base + (size_t)ocid * ring_l.R;
+        float *rrow = ring_row(ring_l, ocid);
         double *wrow = ring_l.wide ? ring_l.wide + (size_t)ocid * ring_l.R : nullptr;
         unsigned *out_run = io_l.out + (size_t)n0 * io_l.out_stride + (oc.out_io[0] - io_l.out_base);
         const bool more_stores = owner && !to_ring && oc.n_out > 1;
@@ -707,10 +712,11 @@ __global__ __launch_bounds__(kBlock) void biquad_pipe(const BiquadArgs a)
                     const unsigned w = flush_word(true);
                     if (wt) {                             /* (write-through, like ring_put) */
                         __hip_atomic_store(reinterpret_cast<unsigned *>(rrow) + ridx, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(reinterpret_cast<unsigned *>(rrow) + ridx + (rmask + 1u), w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (wrow) __hip_atomic_store(reinterpret_cast<unsigned long long *>(wrow) + ((ridx + 3u) & rmask),
                                                      (unsigned long long)__double_as_longlong(mulop(__uint_as_float(w))), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     } else {
-                        rrow[ridx] = __uint_as_float(w);
+                        rrow[ridx] = __uint_as_float(w); rrow[ridx + (rmask + 1u)] = __uint_as_float(w);
                         if (wrow) wrow[(ridx + 3u) & rmask] = mulop(__uint_as_float(w));
                     }
                 } else {
@@ -890,8 +896,10 @@ __global__ __launch_bounds__(kBlock) void biquad_row(const BiquadArgs a)
     /* steady batches of chains that store once (or feed a FIR ring without the operand copy): a running 32-bit byte offset from a
      * per-lane base -- the ring row, wrapping, or the output column, advancing by 16 frames -- one store, nothing to decide */
     const bool lean = __ballot(have_chain && (rr.flags >> 16 & 0xFF) != 1 && !to_ring) == 0 && ring_l.wide == nullptr;
-    char *obase = to_ring ? reinterpret_cast<char *>(ring_l.base + (size_t)cid * ring_l.R)
+    char *obase = to_ring ? reinterpret_cast<char *>(ring_row(ring_l, cid))
                           : reinterpret_cast<char *>(io_l.out + (rr.out_io - io_l.out_base));
+    const bool any_ring = __ballot(have_chain && to_ring) != 0;      /* (wave-uniform: the second copy of a ring sample, R floats on) */
+    const unsigned omirror = to_ring ? (unsigned)ring_l.R * 4u : 0u;
     const unsigned oinc = to_ring ? 64u : 64u * (unsigned)io_l.out_stride;
     const unsigned owrap = to_ring ? (unsigned)ring_l.R * 4u - 1u : 0xFFFFFFFFu;
     const bool dosat = FMT == 6 && c_sat && !to_ring;
@@ -900,8 +908,13 @@ __global__ __launch_bounds__(kBlock) void biquad_row(const BiquadArgs a)
     auto store_lean = [&](unsigned w) __attribute__((always_inline)) {
         const unsigned v = dosat ? __float_as_uint(__builtin_amdgcn_fmed3f(__uint_as_float(w), -1.0f, 1.0f)) : w;     /* = saturate_f32_0db for every value but a NaN (the replay's business) */
         if (have_chain) {
-            if (wt) __hip_atomic_store(reinterpret_cast<unsigned *>(obase + ooff), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else *reinterpret_cast<unsigned *>(obase + ooff) = v;
+            if (wt) {
+                __hip_atomic_store(reinterpret_cast<unsigned *>(obase + ooff), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(reinterpret_cast<unsigned *>(obase + ooff + omirror), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                *reinterpret_cast<unsigned *>(obase + ooff) = v;
+                if (any_ring) *reinterpret_cast<unsigned *>(obase + ooff + omirror) = v;
+            }
         }
         ooff = (ooff + oinc) & owrap;
     };
@@ -1430,7 +1443,7 @@ __device__ __forceinline__ void fir_chunk_fetch(const FirArgs &a, const avdsp_ch
 {
     const int T = c.fir_taps, B = a.io.nframes, tid = threadIdx.x;
     const float *taps = reinterpret_cast<const float *>(a.buf + c.fir_coef_word);
-    const float *ringrow = a.ring.base + (size_t)cid * a.ring.R;
+    const float *ringrow = ring_row(a.ring, cid);
     const int rmask = a.ring.R - 1, wlen = fir_win_len(a.gpc), woff = fir_win_off(a.gpc);
 #pragma unroll
     for (int u = 0; u < kHRegs; u++) { const int t = mlo + u * kBlock + tid; r.h[u] = (t >= 0 && t < T) ? taps[t] : 0.0f; }
@@ -1613,13 +1626,25 @@ template <int R, bool BIG = false> __device__ __forceinline__ constexpr int win_
  * reference's summation order any more (results within north_star's 1e-6, not its bits), which is why it is an option: a launch
  * of at most one tile per SIMD (cfg4: 256 chains x 4 tiles) then has two waves per SIMD, whose MFMAs interleave and whose chunk
  * boundaries hide under each other.  The two halves of a tile are neighbouring waves of one workgroup and meet through LDS. */
-template <int FMT, int R, bool BIG = false, bool SPLIT = false>
+/* LEAN (round 4): a chunk boundary with a third of the vector instructions -- one masked window offset per lane and chunk (the ring
+ * holds every sample twice, so a window never wraps), no look at every sample for Inf / NaN / subnormals (subnormals: the wave's
+ * MODE flushes them in the conversion; Inf / NaN: seen in the tile's sums at the end, such a tile is summed again the reference's
+ * way), the taps copy in whole pieces.  While one wave of a SIMD streams MFMAs the other's boundary gets a vector instruction in
+ * every few hundred cycles (they share the FP64 datapath): 140 instructions outlast the partner's chunk and what is left of them
+ * when it ends is idle matrix pipe; 50 do not.  tools/fir_boundary_lab.sh (both forms on one box): 4096 chains 0.4929 -> 0.4857 ms per
+ * launch with the chip to itself, 256 chains x 4096 taps 41.6 -> 40.3 us.  NOT where the next blocks' cascades run beside a single
+ * round of FIR waves (a shard of the program): those cascades live on exactly the bubbles this removes, and the lean boundary in
+ * turn no longer fits under the partner's chunk once a cascade wave takes its share of the slots -- a 512-chain shard's FIR alone
+ * 68.4 -> 66.7 us, its step 87.6 -> 96.6; 2048 chains 247.2 -> 244.6 us alone, the step 0.259 -> 0.269 ms -- so such launches keep
+ * the long boundary (launch_fir chooses). */
+template <int FMT, int R, bool BIG = false, bool SPLIT = false, bool LEAN = true>
 __global__ __launch_bounds__(kBlock, 2) void fir_tile(const FirTileArgs a)
 {
     static_assert(!SPLIT || (R == 1 && !BIG), "the tap split: one row tile, ordinary chunks");
     using G = TileGeom<R, BIG>;
     constexpr int NR = G::NR;
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    if constexpr (LEAN) flush_f32_subnormals_like_the_reference();          /* (win_store's conversions; the stores below still flush by hand) */
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int B = a.io.nframes;
     const int blk = xcd_remap(blockIdx.x, a.per_xcd);
@@ -1667,7 +1692,7 @@ __global__ __launch_bounds__(kBlock, 2) void fir_tile(const FirTileArgs a)
     if (a.ready && c.nsec) chain_ready_wait(a.ready, cid, a.seq, a.timeouts);       /* the chain's cascade of this launch has left its block in the ring */
     double *hs = lds + (size_t)wv * G::LDS_DOUBLES, *ws = hs + 2 * G::HLEN;     /* taps images at hs and hs + HLEN */
     const double *hbuf = a.taps64 + (size_t)cid * a.pitch64;
-    const float *ringrow = a.ring.base + (size_t)cid * a.ring.R;
+    const float *ringrow = ring_row(a.ring, cid);
     const int rmask = a.ring.R - 1;
 
     const int i16 = lane & 15, k = lane >> 4;
@@ -1696,23 +1721,37 @@ __global__ __launch_bounds__(kBlock, 2) void fir_tile(const FirTileArgs a)
         const int JT = (4 * (ckc - 1) + NR - 1) / NR;
         /* frame of (row, entry): F0 - 3 + NR (entry + 1 - 4 s0 / NR - JT) + row */
         const unsigned b0 = (unsigned)(a.ring.wpos + F0 - 3 + NR * (went + 1 - 4 * s0 / NR - JT) + wrow) << 2;
+        /* ONE masked offset per lane and chunk; the lane's further samples lie 64 frames apart behind it -- immediates -- and run on
+         * into the row's second copy where the ring wraps (Ring: every sample is stored twice, R floats apart) */
+        if constexpr (LEAN) {
+            const char *p0 = ringbytes + (b0 & rmaskb);
 #pragma unroll
-        for (int t = 0; t < G::NW; t++) wreg[t] = *reinterpret_cast<const float *>(ringbytes + ((b0 + 256u * t) & rmaskb));
+            for (int t = 0; t < G::NW; t++) wreg[t] = *reinterpret_cast<const float *>(p0 + 256 * t);
+        } else {
+#pragma unroll
+            for (int t = 0; t < G::NW; t++) wreg[t] = *reinterpret_cast<const float *>(ringbytes + ((b0 + 256u * t) & rmaskb));
+        }
     };
     auto win_store = [&](double *wdst) {
         double *wp = wdst + wrow * G::ROW + went;
-        bool odd = false;                                   /* NaN, Inf or subnormal among the samples: the reference's bit-field operand */
+        /* (double)sample IS the reference's operand (mulop) for every sample but Inf / NaN -- the wave runs with single-precision
+         * subnormals flushed, so the conversion reads a subnormal as a signed zero, and the sign of a zero operand never reaches a sum
+         * that starts at +0.  Inf and NaN are not looked for here (a v_cmp_class per sample was a sixth of a boundary's instructions):
+         * they make the tile's sums non-finite, which is seen once, behind the last chunk, and such a tile is summed again the
+         * reference's way (exact_tile). */
+        bool odd = false;                                   /* (!LEAN) NaN, Inf or subnormal among the samples: the reference's bit-field operand */
 #pragma unroll
-        for (int t = 0; t < G::NW; t++) {
+        for (int t = 0; t < G::NW; t++)
             if (t * 64 + 63 < NR * G::ROW || lane + t * 64 < NR * G::ROW) {
-                odd |= __builtin_amdgcn_classf(wreg[t], 0x297);
+                if constexpr (!LEAN) odd |= __builtin_amdgcn_classf(wreg[t], 0x297);
                 wp[t * (64 / NR)] = (double)wreg[t];
             }
-        }
-        if (__builtin_expect(__ballot(odd) != 0, 0)) {      /* (no audio stream gets here) the same again with mulop() */
+        if constexpr (!LEAN) {
+            if (__builtin_expect(__ballot(odd) != 0, 0)) {      /* (no audio stream gets here) the same again with mulop() */
 #pragma unroll
-            for (int t = 0; t < G::NW; t++)
-                if (t * 64 + 63 < NR * G::ROW || lane + t * 64 < NR * G::ROW) wp[t * (64 / NR)] = mulop(wreg[t]);
+                for (int t = 0; t < G::NW; t++)
+                    if (t * 64 + 63 < NR * G::ROW || lane + t * 64 < NR * G::ROW) wp[t * (64 / NR)] = mulop(wreg[t]);
+            }
         }
     };
     /* A chunk's taps image u = 0 .. 4 ckc + 16 (R-1) + 27 <- Hbuf[48 - 16 (R-1) + 4 s0 + u] is a plain copy (the taps are doubles
@@ -1724,11 +1763,20 @@ __global__ __launch_bounds__(kBlock, 2) void fir_tile(const FirTileArgs a)
         const char *src = reinterpret_cast<const char *>(hbuf + (kTapsLead - 16) - 16 * (R - 1) + 4 * s0);
         const int np = (4 * ckc + 16 * (R - 1) + 28) / 2;          /* 16-byte pieces the chunk needs; lanes beyond re-read the last one */
         __attribute__((address_space(3))) char *dst = (__attribute__((address_space(3))) char *)hdst;
+        /* (whole 1-KiB pieces: what the last one reads beyond the chunk's need lies inside the row's own zero tail -- kTapsTail covers
+         * HLEN - HNEED < 128 doubles -- and lands behind the part of the image that is read) */
+        if constexpr (LEAN) {
+            const char *mine = src + 16 * lane;
 #pragma unroll
-        for (int t = 0; t < G::HLEN / 128; t++) {
-            const int pi = lane + 64 * t;
-            if (64 * t < np)
-                __builtin_amdgcn_global_load_lds(src + 16 * (pi < np ? pi : np - 1), dst + 1024 * t, 16, 0, 0);
+            for (int t = 0; t < G::HLEN / 128; t++)
+                if (64 * t < np) __builtin_amdgcn_global_load_lds(mine + 1024 * t, dst + 1024 * t, 16, 0, 0);
+        } else {
+#pragma unroll
+            for (int t = 0; t < G::HLEN / 128; t++) {
+                const int pi = lane + 64 * t;
+                if (64 * t < np)
+                    __builtin_amdgcn_global_load_lds(src + 16 * (pi < np ? pi : np - 1), dst + 1024 * t, 16, 0, 0);
+            }
         }
     };
 
@@ -1797,6 +1845,31 @@ __global__ __launch_bounds__(kBlock, 2) void fir_tile(const FirTileArgs a)
     }
     FIR_STAMP(23);
     /* C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg */
+    if constexpr (LEAN) {
+        /* Inf / NaN among the tile's samples (dspMulFloatDouble reads exponent 255 as 2^128 x 1.m, the matrix pipe as what it is): every
+         * such sample reaches every output of the tile it is under, and Inf x 0 is a NaN, so the sums of a tile that met one are not
+         * finite.  One look; such a tile -- no audio stream has one -- is summed again tap by tap with the reference's operands. */
+        bool odd = false;
+#pragma unroll
+        for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int v = 0; v < 4; v++)
+                odd |= F0 + NR * i16 + 16 * r + 4 * v + k < B && ((unsigned long long)__double_as_longlong(acc[r][v]) >> 52 & 0x7FF) == 0x7FF;
+        if (__builtin_expect(__ballot(odd) != 0, 0)) {
+            const float *ftaps = reinterpret_cast<const float *>(a.buf + c.fir_coef_word);
+            const int Sfrom = SPLIT ? (half ? 4 * Sb - NR : 0) : 0, Sto = SPLIT && !half ? min(T, 4 * S - NR) : T;      /* (the tap split: this wave's taps) */
+#pragma unroll
+            for (int r = 0; r < R; r++)                     /* (unrolled: the sums stay in registers) */
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    const int n = F0 + NR * i16 + 16 * r + 4 * v + k;
+                    double sum = 0.0;
+                    for (int tp = max(Sfrom, 0); tp < Sto; tp++)
+                        sum = __builtin_fma(mulop(ringrow[(a.ring.wpos + n - tp) & rmask]), mulop(ftaps[tp]), sum);
+                    acc[r][v] = sum;
+                }
+        }
+    }
     if constexpr (R >= 2) {
         /* The tiles leave as 16-byte (R = 4) or 8-byte (R = 2) pieces.  A wave's results are one CHANNEL: stored by itself it
          * writes 4 bytes into each of 256 R different 128-byte lines, and with every wave of the chip doing that the L2's request
@@ -2155,7 +2228,7 @@ __global__ __launch_bounds__(kBlock) void fir_plain(const FirArgs a)
     const int T = c.fir_taps, B = a.io.nframes;
     if (c.nsec == 0) fir_append_input<FMT>(a, c, cid);
     const float *taps = reinterpret_cast<const float *>(a.buf + c.fir_coef_word);
-    const float *ringrow = a.ring.base + (size_t)cid * a.ring.R;
+    const float *ringrow = ring_row(a.ring, cid);
     const int rmask = a.ring.R - 1;
     for (int n = threadIdx.x; n < B; n += blockDim.x) {
         double acc = 0.0;
@@ -2189,7 +2262,8 @@ __global__ __launch_bounds__(kBlock) void ring_widen(const RingConvArgs a)
 {
     const int cid = a.group[blockIdx.x];
     const size_t row = (size_t)cid * a.ring.R;
-    for (int i = threadIdx.x; i < a.ring.R; i += blockDim.x) a.ring.wide[row + ((i + 3) & (a.ring.R - 1))] = mulop(a.ring.base[row + i]);
+    const float *src = ring_row(a.ring, cid);
+    for (int i = threadIdx.x; i < a.ring.R; i += blockDim.x) a.ring.wide[row + ((i + 3) & (a.ring.R - 1))] = mulop(src[i]);
 }
 
 /* chains with neither biquads nor FIR: LOAD -> [SAT0DB] -> STORE */
@@ -2958,6 +3032,7 @@ struct avdsp_hip_prog {
     /* cascade of block k+1 under the FIR of block k ("overlap"): the cascades run on a stream of their own */
     int overlap = 0;
     int fir_rows = 0;                    /* fir_tile: row tiles per wave (1, 2, 4), 0 = by the number of chains */
+    int fir_lean = -1;                   /* fir_tile's lean chunk boundary: -1 by the plan (launch_fir), 0 never, 1 always */
     int fir_split = 0;                   /* fir_tile: launches of at most a tile per SIMD cut every tile's taps over two waves (sums within 1e-6, not the reference's bits) */
     hipStream_t s_bq = nullptr;
     hipStream_t s_fir[2] = {nullptr, nullptr};           /* "overlap" 2: the FIRs of consecutive blocks in turn */
@@ -3180,7 +3255,7 @@ extern "C" int avdsp_hip_debug_fir_stamps(unsigned long long *host_out, int max_
 #endif
 
 template <int FMT, int R, bool BIG = false, bool SPLIT = false>
-int launch_fir_tile(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, BlockIO io, hipStream_t stream, ProfileScope &scope, bool wait_ready, hipEvent_t stop = nullptr)
+int launch_fir_tile(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, BlockIO io, hipStream_t stream, ProfileScope &scope, bool wait_ready, hipEvent_t stop = nullptr, bool lean = true)
 {
     FirTileArgs a{};
     a.buf = prog->d_buf; a.chains = pl.d_chains; a.group = ids; a.ngroup = n;
@@ -3196,7 +3271,8 @@ int launch_fir_tile(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, Block
     a.stamps = d_stamps;
     g_fir_stamps = d_stamps; g_fir_stamp_waves = a.per_xcd * 8 * 4;
 #endif
-    return launch_timed(scope, (const void *)fir_tile<FMT, R, BIG, SPLIT>, dim3(a.per_xcd * 8), dim3(kBlock), lds, stream, a, stop);
+    return launch_timed(scope, lean ? (const void *)fir_tile<FMT, R, BIG, SPLIT, true> : (const void *)fir_tile<FMT, R, BIG, SPLIT, false>,
+                        dim3(a.per_xcd * 8), dim3(kBlock), lds, stream, a, stop);
 }
 
 
@@ -3262,11 +3338,16 @@ int launch_fir(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, BlockIO io
             /* one row tile and at most a wave per SIMD (1024): chunks twice as long -- nothing hides a boundary there */
             const long long waves1 = (long long)n * ((io.nframes + 255) / 256);
             /* "fir_split" (opt-in, not the reference's summation order): such a launch with two waves per tile instead */
-            if (rows == 1 && waves1 <= 1024 && prog->fir_split) return launch_fir_tile<FMT, 1, false, true>(prog, pl, ids, n, io, stream, scope, wait_ready, stop);
-            if (rows == 1 && waves1 <= 1024 && prog->fir_rows != 1) return launch_fir_tile<FMT, 1, true>(prog, pl, ids, n, io, stream, scope, wait_ready, stop);
-            return rows == 4 ? launch_fir_tile<FMT, 4>(prog, pl, ids, n, io, stream, scope, wait_ready, stop)
-                 : rows == 2 ? launch_fir_tile<FMT, 2>(prog, pl, ids, n, io, stream, scope, wait_ready, stop)
-                             : launch_fir_tile<FMT, 1>(prog, pl, ids, n, io, stream, scope, wait_ready, stop);
+            /* the lean chunk boundary (fir_tile, LEAN) where it was measured to win (tools/fir_boundary_lab.sh, one box, long / lean):
+             * plans without cascades in front (256 chains x 4096 taps: 40.9 -> 39.4 us per step) and launches of more than one round of
+             * waves (4096 chains: 0.511 -> 0.506 ms).  In between, the next blocks' cascades run beside the FIR and live on the long
+             * boundary's bubbles: 2048 chains 0.259 -> 0.269 ms, 1024 chains 0.147 -> 0.154, 512 chains 0.0876 -> 0.0966. */
+            const bool lean = prog->fir_lean >= 0 ? prog->fir_lean != 0 : (pl.bq.empty() || (long long)pl.n_fir * pl.max_taps >= 12000000ll);
+            if (rows == 1 && waves1 <= 1024 && prog->fir_split) return launch_fir_tile<FMT, 1, false, true>(prog, pl, ids, n, io, stream, scope, wait_ready, stop, lean);
+            if (rows == 1 && waves1 <= 1024 && prog->fir_rows != 1) return launch_fir_tile<FMT, 1, true>(prog, pl, ids, n, io, stream, scope, wait_ready, stop, lean);
+            return rows == 4 ? launch_fir_tile<FMT, 4>(prog, pl, ids, n, io, stream, scope, wait_ready, stop, lean)
+                 : rows == 2 ? launch_fir_tile<FMT, 2>(prog, pl, ids, n, io, stream, scope, wait_ready, stop, lean)
+                             : launch_fir_tile<FMT, 1>(prog, pl, ids, n, io, stream, scope, wait_ready, stop, lean);
         }
         FirArgs a{};
         a.buf = prog->d_buf; a.chains = pl.d_chains; a.group = ids; a.ngroup = n;
@@ -3534,7 +3615,7 @@ int avdsp_hip_prog_add_plan(avdsp_hip_prog *prog, const avdsp_plan_desc *d)
         /* + one more launch of frames: under "overlap" the cascade appends block k+1 while the FIR still reads block k's window */
         pl.ring_R = pow2ceil(pl.max_taps + avdsp_hip_prog::kAhead * kFirChunk + 16 * pl.fir_gpc + 16 * (kNG + 4) + 64);
         static_assert(kFirChunk == kFirPad, "one FIR launch covers exactly the frames the window image is laid out for");
-        hipError_t e = hipMalloc((void **)&pl.d_ring, (size_t)d->nchains * pl.ring_R * sizeof(float));
+        hipError_t e = hipMalloc((void **)&pl.d_ring, (size_t)d->nchains * 2 * pl.ring_R * sizeof(float));      /* (every sample twice: Ring) */
         if (e != hipSuccess) { free_plan(pl); return set_err("hipMalloc(FIR rings, %d x %d): %s", d->nchains, pl.ring_R, hipGetErrorString(e)); }
         pl.wpos = 0;
         for (int i = 0; i < d->nchains; i++) pl.n_fir_only += chains[i].fir_taps && !chains[i].nsec;
@@ -3550,9 +3631,19 @@ int avdsp_hip_prog_add_plan(avdsp_hip_prog *prog, const avdsp_plan_desc *d)
         }
         {   /* fir_tile: LDS opt-in per variant, and the taps as doubles */
             {
-                const void *sp = d->format == 4 ? (const void *)fir_tile<4, 1, false, true> : (const void *)fir_tile<6, 1, false, true>;
-                hipError_t e3 = hipFuncSetAttribute(sp, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TileGeom<1>::LDS_DOUBLES * 8 + 64);
-                if (e3 != hipSuccess) { free_plan(pl); return set_err("hipFuncSetAttribute(fir_tile split LDS): %s", hipGetErrorString(e3)); }
+                const bool f4 = d->format == 4;
+                const void *more[6] = { f4 ? (const void *)fir_tile<4, 1, false, true> : (const void *)fir_tile<6, 1, false, true>,
+                                        f4 ? (const void *)fir_tile<4, 1, false, true, false> : (const void *)fir_tile<6, 1, false, true, false>,
+                                        f4 ? (const void *)fir_tile<4, 1, false, false, false> : (const void *)fir_tile<6, 1, false, false, false>,
+                                        f4 ? (const void *)fir_tile<4, 2, false, false, false> : (const void *)fir_tile<6, 2, false, false, false>,
+                                        f4 ? (const void *)fir_tile<4, 4, false, false, false> : (const void *)fir_tile<6, 4, false, false, false>,
+                                        f4 ? (const void *)fir_tile<4, 1, true, false, false> : (const void *)fir_tile<6, 1, true, false, false> };
+                const int mlds[6] = { 4 * TileGeom<1>::LDS_DOUBLES * 8 + 64, 4 * TileGeom<1>::LDS_DOUBLES * 8 + 64, 4 * TileGeom<1>::LDS_DOUBLES * 8 + 64,
+                                      4 * TileGeom<2>::LDS_DOUBLES * 8 + 64, 4 * TileGeom<4>::LDS_DOUBLES * 8 + 64, 4 * TileGeom<1, true>::LDS_DOUBLES * 8 + 64 };
+                for (int v = 0; v < 6; v++) {
+                    hipError_t e3 = hipFuncSetAttribute(more[v], hipFuncAttributeMaxDynamicSharedMemorySize, mlds[v]);
+                    if (e3 != hipSuccess) { free_plan(pl); return set_err("hipFuncSetAttribute(fir_tile LDS): %s", hipGetErrorString(e3)); }
+                }
             }
             const void *tiles[4] = { d->format == 4 ? (const void *)fir_tile<4, 1> : (const void *)fir_tile<6, 1>,
                                      d->format == 4 ? (const void *)fir_tile<4, 2> : (const void *)fir_tile<6, 2>,
@@ -4746,6 +4837,7 @@ int avdsp_hip_prog_set_option(avdsp_hip_prog *prog, int key, int value)
     case AVDSP_OPT_READY_WORDS: prog->ready_words = value != 0; return 0;
     case AVDSP_OPT_LANE_HW: prog->lane_hw = value != 0; return 0;
     case AVDSP_OPT_FIR_SPLIT: prog->fir_split = value != 0; return 0;
+    case AVDSP_OPT_FIR_LEAN: if (value < -1 || value > 1) return set_err("fir_lean: -1 (auto), 0 or 1"); prog->fir_lean = value; return 0;
     case AVDSP_OPT_FIR_LAUNCH: if (value < -1 || value > 2) return set_err("fir_launch: -1 (auto), 0, 1 or 2"); prog->fir_launch_mode = value; return 0;
     case AVDSP_OPT_FIR_ROWS: if (value != 0 && value != 1 && value != 2 && value != 4) return set_err("fir_tile row tiles: 0 (auto), 1, 2 or 4");
                              prog->fir_rows = value; return 0;

@@ -17,6 +17,7 @@ def _release():
     yield
     rt.lib().dspRuntimeSetOption(b"fir_rows", 0)
     rt.lib().dspRuntimeSetOption(b"fir_split", 0)
+    rt.lib().dspRuntimeSetOption(b"fir_lean", -1)
     rt.lib().dspRuntimeRelease()
 
 
@@ -24,11 +25,13 @@ def words(a):
     return np.ascontiguousarray(a).view(np.uint32)
 
 
-def run_vs_oracle(fmt, prog, x, C, blocks, rows, fir_impl=1):
+def run_vs_oracle(fmt, prog, x, C, blocks, rows, fir_impl=1, fir_lean=None):
     o = po.OracleProgram(fmt, prog)
     r = rt.Runtime(fmt, prog)
     r.set_option("fir_impl", fir_impl)
     r.set_option("fir_rows", rows)
+    if fir_lean is not None:
+        r.set_option("fir_lean", fir_lean)
     pos = 0
     for b in blocks:
         want = o.run_block(x[pos:pos + b], C, C)
@@ -172,3 +175,21 @@ def test_opt_in_tap_split_is_within_the_stated_tolerance(fmt, C, S, T):
     r = rt.Runtime(fmt, prog)
     got = np.concatenate([r.run_block(x[p:p + b], C, C) for p, b in zip(np.cumsum([0] + blocks[:-1]), blocks)])
     assert (words(got) == words(want)).all()
+
+
+@pytest.mark.parametrize("fir_lean", [0, 1])
+@pytest.mark.parametrize("rows", ROWS)
+@pytest.mark.parametrize("fmt,C,S,T", [(6, 5, 0, 641), (6, 7, 3, 2048), (4, 6, 2, 4100), (6, 3, 0, 4096)])
+def test_both_chunk_boundaries_every_row_count(rows, fmt, C, S, T, fir_lean):
+    """fir_tile's long chunk boundary (a masked offset and a class look per window sample) and the lean one (one masked offset per
+    lane and chunk into a ring that holds every sample twice; Inf / NaN found in the tile's sums at the end), forced either way
+    ("fir_lean" 0 / 1; the library chooses by plan): ragged blocks -- the ring wraps several times --, with Inf, NaN, subnormal and
+    exponent-255 samples in some channels (float samples), against the oracle bit for bit, outputs and state."""
+    prog = pb.synth_program(fmt, C, S, T)
+    blocks = [1024, 1, 37, 1024, 300, 1024, 1024, 513, 1024, 1024, 1024]
+    x = pb.lcg_input(sum(blocks), C, fmt == 6, seed=T + rows)
+    if fmt == 6:
+        xv = x.view(np.uint32)
+        xv[5, 0] = 0x7F800000; xv[1030, 1] = 0xFFC00001; xv[2100, 2] = 0x7F7FFFFF; xv[2101, 2] = 0xFF7FFFFF
+        xv[3000:3004, 1] = 0x00012345; xv[3500, 0] = 0x80000000; xv[4000, C - 1] = 0x7F812345
+    run_vs_oracle(fmt, prog, x, C, blocks, rows, 1, fir_lean)
