@@ -230,9 +230,11 @@ struct Ring {
                          * lane and immediates from there (a masked offset per sample was a third of a chunk boundary's instructions) */
     int    R;
     int    wpos;
-    double *wide;       /* the same ring as the FIR's window operand: mulop(sample), doubles, frame n at (wpos + n + 3) & (R-1); rows of R */
+    double *wide;       /* the same ring as the FIR's window operand: mulop(sample), doubles, frame n at (wpos + n + 3) & (R-1); rows of 2 R
+                         * doubles, every operand twice like the floats (fir_flow copies a chunk's window from one masked start) */
 };
 __device__ __forceinline__ float *ring_row(const Ring &r, int cid) { return r.base + (size_t)cid * 2 * r.R; }
+__device__ __forceinline__ double *wide_row(const Ring &r, int cid) { return r.wide + (size_t)cid * 2 * r.R; }
 __device__ __forceinline__ float *ring_at(const Ring &r, int cid, int q)
 {
     return ring_row(r, cid) + ((r.wpos + q) & (r.R - 1));
@@ -244,18 +246,20 @@ __device__ __forceinline__ float *ring_at(const Ring &r, int cid, int q)
  * the plain way (a write-through store drops its line from the L2: the FIR-only chains' own appends are read back at once). */
 __device__ __forceinline__ void ring_put(const Ring &r, int cid, int q, unsigned bits, bool wt = false)
 {
-    const size_t row = (size_t)cid * r.R;
     float *at = ring_at(r, cid, q);
+    double *wat = r.wide ? wide_row(r, cid) + ((r.wpos + q + 3) & (r.R - 1)) : nullptr;
     if (wt) {
         __hip_atomic_store(reinterpret_cast<unsigned *>(at), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(reinterpret_cast<unsigned *>(at + r.R), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (r.wide)
-            __hip_atomic_store(reinterpret_cast<unsigned long long *>(r.wide) + row + ((r.wpos + q + 3) & (r.R - 1)),
-                               (unsigned long long)__double_as_longlong(mulop(__uint_as_float(bits))), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (wat) {
+            const unsigned long long w = (unsigned long long)__double_as_longlong(mulop(__uint_as_float(bits)));
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(wat), w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(wat + r.R), w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         return;
     }
     at[0] = __uint_as_float(bits); at[r.R] = __uint_as_float(bits);
-    if (r.wide) r.wide[row + ((r.wpos + q + 3) & (r.R - 1))] = mulop(__uint_as_float(bits));
+    if (wat) { const double w = mulop(__uint_as_float(bits)); wat[0] = w; wat[r.R] = w; }
 }
 
 /* Cascade -> FIR inside the device, without an event between two queues ("ready words"): the cascade of launch n
@@ -696,7 +700,7 @@ __global__ __launch_bounds__(kBlock) void biquad_pipe(const BiquadArgs a)
         const unsigned rmask = (unsigned)ring_l.R - 1u;
         unsigned ridx = ((unsigned)(ring_l.wpos + n0)) & rmask;
         float *rrow = ring_row(ring_l, ocid);
-        double *wrow = ring_l.wide ? ring_l.wide + (size_t)ocid * ring_l.R : nullptr;
+        double *wrow = ring_l.wide ? wide_row(ring_l, ocid) : nullptr;
         unsigned *out_run = io_l.out + (size_t)n0 * io_l.out_stride + (oc.out_io[0] - io_l.out_base);
         const bool more_stores = owner && !to_ring && oc.n_out > 1;
         const bool wt = a.ready != nullptr;
@@ -713,11 +717,14 @@ __global__ __launch_bounds__(kBlock) void biquad_pipe(const BiquadArgs a)
                     if (wt) {                             /* (write-through, like ring_put) */
                         __hip_atomic_store(reinterpret_cast<unsigned *>(rrow) + ridx, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         __hip_atomic_store(reinterpret_cast<unsigned *>(rrow) + ridx + (rmask + 1u), w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (wrow) __hip_atomic_store(reinterpret_cast<unsigned long long *>(wrow) + ((ridx + 3u) & rmask),
-                                                     (unsigned long long)__double_as_longlong(mulop(__uint_as_float(w))), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (wrow) {
+                            const unsigned long long wd = (unsigned long long)__double_as_longlong(mulop(__uint_as_float(w)));
+                            __hip_atomic_store(reinterpret_cast<unsigned long long *>(wrow) + ((ridx + 3u) & rmask), wd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(reinterpret_cast<unsigned long long *>(wrow) + ((ridx + 3u) & rmask) + (rmask + 1u), wd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
                     } else {
                         rrow[ridx] = __uint_as_float(w); rrow[ridx + (rmask + 1u)] = __uint_as_float(w);
-                        if (wrow) wrow[(ridx + 3u) & rmask] = mulop(__uint_as_float(w));
+                        if (wrow) { const double wd = mulop(__uint_as_float(w)); wrow[(ridx + 3u) & rmask] = wd; wrow[((ridx + 3u) & rmask) + (rmask + 1u)] = wd; }
                     }
                 } else {
                     const unsigned w = flush_word(false);
@@ -895,11 +902,14 @@ __global__ __launch_bounds__(kBlock) void biquad_row(const BiquadArgs a)
     };
     /* steady batches of chains that store once (or feed a FIR ring without the operand copy): a running 32-bit byte offset from a
      * per-lane base -- the ring row, wrapping, or the output column, advancing by 16 frames -- one store, nothing to decide */
-    const bool lean = __ballot(have_chain && (rr.flags >> 16 & 0xFF) != 1 && !to_ring) == 0 && ring_l.wide == nullptr;
+    const bool lean = __ballot(have_chain && (rr.flags >> 16 & 0xFF) != 1 && !to_ring) == 0;
     char *obase = to_ring ? reinterpret_cast<char *>(ring_row(ring_l, cid))
                           : reinterpret_cast<char *>(io_l.out + (rr.out_io - io_l.out_base));
     const bool any_ring = __ballot(have_chain && to_ring) != 0;      /* (wave-uniform: the second copy of a ring sample, R floats on) */
     const unsigned omirror = to_ring ? (unsigned)ring_l.R * 4u : 0u;
+    /* ... and the operand ring, where the plan keeps one (fir_stream / fir_flow): mulop(sample) as a double at (position + 3) mod R, twice */
+    const bool any_wide = any_ring && ring_l.wide != nullptr;
+    char *wbase = any_wide && to_ring ? reinterpret_cast<char *>(wide_row(ring_l, cid)) : nullptr;
     const unsigned oinc = to_ring ? 64u : 64u * (unsigned)io_l.out_stride;
     const unsigned owrap = to_ring ? (unsigned)ring_l.R * 4u - 1u : 0xFFFFFFFFu;
     const bool dosat = FMT == 6 && c_sat && !to_ring;
@@ -914,6 +924,17 @@ __global__ __launch_bounds__(kBlock) void biquad_row(const BiquadArgs a)
             } else {
                 *reinterpret_cast<unsigned *>(obase + ooff) = v;
                 if (any_ring) *reinterpret_cast<unsigned *>(obase + ooff + omirror) = v;
+            }
+            if (any_wide && wbase) {
+                const unsigned woff8 = ((ooff + 12u) & owrap) * 2u;          /* (frame position + 3) mod R, in doubles */
+                const double wd = mulop(__uint_as_float(v));
+                if (wt) {
+                    __hip_atomic_store(reinterpret_cast<unsigned long long *>(wbase + woff8), (unsigned long long)__double_as_longlong(wd), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(reinterpret_cast<unsigned long long *>(wbase + woff8 + 2u * omirror), (unsigned long long)__double_as_longlong(wd), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    *reinterpret_cast<double *>(wbase + woff8) = wd;
+                    *reinterpret_cast<double *>(wbase + woff8 + 2u * omirror) = wd;
+                }
             }
         }
         ooff = (ooff + oinc) & owrap;
@@ -1759,25 +1780,44 @@ __global__ __launch_bounds__(kBlock, 2) void fir_tile(const FirTileArgs a)
      * until the image is read a chunk later.  (Through registers the copy stood in the way: requested at the boundary, its memory
      * latency was 3000 of a boundary's 4000 cycles, a fifth of a wave's life -- tools/fir_timeline.py; requested a chunk ahead, the
      * 24-36 registers it held slowed the k-step loop by more than that.) */
-    auto taps_dma = [&](double *hdst, int s0, int ckc) {
-        const char *src = reinterpret_cast<const char *>(hbuf + (kTapsLead - 16) - 16 * (R - 1) + 4 * s0);
+    /* The copy instruction is written by name: the lane's source = a SCALAR base + the lane's 32-bit offset, the destination's LDS
+     * address in M0 from a scalar.  The compiler's own form (__builtin_amdgcn_global_load_lds) costs more than its address arithmetic:
+     * it books the instruction as a FLAT access that may touch LDS, and while one is in flight -- here: all through the k-steps, by
+     * design -- every wait for an LDS read becomes lgkmcnt(0), i.e. a k-step waits for the reads it has just issued instead of
+     * those of two steps ago (six such waits per 16 k-steps; 66.2 cycles per MFMA at four row tiles where the pipe takes 64).
+     * (M0 is the compiler's: saved and restored inside the statement.  These loads are not in the compiler's vmcnt arithmetic, which
+     * only makes its own waits wait for more; the wait for a taps image is written out at the head of a chunk.) */
+    auto dma16 = [&](const char *sbase, unsigned voff, unsigned lds_addr) __attribute__((always_inline)) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %[k], m0\n\t"
+                     "s_mov_b32 m0, %[d]\n\t"
+                     "s_nop 0\n\t"
+                     "global_load_lds_dwordx4 %[v], %[s]\n\t"
+                     "s_mov_b32 m0, %[k]"
+                     : [k] "=&s"(keep) : [v] "v"(voff), [s] "s"(sbase), [d] "s"(lds_addr) : "memory");
+    };
+    const unsigned hs_addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char *)hs);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    auto taps_dma = [&](int which, int s0, int ckc) {
+        const unsigned long long sv = reinterpret_cast<unsigned long long>(hbuf + (kTapsLead - 16) - 16 * (R - 1) + 4 * s0);
+        const char *src = reinterpret_cast<const char *>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(sv >> 32)) << 32) |
+                                                         (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)sv));    /* (the same in every lane: say so; the builtin returns int) */
         const int np = (4 * ckc + 16 * (R - 1) + 28) / 2;          /* 16-byte pieces the chunk needs; lanes beyond re-read the last one */
-        __attribute__((address_space(3))) char *dst = (__attribute__((address_space(3))) char *)hdst;
-        /* (whole 1-KiB pieces: what the last one reads beyond the chunk's need lies inside the row's own zero tail -- kTapsTail covers
-         * HLEN - HNEED < 128 doubles -- and lands behind the part of the image that is read) */
-        if constexpr (LEAN) {
-            const char *mine = src + 16 * lane;
+        const unsigned dst = hs_addr + (unsigned)which * (unsigned)(G::HLEN * 8);
+        /* (LEAN, whole 1-KiB pieces: what the last one reads beyond the chunk's need lies inside the row's own zero tail -- kTapsTail
+         * covers HLEN - HNEED < 128 doubles -- and lands behind the part of the image that is read) */
 #pragma unroll
-            for (int t = 0; t < G::HLEN / 128; t++)
-                if (64 * t < np) __builtin_amdgcn_global_load_lds(mine + 1024 * t, dst + 1024 * t, 16, 0, 0);
-        } else {
-#pragma unroll
-            for (int t = 0; t < G::HLEN / 128; t++) {
-                const int pi = lane + 64 * t;
-                if (64 * t < np)
-                    __builtin_amdgcn_global_load_lds(src + 16 * (pi < np ? pi : np - 1), dst + 1024 * t, 16, 0, 0);
+        for (int t = 0; t < G::HLEN / 128; t++)
+            if (64 * t < np) {
+                if constexpr (LEAN) dma16(src + 1024 * t, lane16, dst + 1024u * t);
+                else {
+                    /* the long boundary keeps the compiler's form ON PURPOSE: it is the one chosen where a cascade of the next block runs
+                     * beside this launch (launch_fir), and that cascade lives on the bubbles the conservative waits leave (DESIGN.md 5b:
+                     * with the waits exact a 512-chain shard's step goes 0.0870 -> 0.0983 ms, a 2048-chain one 0.2602 -> 0.2733) */
+                    const int pi = lane + 64 * t;
+                    __builtin_amdgcn_global_load_lds(src + 16 * (pi < np ? pi : np - 1), (__attribute__((address_space(3))) char *)(hs + which * G::HLEN) + 1024 * t, 16, 0, 0);
+                }
             }
-        }
     };
 
     double q[16], bq[4];
@@ -1816,7 +1856,7 @@ __global__ __launch_bounds__(kBlock, 2) void fir_tile(const FirTileArgs a)
      * (Tried and dropped, measured slower: a second WINDOW image filled in slices between the MFMAs -- the slices' address
      * arithmetic and conversions cost the f64 matrix pipe more than the stop they replace, 83 -> 95 us on a 512-chain shard.) */
     win_fetch(Sb, min(ck, S - Sb));
-    taps_dma(hs, Sb, min(ck, S - Sb));
+    taps_dma(0, Sb, min(ck, S - Sb));
     [[maybe_unused]] int stamp_i = 1;
     int cur = 0;
     for (int s0 = Sb; s0 < S; s0 += ck, cur ^= 1) {
@@ -1833,7 +1873,7 @@ __global__ __launch_bounds__(kBlock, 2) void fir_tile(const FirTileArgs a)
         if (s0 + ckc < S) {
             win_fetch(s0 + ckc, min(ck, S - s0 - ckc));
             if (s0 == Sb + ck) FIR_STAMP(26);
-            taps_dma(hs + (cur ^ 1) * G::HLEN, s0 + ckc, min(ck, S - s0 - ckc));
+            taps_dma(cur ^ 1, s0 + ckc, min(ck, S - s0 - ckc));
         }
         if (s0 == Sb + ck) FIR_STAMP(27);
         const double *hp = hs + cur * G::HLEN + k + i16;                       /* oldest operand of step sc at hp[4 sc] */
@@ -2051,7 +2091,7 @@ __global__ __launch_bounds__(kStreamBlock, 1) void fir_stream(const FirTileArgs 
         const int nch = (d.S + G::CK - 1) / G::CK;
         d.ck = (((d.S + nch - 1) / nch) + 15) & ~15;
         d.hbuf = a.taps64 + (size_t)d.cid * a.pitch64;
-        d.ring8 = reinterpret_cast<const char *>(a.ring.wide + (size_t)d.cid * a.ring.R);
+        d.ring8 = reinterpret_cast<const char *>(wide_row(a.ring, d.cid));
         return d;
     };
     /* (bounded: the partner wave is resident in the same workgroup and always gets there; should that ever not hold, the grid
@@ -2184,6 +2224,263 @@ __global__ __launch_bounds__(kStreamBlock, 1) void fir_stream(const FirTileArgs 
     FIR_STAMP(30); FIR_REALTIME(28);
 }
 
+/* ------------------------------------------------------------------------------------------
+ * fir_flow<FMT, R> (round 4): fir_tile's launch -- one wave per (chain, tile), two waves per SIMD, nothing shared between waves, the
+ * workgroup's tiles leaving together -- with fir_stream's operands: the window comes READY-MADE from the operand ring (every writer
+ * of a ring leaves mulop(sample) there as a double, twice, R apart), so a chunk's window image is a copy like its taps image, both by
+ * LDS-DMA, and a chunk boundary has NO vector instruction in it: the copy instructions take their lane's source from a register
+ * computed once per wave and a scalar base, the rest is scalar arithmetic and a wait.
+ *
+ * Why that matters: while one wave of a SIMD streams MFMAs the other gets a VECTOR instruction in only every few hundred cycles (they
+ * share the FP64 datapath), so fir_tile's boundary -- 140 vector instructions, 50 in its lean form -- lasts about as long as the
+ * partner's chunk: the two waves take strict turns, the pipe runs one wave's dependent stream at a time (66 cycles per MFMA at four
+ * row tiles, 72 at one) and idles for what is left of a boundary when the partner's chunk ends.  Scalar instructions, LDS-DMA
+ * requests and waits are not held up by the partner's stream: this boundary is the copy's latency, under which the partner streams
+ * alone, and the rest of the time BOTH waves stream (64.5 cycles per MFMA, r01's microbench).
+ * The window image is single (the copy for chunk n + 1 is requested when chunk n's last k-step has read it: its latency is the
+ * boundary), the taps images are two (requested a chunk ahead, as in fir_tile).  Same tile, same operand order, same accumulators as
+ * fir_tile and fir_stream: bit-exact for the same reason, Inf / NaN included (the operand ring holds mulop(sample)).
+ * ---------------------------------------------------------------------------------------- */
+template <int R> struct FlowGeom {
+    static constexpr int NR = 16 * R;
+    static constexpr int FW = 256 * R;
+    static constexpr int WPC = 4 / R;
+    static constexpr int QD = 4 * (R - 1);
+    static constexpr int PD = R == 4 ? 2 : 4;
+    static constexpr int CK = R == 4 ? 96 : R == 2 ? 128 : 144;       /* k-steps per chunk: what leaves a CU's LDS to eight waves */
+    static constexpr int UB = NR / 2 + 1;
+    static constexpr int UP = R == 4 ? 64 : UB * (64 / UB);
+    static constexpr int MAGIC = (65536 + UB - 1) / UB;
+    static constexpr int GS = 64 + 128 / NR;
+    static constexpr int C60 = (60 + NR - 1) / NR;
+    static constexpr int LOW = 60 + 2 * C60;
+    __host__ __device__ static constexpr int wunits(int ckc) { return UB * (15 + 4 * ckc / NR) + 2; }
+    __host__ __device__ static constexpr int wpieces(int ckc) { return (wunits(ckc) - 64 + UP - 1) / UP + 1; }
+    __host__ __device__ static constexpr int hpieces(int ckc) { return (4 * ckc + 16 * (R - 1) + 28 + 4 * PD + 127) / 128; }
+    static constexpr int WLEN = ((wpieces(CK) - 1) * UP + 64) * 2;
+    static constexpr int HLEN = hpieces(CK) * 128;
+    static constexpr int LDS_DOUBLES = 2 * HLEN + WLEN;              /* per wave: two taps images, ONE window image */
+    __host__ __device__ static constexpr int woff(int j) { return 4 * (15 - j) + 2 * (C60 - (4 * j + NR - 1) / NR); }
+};
+static_assert(8 * FlowGeom<4>::LDS_DOUBLES * 8 + 128 <= 160 * 1024 && 8 * FlowGeom<2>::LDS_DOUBLES * 8 + 128 <= 160 * 1024 &&
+              8 * FlowGeom<1>::LDS_DOUBLES * 8 + 128 <= 160 * 1024, "fir_flow: a CU's LDS holds eight waves");
+static_assert(FlowGeom<4>::wpieces(FlowGeom<4>::CK) * 64 < 1985, "fir_flow: the unit-to-block division by multiplication");
+
+template <int FMT, int R>
+__global__ __launch_bounds__(kBlock, 2) void fir_flow(const FirTileArgs a)
+{
+    using G = FlowGeom<R>;
+    constexpr int NR = G::NR, PD = G::PD;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      /* (scalar: the copies' bases and M0 come from it) */
+    const int B = a.io.nframes;
+    const int blk = xcd_remap(blockIdx.x, a.per_xcd);
+    {   /* FIR-only chains: their input is appended first (fir_tile) */
+        FirArgs fa{};
+        fa.ring = a.ring; fa.io = a.io;
+        for (int q = 0; q < 4 / G::WPC; q++) {
+            const int sl = blk * (4 / G::WPC) + q;
+            if (sl < a.ngroup) {
+                const int ci = a.group[sl];
+                const avdsp_chain cc = a.chains[ci];
+                if (cc.nsec == 0) fir_append_input<FMT>(fa, cc, ci);
+            }
+        }
+        __syncthreads();
+    }
+    const int unit = blk * 4 + wv;
+    const int slot = unit / G::WPC, F0 = (unit % G::WPC) * G::FW;
+    [[maybe_unused]] int *xchg = reinterpret_cast<int *>(lds + (size_t)4 * G::LDS_DOUBLES);
+    [[maybe_unused]] const int stamp_row = wv;
+    FIR_STAMP(0); FIR_REALTIME(29);
+#ifdef AVDSP_FIR_STAMPS
+    if (lane == 0) a.stamps[(size_t)(blockIdx.x * 4 + wv) * 32 + 31] = ((unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) << 32) |
+                                                                        (unsigned long long)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 15);
+#endif
+    if (slot >= a.ngroup || F0 >= B) {
+        if constexpr (R >= 2) {
+            if (lane == 0) xchg[wv] = -1;
+            __syncthreads();
+        }
+        return;
+    }
+    const int cid = __builtin_amdgcn_readfirstlane(a.group[slot]);
+    const avdsp_chain c = a.chains[cid];
+    const int T = __builtin_amdgcn_readfirstlane(c.fir_taps);
+    if (a.ready && c.nsec) chain_ready_wait(a.ready, cid, a.seq, a.timeouts);
+    double *hs = lds + (size_t)wv * G::LDS_DOUBLES, *ws = hs + 2 * G::HLEN;
+    const double *hbuf = a.taps64 + (size_t)cid * a.pitch64;
+    const char *ring8 = reinterpret_cast<const char *>(wide_row(a.ring, cid));
+    const unsigned rmask8 = (unsigned)(a.ring.R - 1) << 3;
+    const int i16 = lane & 15, k = lane >> 4;
+    const int S = (((T + NR + 3) >> 2) + 15) & ~15;
+    const int nch = (S + G::CK - 1) / G::CK;
+    const int ck = (((S + nch - 1) / nch) + 15) & ~15;
+
+    /* the copies: image unit U = lane + 64 p (16 bytes) <- ring doubles glo + 2 (U - U / UB) and the next; the lane's part of that is a
+     * register made once (R = 4: one per piece), the chunk's part a scalar -- and since the ring holds every operand twice, R apart, the
+     * masked start may simply be run on from */
+    constexpr int WPMAX = G::wpieces(G::CK);
+    unsigned rel8[R == 4 ? WPMAX : 1];
+    if constexpr (R == 4) {
+#pragma unroll
+        for (int p = 0; p < WPMAX; p++) {
+            const unsigned U = (unsigned)lane + 64u * (unsigned)p;
+            rel8[p] = (2u * (U - ((U * (unsigned)G::MAGIC) >> 16))) << 3;
+        }
+    } else
+        rel8[0] = (2u * ((unsigned)lane - (unsigned)lane / (unsigned)G::UB)) << 3;
+    const unsigned lane16 = (unsigned)lane * 16u;
+    /* One copy instruction, written by name: the lane's source = a SCALAR base + the lane's 32-bit offset (no vector add), the
+     * destination's LDS address in M0 from a scalar (the compiler's own form reads it back out of a vector register for every piece).
+     * (M0 is the compiler's: saved and restored inside the statement.  The loads are not in the compiler's count: the s_waitcnt at the
+     * head of a chunk is written out.) */
+    auto dma16 = [&](const char *sbase, unsigned voff, unsigned lds_addr) __attribute__((always_inline)) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %[k], m0\n\t"
+                     "s_mov_b32 m0, %[d]\n\t"
+                     "s_nop 0\n\t"
+                     "global_load_lds_dwordx4 %[v], %[s]\n\t"
+                     "s_mov_b32 m0, %[k]"
+                     : [k] "=&s"(keep) : [v] "v"(voff), [s] "s"(sbase), [d] "s"(lds_addr) : "memory");
+    };
+    const unsigned ws_addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char *)ws);
+    const unsigned hs_addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char *)hs);
+    auto window_dma = [&](int s0, int ckc) {
+        const int npw = G::wpieces(ckc);
+        const unsigned g08 = ((unsigned)(a.ring.wpos + F0 + NR - 4 * (s0 + ckc)) << 3) & rmask8;       /* ring byte of image unit 0: scalar */
+        const char *base = ring8 + g08;
+#pragma unroll
+        for (int p = 0; p < WPMAX; p++)
+            if (p < npw) {
+                if constexpr (R == 4) dma16(base, rel8[p], ws_addr + 16u * G::UP * p);
+                else dma16(base + 8 * NR * (64 / G::UB) * p, rel8[0], ws_addr + 16u * G::UP * p);
+            }
+    };
+    auto taps_dma = [&](int which, int s0, int ckc) {
+        const int nph = G::hpieces(ckc);
+        const char *src = reinterpret_cast<const char *>(hbuf + (kTapsLead - 16) - 16 * (R - 1) + 4 * s0);
+#pragma unroll
+        for (int t = 0; t < G::hpieces(G::CK); t++)
+            if (t < nph) dma16(src + 1024 * t, lane16, hs_addr + (unsigned)which * (G::HLEN * 8u) + 1024u * t);
+    };
+
+    v4f64 acc[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = v4f64{0.0, 0.0, 0.0, 0.0};
+    double q[16], bq[8];
+    auto chunk_begin = [&](const double *hp, const double *wg) {
+#pragma unroll
+        for (int j = 0; j < G::QD; j++) q[(16 - G::QD + j) & 15] = hp[4 * j];
+#pragma unroll
+        for (int j = 0; j < PD; j++) { q[j] = hp[16 * (R - 1) + 4 * j]; bq[j] = wg[G::woff(j)]; }
+    };
+    auto kstep = [&](const double *hg, const double *wg, auto jc) {
+        constexpr int j = decltype(jc)::value;
+        q[(j + PD) & 15] = hg[4 * (j + PD)];
+        bq[(j + PD) & 7] = j + PD < 16 ? wg[G::woff((j + PD) & 15)] : (wg - G::GS)[G::woff((j + PD) & 15)];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            acc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(q[(j - 4 * (R - 1 - r)) & 15], bq[j & 7], acc[r], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    window_dma(0, min(ck, S));
+    taps_dma(0, 0, min(ck, S));
+    int n = 0;
+    [[maybe_unused]] int stamp_i = 1;
+    for (int s0 = 0; s0 < S; s0 += ck, n++) {
+        const int ckc = min(ck, S - s0);
+        FIR_STAMP_CHUNK();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    /* this chunk's window (requested at the boundary) and taps (a chunk ago) have landed */
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (s0 + ckc < S) taps_dma((n + 1) & 1, s0 + ckc, min(ck, S - s0 - ckc));      /* (lands under this chunk's k-steps) */
+        const double *hp = hs + (n & 1) * G::HLEN + k + i16;
+        const double *wg = ws + (NR + 2) * i16 + 3 - k - G::LOW + (ckc / 16) * G::GS;
+        chunk_begin(hp, wg);
+        FIR_STAMP_CHUNK();
+        for (int g = 0; g < ckc / 16; g++) {
+            const double *hg = hp + 16 * (R - 1) + 64 * g, *wgg = wg - g * G::GS;
+            kstep(hg, wgg, std::integral_constant<int, 0>{});  kstep(hg, wgg, std::integral_constant<int, 1>{});
+            kstep(hg, wgg, std::integral_constant<int, 2>{});  kstep(hg, wgg, std::integral_constant<int, 3>{});
+            kstep(hg, wgg, std::integral_constant<int, 4>{});  kstep(hg, wgg, std::integral_constant<int, 5>{});
+            kstep(hg, wgg, std::integral_constant<int, 6>{});  kstep(hg, wgg, std::integral_constant<int, 7>{});
+            kstep(hg, wgg, std::integral_constant<int, 8>{});  kstep(hg, wgg, std::integral_constant<int, 9>{});
+            kstep(hg, wgg, std::integral_constant<int, 10>{}); kstep(hg, wgg, std::integral_constant<int, 11>{});
+            kstep(hg, wgg, std::integral_constant<int, 12>{}); kstep(hg, wgg, std::integral_constant<int, 13>{});
+            kstep(hg, wgg, std::integral_constant<int, 14>{}); kstep(hg, wgg, std::integral_constant<int, 15>{});
+        }
+        /* the boundary: every read of the window image has been used (an MFMA waits for its operands); the next window may land */
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        FIR_STAMP_CHUNK();
+        if (s0 + ckc < S) window_dma(s0 + ckc, min(ck, S - s0 - ckc));
+    }
+    FIR_STAMP(23);
+    /* the tile leaves as in fir_tile (C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg) */
+    if constexpr (R >= 2) {
+        constexpr int CH = R, WPC = G::WPC;
+        unsigned *mine = reinterpret_cast<unsigned *>(hs);
+        unsigned w16[4 * R];
+#pragma unroll
+        for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                unsigned word = store_stage<FMT>(acc[r][v], c.sat, a.io.store_mask);
+                if constexpr (FMT == 6) word = ftz_bits(word);
+                w16[4 * r + v] = word;
+                mine[(NR + 1) * i16 + 16 * r + 4 * v + k] = word;
+            }
+        if (lane == 0) xchg[wv] = c.n_out == 1 ? c.out_io[0] : -1;
+        __syncthreads();
+        const int o0 = xchg[0];
+        bool together = o0 >= 0 && ((o0 - a.io.out_base) & (CH - 1)) == 0 && (a.io.out_stride & (CH - 1)) == 0 &&
+                        (reinterpret_cast<size_t>(a.io.out) & (4 * CH - 1)) == 0;
+#pragma unroll
+        for (int w = 1; w < 4; w++) together = together && xchg[w] == o0 + w / WPC;
+        if (together) {
+            const unsigned *reg = reinterpret_cast<const unsigned *>(lds);
+#pragma unroll
+            for (int qf = 0; qf < 4; qf++) {
+                const int f = (int)threadIdx.x + 256 * qf;
+                if (f < B) {
+                    const int ti = f / G::FW, fl = f - ti * G::FW;
+                    const int at = (NR + 1) * (fl / NR) + fl % NR;
+                    unsigned o[CH];
+#pragma unroll
+                    for (int j = 0; j < CH; j++) o[j] = reg[(size_t)(j * WPC + ti) * (2 * G::LDS_DOUBLES) + at];
+                    unsigned *dst = a.io.out + (size_t)f * a.io.out_stride + (o0 - a.io.out_base);
+                    if constexpr (CH == 4) *reinterpret_cast<uint4 *>(dst) = make_uint4(o[0], o[1], o[2], o[3]);
+                    else *reinterpret_cast<uint2 *>(dst) = make_uint2(o[0], o[1]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; r++)
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    const int nn = F0 + NR * i16 + 16 * r + 4 * v + k;
+                    if (nn < B) emit_out(a.io, c, nn, w16[4 * r + v]);
+                }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const int nn = F0 + NR * i16 + 16 * r + 4 * v + k;
+                if (nn < B) {
+                    unsigned word = store_stage<FMT>(acc[r][v], c.sat, a.io.store_mask);
+                    if constexpr (FMT == 6) word = ftz_bits(word);
+                    emit_out(a.io, c, nn, word);
+                }
+            }
+    }
+    FIR_STAMP(30); FIR_REALTIME(28);
+}
+
 /* FIR-only chains: the FIR's input is (float)X of the load stage; it is appended to the rings before fir_stream starts
  * (consecutive threads take consecutive chains: the reads of the interleaved block coalesce) */
 template <int FMT>
@@ -2261,9 +2558,9 @@ __global__ __launch_bounds__(kBlock) void state_to_ring(const RingConvArgs a)
 __global__ __launch_bounds__(kBlock) void ring_widen(const RingConvArgs a)
 {
     const int cid = a.group[blockIdx.x];
-    const size_t row = (size_t)cid * a.ring.R;
+    double *row = wide_row(a.ring, cid);
     const float *src = ring_row(a.ring, cid);
-    for (int i = threadIdx.x; i < a.ring.R; i += blockDim.x) a.ring.wide[row + ((i + 3) & (a.ring.R - 1))] = mulop(src[i]);
+    for (int i = threadIdx.x; i < a.ring.R; i += blockDim.x) { const double w = mulop(src[i]); row[(i + 3) & (a.ring.R - 1)] = w; row[((i + 3) & (a.ring.R - 1)) + a.ring.R] = w; }
 }
 
 /* chains with neither biquads nor FIR: LOAD -> [SAT0DB] -> STORE */
@@ -3282,7 +3579,7 @@ int launch_fir_stream(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, Blo
     if (!pl.d_ring64) {
         /* first use: the operand ring (8 bytes per ring entry) is made from the float ring; every ring writer keeps it up from here on */
         HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipMalloc((void **)&pl.d_ring64, (size_t)pl.nchains * pl.ring_R * sizeof(double)));
+        HIP_TRY(hipMalloc((void **)&pl.d_ring64, (size_t)pl.nchains * 2 * pl.ring_R * sizeof(double)));      /* (every operand twice: Ring) */
         RingConvArgs ca{prog->d_buf, pl.d_chains, pl.d_fir_ids, pl.n_fir, plan_ring(pl)};
         hipLaunchKernelGGL(ring_widen, dim3(pl.n_fir), dim3(kBlock), 0, stream, ca);
         HIP_TRY(hipGetLastError());
@@ -3312,13 +3609,50 @@ int launch_fir_stream(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, Blo
     return 0;
 }
 
-/* fir_impl: 0 = fir_plain (the reference's loop), 1 = fir_tile (default), 2 = fir_mfma (round 1's workgroup-per-channel kernel) */
+template <int FMT, int R>
+int launch_fir_flow(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, BlockIO io, hipStream_t stream, ProfileScope &scope, bool wait_ready, hipEvent_t stop)
+{
+    if (!pl.d_ring64) {
+        /* first use: the operand ring is made from the float ring; every ring writer keeps it up from here on */
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMalloc((void **)&pl.d_ring64, (size_t)pl.nchains * 2 * pl.ring_R * sizeof(double)));
+        RingConvArgs ca{prog->d_buf, pl.d_chains, pl.d_fir_ids, pl.n_fir, plan_ring(pl)};
+        hipLaunchKernelGGL(ring_widen, dim3(pl.n_fir), dim3(kBlock), 0, stream, ca);
+        HIP_TRY(hipGetLastError());
+    }
+    FirTileArgs a{};
+    a.buf = prog->d_buf; a.chains = pl.d_chains; a.group = ids; a.ngroup = n;
+    a.ring = plan_ring(pl); a.io = io; a.taps64 = pl.d_taps64; a.pitch64 = pl.pitch64;
+    if (wait_ready) { a.ready = pl.d_ready; a.seq = pl.seq; a.timeouts = prog->d_ready_timeouts; }
+    const int nwg = (n * FlowGeom<R>::WPC + 3) / 4;
+    a.per_xcd = (nwg + 7) / 8;
+    const size_t lds = (size_t)4 * FlowGeom<R>::LDS_DOUBLES * sizeof(double) + 64;
+#ifdef AVDSP_FIR_STAMPS
+    static unsigned long long *d_stamps = nullptr;
+    if (!d_stamps) { HIP_TRY(hipMalloc((void **)&d_stamps, (size_t)8192 * 4 * 32 * 8)); }
+    HIP_TRY(hipMemsetAsync(d_stamps, 0, (size_t)8192 * 4 * 32 * 8, stream));
+    a.stamps = d_stamps;
+    g_fir_stamps = d_stamps; g_fir_stamp_waves = a.per_xcd * 8 * 4;
+#endif
+    return launch_timed(scope, (const void *)fir_flow<FMT, R>, dim3(a.per_xcd * 8), dim3(kBlock), lds, stream, a, stop);
+}
+
+/* fir_impl: 0 = fir_plain (the reference's loop), 1 = fir_tile (default), 2 = fir_mfma (round 1's workgroup-per-channel kernel),
+ * 3 = fir_stream, 4 = fir_flow */
 template <int FMT>
 int launch_fir(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, BlockIO io, int fir_impl, hipStream_t stream, bool wait_ready = false, hipEvent_t stop = nullptr)
 {
     if constexpr (FMT == 2) { (void)prog; (void)pl; (void)ids; (void)n; (void)io; (void)fir_impl; (void)stream; (void)wait_ready; (void)stop; return 0; }
     else {
         ProfileScope scope(prog, stream, AVDSP_KERNEL_FIR);
+        if (fir_impl == 4) {
+            int rows = prog->fir_rows;
+            if (rows != 1 && rows != 2 && rows != 4) rows = n >= 2048 ? 4 : n >= 1024 ? 2 : 1;
+            while (rows > 1 && 128 * rows >= io.nframes) rows >>= 1;
+            return rows == 4 ? launch_fir_flow<FMT, 4>(prog, pl, ids, n, io, stream, scope, wait_ready, stop)
+                 : rows == 2 ? launch_fir_flow<FMT, 2>(prog, pl, ids, n, io, stream, scope, wait_ready, stop)
+                             : launch_fir_flow<FMT, 1>(prog, pl, ids, n, io, stream, scope, wait_ready, stop);
+        }
         if (fir_impl != 1) scope.begin();
         if (fir_impl == 3) {
             /* row tiles per wave: as many as leave every SIMD a wave (1024) */
@@ -3429,7 +3763,7 @@ int launch_all(avdsp_hip_prog *prog, Plan &pl, BlockIO io, int fir_impl, int biq
              * packet on another queue's signal -- holds the next dispatch back by ~9 us even when the signal is long down
              * (tools/step_gaps.py: 10.7 us between two FIRs of the 4096-chain program, 1.5-2 us between two kernels of one queue). */
             if (!words) HIP_TRY(hipStreamWaitEvent(stream, prog->ev_bq[slot], 0));
-            const int mode = fir_impl != 1 ? 0 : prog->fir_launch_mode >= 0 ? prog->fir_launch_mode
+            const int mode = fir_impl != 1 && fir_impl != 4 ? 0 : prog->fir_launch_mode >= 0 ? prog->fir_launch_mode
                            : (long long)pl.n_fir * pl.max_taps <= 6000000ll ? 2 : 1;
             /* (a launch whose kernel timer is sampled carries the timer's events instead; its event is then recorded behind it) */
             const bool rides = mode == 1 && !((prog->profile >> AVDSP_KERNEL_FIR & 1u) && prog->profile_seen[AVDSP_KERNEL_FIR & 7] % (unsigned)prog->profile_stride == 0);
@@ -3627,6 +3961,14 @@ int avdsp_hip_prog_add_plan(avdsp_hip_prog *prog, const avdsp_plan_desc *d)
             for (int v = 0; v < 3; v++) {
                 hipError_t e2 = hipFuncSetAttribute(fns[v], hipFuncAttributeMaxDynamicSharedMemorySize, flds[v]);
                 if (e2 != hipSuccess) { free_plan(pl); return set_err("hipFuncSetAttribute(fir_stream LDS %d): %s", flds[v], hipGetErrorString(e2)); }
+            }
+            const void *ffn[3] = { d->format == 4 ? (const void *)fir_flow<4, 1> : (const void *)fir_flow<6, 1>,
+                                   d->format == 4 ? (const void *)fir_flow<4, 2> : (const void *)fir_flow<6, 2>,
+                                   d->format == 4 ? (const void *)fir_flow<4, 4> : (const void *)fir_flow<6, 4> };
+            const int fl[3] = { 4 * FlowGeom<1>::LDS_DOUBLES * 8 + 64, 4 * FlowGeom<2>::LDS_DOUBLES * 8 + 64, 4 * FlowGeom<4>::LDS_DOUBLES * 8 + 64 };
+            for (int v = 0; v < 3; v++) {
+                hipError_t e2 = hipFuncSetAttribute(ffn[v], hipFuncAttributeMaxDynamicSharedMemorySize, fl[v]);
+                if (e2 != hipSuccess) { free_plan(pl); return set_err("hipFuncSetAttribute(fir_flow LDS %d): %s", fl[v], hipGetErrorString(e2)); }
             }
         }
         {   /* fir_tile: LDS opt-in per variant, and the taps as doubles */

@@ -45,7 +45,7 @@ def run_vs_oracle(fmt, prog, x, C, blocks, rows, fir_impl=1, fir_lean=None):
 
 
 ROWS = [1, 2, 4]                 # row tiles per wave
-IMPLS = [3, 1]                   # fir_stream, fir_tile
+IMPLS = [4, 3, 1]                # fir_flow, fir_stream, fir_tile
 
 
 @pytest.mark.parametrize("impl", IMPLS)
@@ -79,7 +79,7 @@ def test_many_channels_auto_rows_and_other_kernels_agree(rows):
     x = pb.lcg_input(1024 + 500, C, True, seed=3)
     o = po.OracleProgram(6, prog)
     want = np.concatenate([o.run_block(x[:1024], C, C), o.run_block(x[1024:], C, C)])
-    for impl in ((3, 1, 2, 0) if rows == 0 else (3, 1)):
+    for impl in ((4, 3, 1, 2, 0) if rows == 0 else (4, 3, 1)):
         r = rt.Runtime(6, prog)
         r.set_option("fir_impl", impl)
         r.set_option("fir_rows", rows)

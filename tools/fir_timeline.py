@@ -65,6 +65,14 @@ for c in range(nch):
     ok = m1 != 0
     stage[ok] += (m0 - b)[ok]; mfma[ok] += (m1 - m0)[ok]
     print(f"  chunk {c}: staging {np.median((m0 - b)[ok]):8.0f} cycles (p90 {np.percentile((m0 - b)[ok], 90):8.0f})   k-steps {np.median((m1 - m0)[ok]):8.0f} cycles (p90 {np.percentile((m1 - m0)[ok], 90):8.0f})")
+if args.fir_impl == 4:
+    for c in range(nch - 1):
+        e, b = st[:, 3 + 3 * c], st[:, 4 + 3 * c]
+        ok = b != 0
+        print(f"  chunk {c} -> {c + 1}: the window copy's requests {np.median((b - e)[ok]):6.0f} cycles (p90 {np.percentile((b - e)[ok], 90):6.0f})")
+    ok = st[:, 23] != 0
+    print("  start -> first chunk's wait %.0f cycles;  epilogue (convert and store the tile) %.0f cycles (p90 %.0f)"
+          % (np.median(st[ok, 1] - st[ok, 0]), np.median(st[ok, 30] - st[ok, 23]), np.percentile(st[ok, 30] - st[ok, 23], 90)))
 if args.fir_impl == 3 and (st[:, 26] != 0).any():
     ok = st[:, 26] != 0
     print("  first unit: start -> unit known %.0f cycles, -> first chunk's operands ready %.0f;  epilogue (convert and store the tile) %.0f cycles"
@@ -73,7 +81,7 @@ if args.fir_impl == 1 and (st[:, 23] != 0).any():
     ok = st[:, 23] != 0
     print("  start -> first chunk's boundary %.0f cycles;  epilogue (convert and store the tile) %.0f cycles (p90 %.0f)"
           % (np.median(st[ok, 1] - st[ok, 0]), np.median(st[ok, 30] - st[ok, 23]), np.percentile(st[ok, 30] - st[ok, 23], 90)))
-if args.fir_impl != 3 and (st[:, 24] != 0).any():
+if args.fir_impl not in (3, 4) and (st[:, 24] != 0).any():
     ok = st[:, 27] != 0
     b = st[ok, 4]                                    # start of chunk 1's boundary
     print("  chunk 1's boundary: requested data landed +%.0f, window image written +%.0f, taps image landed +%.0f, next window requested +%.0f, next taps requested +%.0f, first operands read +%.0f cycles"
