@@ -2241,13 +2241,19 @@ __global__ __launch_bounds__(kStreamBlock, 1) void fir_stream(const FirTileArgs 
  * boundary), the taps images are two (requested a chunk ahead, as in fir_tile).  Same tile, same operand order, same accumulators as
  * fir_tile and fir_stream: bit-exact for the same reason, Inf / NaN included (the operand ring holds mulop(sample)).
  * ---------------------------------------------------------------------------------------- */
-template <int R> struct FlowGeom {
+/* BIG (R = 1 only): launches that leave a SIMD one wave at most (fir_tile's BIG, same rule).  Nothing hides a boundary there, and the
+ * CU's LDS is shared by four waves instead of eight: chunks of up to 224 k-steps and TWO window images, the copy of chunk n + 1's
+ * window requested with its taps at the head of chunk n -- a boundary is then one s_waitcnt that has nothing left to wait for and
+ * the first operand reads. */
+template <int R, bool BIG = false> struct FlowGeom {
+    static_assert(!BIG || R == 1, "long chunks and two window images: one row tile");
     static constexpr int NR = 16 * R;
     static constexpr int FW = 256 * R;
     static constexpr int WPC = 4 / R;
     static constexpr int QD = 4 * (R - 1);
     static constexpr int PD = R == 4 ? 2 : 4;
-    static constexpr int CK = R == 4 ? 96 : R == 2 ? 128 : 144;       /* k-steps per chunk: what leaves a CU's LDS to eight waves */
+    static constexpr int CK = R == 4 ? 96 : R == 2 ? 128 : BIG ? 224 : 144;       /* k-steps per chunk: what leaves a CU's LDS to eight (BIG: four) waves */
+    static constexpr int NWIN = BIG ? 2 : 1;
     static constexpr int UB = NR / 2 + 1;
     static constexpr int UP = R == 4 ? 64 : UB * (64 / UB);
     static constexpr int MAGIC = (65536 + UB - 1) / UB;
@@ -2259,17 +2265,18 @@ template <int R> struct FlowGeom {
     __host__ __device__ static constexpr int hpieces(int ckc) { return (4 * ckc + 16 * (R - 1) + 28 + 4 * PD + 127) / 128; }
     static constexpr int WLEN = ((wpieces(CK) - 1) * UP + 64) * 2;
     static constexpr int HLEN = hpieces(CK) * 128;
-    static constexpr int LDS_DOUBLES = 2 * HLEN + WLEN;              /* per wave: two taps images, ONE window image */
+    static constexpr int LDS_DOUBLES = 2 * HLEN + NWIN * WLEN;       /* per wave: two taps images, one window image (BIG: two) */
     __host__ __device__ static constexpr int woff(int j) { return 4 * (15 - j) + 2 * (C60 - (4 * j + NR - 1) / NR); }
 };
 static_assert(8 * FlowGeom<4>::LDS_DOUBLES * 8 + 128 <= 160 * 1024 && 8 * FlowGeom<2>::LDS_DOUBLES * 8 + 128 <= 160 * 1024 &&
               8 * FlowGeom<1>::LDS_DOUBLES * 8 + 128 <= 160 * 1024, "fir_flow: a CU's LDS holds eight waves");
+static_assert(4 * FlowGeom<1, true>::LDS_DOUBLES * 8 + 128 <= 160 * 1024, "fir_flow, long chunks: a CU's LDS holds four waves");
 static_assert(FlowGeom<4>::wpieces(FlowGeom<4>::CK) * 64 < 1985, "fir_flow: the unit-to-block division by multiplication");
 
-template <int FMT, int R>
-__global__ __launch_bounds__(kBlock, 2) void fir_flow(const FirTileArgs a)
+template <int FMT, int R, bool BIG = false>
+__global__ __launch_bounds__(kBlock, BIG ? 1 : 2) void fir_flow(const FirTileArgs a)
 {
-    using G = FlowGeom<R>;
+    using G = FlowGeom<R, BIG>;
     constexpr int NR = G::NR, PD = G::PD;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      /* (scalar: the copies' bases and M0 come from it) */
@@ -2346,15 +2353,16 @@ __global__ __launch_bounds__(kBlock, 2) void fir_flow(const FirTileArgs a)
     };
     const unsigned ws_addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char *)ws);
     const unsigned hs_addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char *)hs);
-    auto window_dma = [&](int s0, int ckc) {
+    auto window_dma = [&](int which, int s0, int ckc) {
         const int npw = G::wpieces(ckc);
+        const unsigned wdst = ws_addr + (unsigned)which * (G::WLEN * 8u);
         const unsigned g08 = ((unsigned)(a.ring.wpos + F0 + NR - 4 * (s0 + ckc)) << 3) & rmask8;       /* ring byte of image unit 0: scalar */
         const char *base = ring8 + g08;
 #pragma unroll
         for (int p = 0; p < WPMAX; p++)
             if (p < npw) {
-                if constexpr (R == 4) dma16(base, rel8[p], ws_addr + 16u * G::UP * p);
-                else dma16(base + 8 * NR * (64 / G::UB) * p, rel8[0], ws_addr + 16u * G::UP * p);
+                if constexpr (R == 4) dma16(base, rel8[p], wdst + 16u * G::UP * p);
+                else dma16(base + 8 * NR * (64 / G::UB) * p, rel8[0], wdst + 16u * G::UP * p);
             }
     };
     auto taps_dma = [&](int which, int s0, int ckc) {
@@ -2386,19 +2394,25 @@ __global__ __launch_bounds__(kBlock, 2) void fir_flow(const FirTileArgs a)
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    window_dma(0, min(ck, S));
+    window_dma(0, 0, min(ck, S));
     taps_dma(0, 0, min(ck, S));
     int n = 0;
     [[maybe_unused]] int stamp_i = 1;
     for (int s0 = 0; s0 < S; s0 += ck, n++) {
         const int ckc = min(ck, S - s0);
         FIR_STAMP_CHUNK();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    /* this chunk's window (requested at the boundary) and taps (a chunk ago) have landed */
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    /* this chunk's window (requested at the boundary; BIG: a chunk ago) and taps (a chunk ago) have landed */
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (s0 + ckc < S) taps_dma((n + 1) & 1, s0 + ckc, min(ck, S - s0 - ckc));      /* (lands under this chunk's k-steps) */
+        if (s0 + ckc < S) {                                 /* (land under this chunk's k-steps) */
+            taps_dma((n + 1) & 1, s0 + ckc, min(ck, S - s0 - ckc));
+            /* (Tried: these copies one piece per k-step instead of in a row here -- with one row tile every MFMA waits ~72 cycles for the
+             * one before, a shadow a copy instruction might fit.  It does not: a piece costs 165 cycles there, its scalar address
+             * arithmetic and branches included; k-steps 14.7 k -> 17.9 k cycles per chunk for 1.1 k saved at its head, cfg4 39.2 -> 43.4 us.) */
+            if constexpr (BIG) window_dma((n + 1) & 1, s0 + ckc, min(ck, S - s0 - ckc));
+        }
         const double *hp = hs + (n & 1) * G::HLEN + k + i16;
-        const double *wg = ws + (NR + 2) * i16 + 3 - k - G::LOW + (ckc / 16) * G::GS;
+        const double *wg = ws + (BIG ? (n & 1) * G::WLEN : 0) + (NR + 2) * i16 + 3 - k - G::LOW + (ckc / 16) * G::GS;
         chunk_begin(hp, wg);
         FIR_STAMP_CHUNK();
         for (int g = 0; g < ckc / 16; g++) {
@@ -2412,11 +2426,11 @@ __global__ __launch_bounds__(kBlock, 2) void fir_flow(const FirTileArgs a)
             kstep(hg, wgg, std::integral_constant<int, 12>{}); kstep(hg, wgg, std::integral_constant<int, 13>{});
             kstep(hg, wgg, std::integral_constant<int, 14>{}); kstep(hg, wgg, std::integral_constant<int, 15>{});
         }
-        /* the boundary: every read of the window image has been used (an MFMA waits for its operands); the next window may land */
+        /* the boundary: every read of the window image has been used (an MFMA waits for its operands); one image: the next window may land */
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
         FIR_STAMP_CHUNK();
-        if (s0 + ckc < S) window_dma(s0 + ckc, min(ck, S - s0 - ckc));
+        if constexpr (!BIG) { if (s0 + ckc < S) window_dma(0, s0 + ckc, min(ck, S - s0 - ckc)); }
     }
     FIR_STAMP(23);
     /* the tile leaves as in fir_tile (C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg) */
@@ -3609,7 +3623,7 @@ int launch_fir_stream(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, Blo
     return 0;
 }
 
-template <int FMT, int R>
+template <int FMT, int R, bool BIG = false>
 int launch_fir_flow(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, BlockIO io, hipStream_t stream, ProfileScope &scope, bool wait_ready, hipEvent_t stop)
 {
     if (!pl.d_ring64) {
@@ -3624,9 +3638,9 @@ int launch_fir_flow(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, Block
     a.buf = prog->d_buf; a.chains = pl.d_chains; a.group = ids; a.ngroup = n;
     a.ring = plan_ring(pl); a.io = io; a.taps64 = pl.d_taps64; a.pitch64 = pl.pitch64;
     if (wait_ready) { a.ready = pl.d_ready; a.seq = pl.seq; a.timeouts = prog->d_ready_timeouts; }
-    const int nwg = (n * FlowGeom<R>::WPC + 3) / 4;
+    const int nwg = (n * FlowGeom<R, BIG>::WPC + 3) / 4;
     a.per_xcd = (nwg + 7) / 8;
-    const size_t lds = (size_t)4 * FlowGeom<R>::LDS_DOUBLES * sizeof(double) + 64;
+    const size_t lds = (size_t)4 * FlowGeom<R, BIG>::LDS_DOUBLES * sizeof(double) + 64;
 #ifdef AVDSP_FIR_STAMPS
     static unsigned long long *d_stamps = nullptr;
     if (!d_stamps) { HIP_TRY(hipMalloc((void **)&d_stamps, (size_t)8192 * 4 * 32 * 8)); }
@@ -3634,7 +3648,7 @@ int launch_fir_flow(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, Block
     a.stamps = d_stamps;
     g_fir_stamps = d_stamps; g_fir_stamp_waves = a.per_xcd * 8 * 4;
 #endif
-    return launch_timed(scope, (const void *)fir_flow<FMT, R>, dim3(a.per_xcd * 8), dim3(kBlock), lds, stream, a, stop);
+    return launch_timed(scope, (const void *)fir_flow<FMT, R, BIG>, dim3(a.per_xcd * 8), dim3(kBlock), lds, stream, a, stop);
 }
 
 /* fir_impl: 0 = fir_plain (the reference's loop), 1 = fir_tile (default), 2 = fir_mfma (round 1's workgroup-per-channel kernel),
@@ -3649,6 +3663,8 @@ int launch_fir(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, BlockIO io
             int rows = prog->fir_rows;
             if (rows != 1 && rows != 2 && rows != 4) rows = n >= 2048 ? 4 : n >= 1024 ? 2 : 1;
             while (rows > 1 && 128 * rows >= io.nframes) rows >>= 1;
+            if (rows == 1 && (long long)n * ((io.nframes + 255) / 256) <= 1024 && prog->fir_rows != 1)     /* at most a wave per SIMD: long chunks, two window images */
+                return launch_fir_flow<FMT, 1, true>(prog, pl, ids, n, io, stream, scope, wait_ready, stop);
             return rows == 4 ? launch_fir_flow<FMT, 4>(prog, pl, ids, n, io, stream, scope, wait_ready, stop)
                  : rows == 2 ? launch_fir_flow<FMT, 2>(prog, pl, ids, n, io, stream, scope, wait_ready, stop)
                              : launch_fir_flow<FMT, 1>(prog, pl, ids, n, io, stream, scope, wait_ready, stop);
@@ -3962,11 +3978,13 @@ int avdsp_hip_prog_add_plan(avdsp_hip_prog *prog, const avdsp_plan_desc *d)
                 hipError_t e2 = hipFuncSetAttribute(fns[v], hipFuncAttributeMaxDynamicSharedMemorySize, flds[v]);
                 if (e2 != hipSuccess) { free_plan(pl); return set_err("hipFuncSetAttribute(fir_stream LDS %d): %s", flds[v], hipGetErrorString(e2)); }
             }
-            const void *ffn[3] = { d->format == 4 ? (const void *)fir_flow<4, 1> : (const void *)fir_flow<6, 1>,
+            const void *ffn[4] = { d->format == 4 ? (const void *)fir_flow<4, 1> : (const void *)fir_flow<6, 1>,
                                    d->format == 4 ? (const void *)fir_flow<4, 2> : (const void *)fir_flow<6, 2>,
-                                   d->format == 4 ? (const void *)fir_flow<4, 4> : (const void *)fir_flow<6, 4> };
-            const int fl[3] = { 4 * FlowGeom<1>::LDS_DOUBLES * 8 + 64, 4 * FlowGeom<2>::LDS_DOUBLES * 8 + 64, 4 * FlowGeom<4>::LDS_DOUBLES * 8 + 64 };
-            for (int v = 0; v < 3; v++) {
+                                   d->format == 4 ? (const void *)fir_flow<4, 4> : (const void *)fir_flow<6, 4>,
+                                   d->format == 4 ? (const void *)fir_flow<4, 1, true> : (const void *)fir_flow<6, 1, true> };
+            const int fl[4] = { 4 * FlowGeom<1>::LDS_DOUBLES * 8 + 64, 4 * FlowGeom<2>::LDS_DOUBLES * 8 + 64, 4 * FlowGeom<4>::LDS_DOUBLES * 8 + 64,
+                                4 * FlowGeom<1, true>::LDS_DOUBLES * 8 + 64 };
+            for (int v = 0; v < 4; v++) {
                 hipError_t e2 = hipFuncSetAttribute(ffn[v], hipFuncAttributeMaxDynamicSharedMemorySize, fl[v]);
                 if (e2 != hipSuccess) { free_plan(pl); return set_err("hipFuncSetAttribute(fir_flow LDS %d): %s", fl[v], hipGetErrorString(e2)); }
             }

@@ -69,6 +69,17 @@ def test_long_fir_behind_a_cascade(rows, fmt, C, S, T, impl):
     run_vs_oracle(fmt, prog, x, C, blocks, rows, impl)
 
 
+@pytest.mark.parametrize("impl", [4, 1])
+@pytest.mark.parametrize("fmt,C,S,T", [(6, 5, 0, 1), (6, 3, 0, 255), (6, 4, 0, 893), (6, 6, 0, 3581), (6, 5, 0, 4096), (6, 3, 2, 5000), (4, 4, 0, 2560), (4, 5, 3, 4100)])
+def test_long_chunks_where_a_launch_leaves_a_simd_one_wave(fmt, C, S, T, impl):
+    """automatic row choice with few chains: fir_tile's chunks of 320 k-steps, fir_flow's of 224 with two window images (the tap
+    counts sit on both sides of one, two and several such chunks); ragged blocks, a FIR-only program and one behind a cascade"""
+    prog = pb.synth_program(fmt, C, S, T)
+    blocks = [1024, 1024, 1, 300, 1024, 257, 1024, 700]
+    x = pb.lcg_input(sum(blocks), C, fmt == 6, seed=T + C)
+    run_vs_oracle(fmt, prog, x, C, blocks, 0, impl)
+
+
 @pytest.mark.parametrize("rows", [0] + ROWS)
 def test_many_channels_auto_rows_and_other_kernels_agree(rows):
     """enough chains for every automatic choice (>= 2048: 4 row tiles), short taps so that the oracle keeps up; the same blocks

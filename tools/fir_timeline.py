@@ -19,6 +19,8 @@ ap.add_argument("--fir-rows", type=int, default=0)
 ap.add_argument("--fir-impl", type=int, default=3)
 ap.add_argument("--fir-split", type=int, default=0)
 ap.add_argument("--blocks", type=int, default=6, help="blocks run before the one that is summarised")
+ap.add_argument("--overlap", type=int, default=-1, help="the library's \"overlap\" option (-1: its default)")
+ap.add_argument("--fir-lean", type=int, default=-1)
 args = ap.parse_args()
 
 lib = "/tmp/libavdsp_stamps.so"
@@ -38,6 +40,8 @@ r = rt.Runtime(fmt, pb.synth_program(fmt, Cn, S, T))
 r.set_option("fir_rows", args.fir_rows)
 r.set_option("fir_impl", args.fir_impl)
 r.set_option("fir_split", args.fir_split)
+if args.overlap >= 0: r.set_option("overlap", args.overlap)
+if args.fir_lean >= 0: r.set_option("fir_lean", args.fir_lean)
 if args.shard:
     a, b = (int(v) for v in args.shard.split("/"))
     r.set_shard(a, b)
@@ -96,6 +100,8 @@ print(f"  per wave: life {np.median(life) / 2400:.1f} us, staging {np.median(sta
 rs = (st[:, 29] - st[:, 29].min()) / 100.0; re_ = (st[:, 28] - st[:, 29].min()) / 100.0        # s_memrealtime: 100 MHz, one clock for the chip
 print("  wave starts (us after the first, by the 100 MHz clock): p10 %.1f p50 %.1f p90 %.1f max %.1f;  ends: p10 %.1f p50 %.1f p90 %.1f max %.1f"
       % (*np.percentile(rs, [10, 50, 90, 100]), *np.percentile(re_, [10, 50, 90, 100])))
+hist, edges = np.histogram(rs, bins=12)
+print("  wave starts, histogram over the launch: " + " ".join(f"{int(e)}us:{h}" for h, e in zip(hist, edges[:-1])))
 hw = (st[:, 31].astype(np.uint64) >> np.uint64(32)).astype(np.int64)
 simd = (hw >> 4) & 3; cu = (hw >> 8) & 15; sh = (hw >> 12) & 1; se = (hw >> 13) & 7; xcc = st[:, 31] & 7
 key = ((xcc * 8 + se) * 2 + sh) * 16 + cu
