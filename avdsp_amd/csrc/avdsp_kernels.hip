@@ -3318,6 +3318,7 @@ struct avdsp_hip_prog {
     unsigned *d_alias = nullptr; size_t alias_cap = 0;    /* copy of the input block of an in-place device call (avdsp_hip_run_block) */
     /* N instances of the program (avdsp_hip_run_levels_instances): copies 1 .. N-1 of the device state; instance 0 is the program's own */
     int inst_n = 1; bool inst_valid = false;
+    bool call_shown = false;                 /* inside a dspRuntimeBlockAll call whose shared window columns have been copied (show_through) */
     int *d_inst_buf = nullptr; TpdfGlobals *d_inst_tpdf = nullptr; unsigned *d_inst_frame = nullptr; int *d_inst_seq = nullptr;
     int inst_frame_words = 0, inst_seq_frames = 0;
     static constexpr int kSmallWords = 4096;             /* host calls of up to that many sample words (dspRuntime_N) ... */
@@ -4291,11 +4292,44 @@ static bool wave_plan_fits(const avdsp_hip_prog *prog, const Plan &pl, const Blo
 
 /* where the two windows share IO numbers the host loop hands the input through to the output rows for slots the
  * core does not store: that (and unknown ownership) needs the whole windows moved, not the core's slots */
-static bool rows_whole(const Plan &pl, const BlockIO &io)
+static bool windows_overlap(const BlockIO &io)
 {
-    const bool overlap = io.in_stride > 0 && io.out_stride > 0 && io.in_base < io.out_base + io.out_stride && io.out_base < io.in_base + io.in_stride;
-    return overlap || pl.ga.nown < 0 || pl.ga.nrd_slot < 0 || pl.ga.nwr_slot < 0;
+    return io.in_stride > 0 && io.out_stride > 0 && io.in_base < io.out_base + io.out_stride && io.out_base < io.in_base + io.in_stride;
 }
+static bool needs_whole(const Plan &pl) { return pl.ga.nown < 0 || pl.ga.nrd_slot < 0 || pl.ga.nwr_slot < 0; }
+static bool rows_whole(const Plan &pl, const BlockIO &io) { return windows_overlap(io) || needs_whole(pl); }
+
+/* ... unless the handing-through is done apart (round 4): one small kernel copies the shared IO numbers' columns from the input rows
+ * to the output rows; every launch behind it then moves only its core's slots (a slot in both windows is READ from the input row
+ * and STORED to the output row, so the copy and the launches do not meet), and the pieces of a level can run side by side again.
+ * This is the reference's one samples[] frame: an IO inside both windows shows the input unless somebody stores it.  (The reference's
+ * own dacdiy1.bin has its outputs on both sides of its inputs: no pair of windows that take all of them can be kept apart.) */
+__global__ void show_through(const unsigned *in, int in_stride, int in_base, unsigned *out, int out_stride, int out_base,
+                             int nframes, int lo, int hi, size_t in_inst_words, size_t out_inst_words)
+{
+    const int w = hi - lo;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)nframes * w) return;
+    const int f = (int)(idx / w), sl = lo + (int)(idx % w);
+    out[(size_t)blockIdx.y * out_inst_words + (size_t)f * out_stride + (sl - out_base)] =
+        in[(size_t)blockIdx.y * in_inst_words + (size_t)f * in_stride + (sl - in_base)];
+}
+static int launch_show_through(const BlockIO &io, hipStream_t stream, int ninst = 1, size_t in_inst_words = 0, size_t out_inst_words = 0)
+{
+    const int lo = std::max(io.in_base, io.out_base), hi = std::min(io.in_base + io.in_stride, io.out_base + io.out_stride);
+    if (hi <= lo || io.nframes <= 0) return 0;
+    const long long total = (long long)io.nframes * (hi - lo);
+    hipLaunchKernelGGL(show_through, dim3((unsigned)((total + kBlock - 1) / kBlock), (unsigned)ninst), dim3(kBlock), 0, stream,
+                       io.in, io.in_stride, io.in_base, io.out, io.out_stride, io.out_base, io.nframes, lo, hi, in_inst_words, out_inst_words);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+/* a dspRuntimeBlockAll call does it once, in front of its first level (on the caller's stream: every launch of the call is ordered behind it) */
+struct ShownScope {
+    avdsp_hip_prog *p;
+    explicit ShownScope(avdsp_hip_prog *prog) : p(prog) { p->call_shown = true; }
+    ~ShownScope() { p->call_shown = false; }
+};
 
 /* pieces of a cut core exchange the per-frame dither values through one buffer per program */
 static int tpdf_seq_for(avdsp_hip_prog *prog, GenericArgs &a, int nframes)
@@ -4319,6 +4353,15 @@ static int launch_generic(avdsp_hip_prog *prog, Plan &pl, BlockIO io, hipStream_
     a.io = io;
     a.rows_whole = rows_whole(pl, io);
     if (tpdf_seq_for(prog, a, io.nframes)) return -1;
+    if (windows_overlap(io) && !needs_whole(pl) && !strands_take(pl, io)) {
+        /* the frame-parallel kernel with slot lists behind the copy of the shared columns, where the core fits it that way */
+        GenericArgs b = a;
+        b.rows_whole = 0;
+        if (wave_plan_fits(prog, pl, io, b)) {
+            if (!prog->call_shown && launch_show_through(io, stream)) return -1;
+            a = b;
+        }
+    }
     if (strands_take(pl, io)) {
         ProfileScope scope(prog, stream, AVDSP_KERNEL_STRANDS); scope.begin();
         StrandArgs sa{};
@@ -4800,6 +4843,15 @@ int avdsp_hip_run_levels(avdsp_hip_prog *prog, const int *plans, const int *leve
 {
     hipStream_t main = (hipStream_t)stream;
     int at = 0;
+    /* windows that share IO numbers: the shared columns go from the input rows to the output rows once, here; the launches behind it
+     * move their cores' slots only (show_through) */
+    BlockIO wio{};
+    wio.in_stride = in_stride; wio.in_base = in_io_base; wio.out_stride = out_stride; wio.out_base = out_io_base;
+    wio.in = (const unsigned *)d_in; wio.out = (unsigned *)d_out; wio.nframes = nframes;
+    const bool shown = windows_overlap(wio) && nframes > 1;
+    if (shown && launch_show_through(wio, main)) return -1;
+    ShownScope shown_scope(prog);
+    if (!shown) prog->call_shown = false;
     for (int l = 0; l < nlevels; l++) {
         const int n = level_size[l];
         bool together = n > 1;
@@ -4810,7 +4862,7 @@ int avdsp_hip_run_levels(avdsp_hip_prog *prog, const int *plans, const int *leve
             if (id < 0 || id >= (int)prog->plans.size()) return set_err("bad plan id %d", id);
             const Plan &pl = prog->plans[id];
             /* chain plans and interpreter cores working out of HBM share buffers; whole-window delivery overwrites */
-            if (!pl.generic || !pl.ga_staged || rows_whole(pl, io)) together = false;
+            if (!pl.generic || !pl.ga_staged || (shown ? needs_whole(pl) : rows_whole(pl, io))) together = false;
         }
         if (!together) {
             for (int i = 0; i < n; i++)
@@ -4961,68 +5013,82 @@ int avdsp_hip_run_levels_instances(avdsp_hip_prog *prog, const int *plans, const
     if (nframes < 2 || nframes > kFirChunk * 64) return set_err("instances: blocks of 2 .. %d frames", kFirChunk * 64);
     /* (the dither-pair buffers and the frame exist once the pieces have been looked at: a first pass over the table) */
     constexpr int K = avdsp_hip_prog::kTableSlots;
+    BlockIO gio{};
+    gio.in_stride = in_stride; gio.in_base = in_io_base; gio.out_stride = out_stride; gio.out_base = out_io_base;
+    gio.in = (const unsigned *)d_in; gio.out = (unsigned *)d_out; gio.nframes = nframes; gio.store_mask = -1;
+    if (windows_overlap(gio) && launch_show_through(gio, main, ninst, in_inst_words, out_inst_words)) return -1;     /* (the callers' rows: nothing of the instances' state) */
     int at = 0;
     for (int l = 0; l < nlevels; l++) {
-        const int n = level_size[l];
-        if (prog->table_cap < n) {
-            HIP_TRY(hipDeviceSynchronize());
-            (void)hipFree(prog->d_table); (void)hipHostFree(prog->h_table);
-            prog->d_table = nullptr; prog->h_table = nullptr; prog->table_cap = 0;
-            const int cap = std::max(n, 16);
-            HIP_TRY(hipMalloc((void **)&prog->d_table, (size_t)K * cap * sizeof(GenericArgs)));
-            HIP_TRY(hipHostMalloc((void **)&prog->h_table, (size_t)K * cap * sizeof(GenericArgs), hipHostMallocDefault));
-            prog->table_cap = cap;
-            for (auto &ev : prog->table_done) if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        }
-        const int slot = prog->table_next;
-        GenericArgs *table = prog->h_table + (size_t)slot * prog->table_cap;
-        GenericArgs *d_slot = prog->d_table + (size_t)slot * prog->table_cap;
-        HIP_TRY(hipEventSynchronize(prog->table_done[slot]));
-        size_t lds = 0;
-        BlockIO gio{};
-        gio.in_stride = in_stride; gio.in_base = in_io_base; gio.out_stride = out_stride; gio.out_base = out_io_base;
-        gio.in = (const unsigned *)d_in; gio.out = (unsigned *)d_out; gio.nframes = nframes; gio.store_mask = -1;
-        int fmt = 0;
-        for (int i = 0; i < n; i++) {
+        const int nl = level_size[l];
+        /* The pieces of a level go out as ONE grid of pieces x instances -- unless a piece delivers whole rows (the call's windows share IO
+         * numbers, or the host could not tell what the core owns): whole rows of two pieces would overwrite each other, so such a
+         * level's pieces run one after the other, each as a grid of its own over the instances (avdsp_hip_run_levels does the same
+         * with one launch per piece). */
+        bool together = true;
+        for (int i = 0; i < nl; i++) {
             const int id = plans[at + i];
             if (id < 0 || id >= (int)prog->plans.size()) return set_err("bad plan id %d", id);
-            Plan &pl = prog->plans[id];
-            GenericArgs a = pl.ga;
-            a.io = gio;
-            a.rows_whole = 0;
-            if (!pl.generic || !pl.ga_staged || rows_whole(pl, gio))
-                return set_err("instances: every core must run on the frame-parallel interpreter with windows that do not share IO numbers (plan %d does not)", id);
-            if (tpdf_seq_for(prog, a, nframes)) return -1;
-            if (in_stride < 0 || out_stride < 0 || in_io_base < 0 || out_io_base < 0 ||
-                (in_stride && in_io_base + in_stride > pl.ga.scratch_len) || (out_stride && out_io_base + out_stride > pl.ga.scratch_len) ||
-                (fmt && pl.format != fmt) || !wave_plan_fits(prog, pl, gio, a))
-                return set_err("instances: plan %d does not fit the frame-parallel interpreter for these windows", id);
-            fmt = pl.format;
-            lds = std::max(lds, ((size_t)a.batch_lds + 128 + (size_t)a.nvm * 128 + a.seq_words) * 4);
-            table[i] = a;
+            const Plan &pl = prog->plans[id];
+            if (!pl.generic || !pl.ga_staged)
+                return set_err("instances: every core must run on the frame-parallel interpreter (plan %d does not)", id);
+            if (needs_whole(pl)) together = false;          /* (windows that share IO numbers: their columns were copied in front, show_through) */
         }
-        if (instances_ready(prog, nframes)) return -1;
-        InstanceStrides st{};
-        st.n = n; st.buf = prog->d_inst_buf; st.buf_words = (size_t)prog->total_words + 2; st.tpdf = prog->d_inst_tpdf;
-        st.scratch = prog->d_inst_frame; st.frame_words = (size_t)prog->frame_words;
-        st.tpdf_seq = prog->d_inst_seq; st.seq_words = (size_t)prog->inst_seq_frames * 2;
-        st.in_words = in_inst_words; st.out_words = out_inst_words;
-        HIP_TRY(hipMemcpyAsync(d_slot, table, (size_t)n * sizeof(GenericArgs), hipMemcpyHostToDevice, main));
-        {
-            ProfileScope scope(prog, main, AVDSP_KERNEL_GENERIC_WAVE); scope.begin();
-            const dim3 grid((unsigned)n * (unsigned)ninst), block(64);
-            switch (fmt) {
-            case 2:  hipLaunchKernelGGL((interp_wave_instances<2>), grid, block, lds, main, d_slot, st); break;
-            case 3:  hipLaunchKernelGGL((interp_wave_instances<3>), grid, block, lds, main, d_slot, st); break;
-            case 4:  hipLaunchKernelGGL((interp_wave_instances<4>), grid, block, lds, main, d_slot, st); break;
-            case 5:  hipLaunchKernelGGL((interp_wave_instances<5>), grid, block, lds, main, d_slot, st); break;
-            default: hipLaunchKernelGGL((interp_wave_instances<6>), grid, block, lds, main, d_slot, st); break;
+        for (int first = 0; first < nl; first += together ? nl : 1) {
+            const int n = together ? nl : 1;
+            if (prog->table_cap < n) {
+                HIP_TRY(hipDeviceSynchronize());
+                (void)hipFree(prog->d_table); (void)hipHostFree(prog->h_table);
+                prog->d_table = nullptr; prog->h_table = nullptr; prog->table_cap = 0;
+                const int cap = std::max(n, 16);
+                HIP_TRY(hipMalloc((void **)&prog->d_table, (size_t)K * cap * sizeof(GenericArgs)));
+                HIP_TRY(hipHostMalloc((void **)&prog->h_table, (size_t)K * cap * sizeof(GenericArgs), hipHostMallocDefault));
+                prog->table_cap = cap;
+                for (auto &ev : prog->table_done) if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
             }
-            HIP_TRY(hipGetLastError());
+            const int slot = prog->table_next;
+            GenericArgs *table = prog->h_table + (size_t)slot * prog->table_cap;
+            GenericArgs *d_slot = prog->d_table + (size_t)slot * prog->table_cap;
+            HIP_TRY(hipEventSynchronize(prog->table_done[slot]));
+            size_t lds = 0;
+            int fmt = 0;
+            for (int i = 0; i < n; i++) {
+                const int id = plans[at + first + i];
+                Plan &pl = prog->plans[id];
+                GenericArgs a = pl.ga;
+                a.io = gio;
+                a.rows_whole = together ? 0 : needs_whole(pl);
+                if (tpdf_seq_for(prog, a, nframes)) return -1;
+                if (in_stride < 0 || out_stride < 0 || in_io_base < 0 || out_io_base < 0 ||
+                    (in_stride && in_io_base + in_stride > pl.ga.scratch_len) || (out_stride && out_io_base + out_stride > pl.ga.scratch_len) ||
+                    (fmt && pl.format != fmt) || !wave_plan_fits(prog, pl, gio, a))
+                    return set_err("instances: plan %d does not fit the frame-parallel interpreter for these windows", id);
+                fmt = pl.format;
+                lds = std::max(lds, ((size_t)a.batch_lds + 128 + (size_t)a.nvm * 128 + a.seq_words) * 4);
+                table[i] = a;
+            }
+            if (instances_ready(prog, nframes)) return -1;
+            InstanceStrides st{};
+            st.n = n; st.buf = prog->d_inst_buf; st.buf_words = (size_t)prog->total_words + 2; st.tpdf = prog->d_inst_tpdf;
+            st.scratch = prog->d_inst_frame; st.frame_words = (size_t)prog->frame_words;
+            st.tpdf_seq = prog->d_inst_seq; st.seq_words = (size_t)prog->inst_seq_frames * 2;
+            st.in_words = in_inst_words; st.out_words = out_inst_words;
+            HIP_TRY(hipMemcpyAsync(d_slot, table, (size_t)n * sizeof(GenericArgs), hipMemcpyHostToDevice, main));
+            {
+                ProfileScope scope(prog, main, AVDSP_KERNEL_GENERIC_WAVE); scope.begin();
+                const dim3 grid((unsigned)n * (unsigned)ninst), block(64);
+                switch (fmt) {
+                case 2:  hipLaunchKernelGGL((interp_wave_instances<2>), grid, block, lds, main, d_slot, st); break;
+                case 3:  hipLaunchKernelGGL((interp_wave_instances<3>), grid, block, lds, main, d_slot, st); break;
+                case 4:  hipLaunchKernelGGL((interp_wave_instances<4>), grid, block, lds, main, d_slot, st); break;
+                case 5:  hipLaunchKernelGGL((interp_wave_instances<5>), grid, block, lds, main, d_slot, st); break;
+                default: hipLaunchKernelGGL((interp_wave_instances<6>), grid, block, lds, main, d_slot, st); break;
+                }
+                HIP_TRY(hipGetLastError());
+            }
+            HIP_TRY(hipEventRecord(prog->table_done[slot], main));
+            prog->table_next = (slot + 1) % K;
         }
-        HIP_TRY(hipEventRecord(prog->table_done[slot], main));
-        prog->table_next = (slot + 1) % K;
-        at += n;
+        at += nl;
     }
     return 0;
 }

@@ -247,7 +247,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="north", choices=sorted(WORKLOADS))
-    ap.add_argument("--fir-impl", type=int, default=1)
+    ap.add_argument("--fir-impl", type=int, default=1, help="0 the reference's tap loop, 1 fir_tile (default), 2 fir_mfma (round 1), 3 fir_stream, 4 fir_flow (DESIGN.md 4.2)")
     ap.add_argument("--biquad-impl", type=int, default=1)
     ap.add_argument("--overlap", type=int, default=1, help="cascade of the next block under the FIR of this one (the blocks are resident in HBM, which is that mode's contract): 0 off, 1 on, 2 also the FIRs of consecutive blocks on two streams in turn")
     ap.add_argument("--ready-words", type=int, default=0, help="under --overlap: 1 the FIR waits for its cascades through per-chain ready words inside the kernel, 0 (default) through an event between the two queues")
@@ -540,7 +540,7 @@ def main():
             launches_per_step = (B + 1023) // 1024           # blocks longer than 1024 frames are cut into 1024-frame launches
             flops = 2.0 * T * B * Cl / launches_per_step
             ach = flops / per_launch / 1e12
-            kname = {0: "fir_plain", 1: "fir_tile", 2: "fir_mfma", 3: "fir_stream"}[args.fir_impl]
+            kname = {0: "fir_plain", 1: "fir_tile", 2: "fir_mfma", 3: "fir_stream", 4: "fir_flow"}[args.fir_impl]
             fir_bytes = (4.0 * Cl * B + 4.0 * (T - 1 + B) * Cl + 4.0 * T * Cl) / launches_per_step   # out, window, taps
             roof = dict(bound="mfma", kernel=kname, achieved=ach,
                         peak=PEAK_F64_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_F64_TFLOPS,

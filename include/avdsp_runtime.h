@@ -200,7 +200,8 @@ int dspRuntimeShardInfo(int format, opcode_t *core, int *total_chains, int *firs
  * the run is too short for the current "strand_lanes" setting (default: more than 64 strands; 2: any run). */
 int dspRuntimeStrandInfo(int format, opcode_t *core, int *strands, int *ops_per_strand, int *prefix_words);
 
-/* Tunables: "fir_impl" 0 = plain tap loop, 1 = MFMA (default); "biquad_impl" 0 = lane per channel,
+/* Tunables: "fir_impl" 0 = plain tap loop, 1 = MFMA (fir_tile, default), 2 / 3 / 4 = the other MFMA kernels kept for comparison (fir_mfma,
+ * fir_stream, fir_flow: same results); "biquad_impl" 0 = lane per channel,
  * 1 = section-pipelined (default: biquad_row where it applies, else biquad_pipe), 2 = round 2's biquad_pipe throughout; "interp_impl" 0 = interpreter always frame by frame, 1 = frame-parallel
  * where the core allows it (default); "strand_split" 0 = dspRuntimeBlockAll keeps cores whole; "strand_lanes" 0 = strand runs stay with the interpreter, 1 = runs of more than 64 strands on lanes (default: up to 64 strand groups get a wave each from the interpreter, which is faster), 2 = every run; "generic" 1 = every core through the interpreter;
  * "device" = HIP device ordinal (before the first block);

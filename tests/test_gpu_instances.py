@@ -43,7 +43,7 @@ def _run_instances(fmt, prog, xs, in_stride, in_base, out_stride, blocks, fs=480
 
 def test_instances_of_the_reference_crossover_each_match_the_oracle():
     """crossoverLV6.bin (dspprogs/crossoverLV6.c: inputs IO 16, 17; outputs IO 25 .. 29) in 37 instances with inputs of their own.
-    (dacdiy1.bin's outputs lie on both sides of its inputs: its windows share IO numbers, which the instances do not take.)"""
+    (windows that share no IO number: the pieces of a level go out as one grid; the other way round: the next test)"""
     prog = np.fromfile(os.path.join(GOLDEN_DIR, "crossoverLV6.bin"), dtype=np.uint32)
     ninst, blocks = 37, [64, 300, 2, 129]
     frames = sum(blocks)
@@ -76,6 +76,44 @@ def test_instances_of_the_reference_crossover_each_match_the_oracle():
         assert bad.size == 0, f"instance {i}: output columns {list(bad)} differ"
         assert (r.instance_state(i) == o.state).all(), f"instance {i}: data area differs"
     assert (got[6] == got[7]).all() and got[1:5].any()
+    r.release()
+
+
+@pytest.mark.parametrize("name", ["dacdiy1.bin", "crossoverLV6.bin"])
+def test_instances_with_windows_that_share_io_numbers(name):
+    """the goldens' windows (input IO 8 .. 23 inside output IO 0 .. 31): dacdiy1.bin's outputs lie on both sides of its inputs, so its
+    windows cannot be kept apart.  Whole rows then move (the input shows through where the program stores nothing) and the pieces
+    of a level run one after the other, each as a grid over the instances; every instance is still the oracle's bits."""
+    import torch
+    prog = np.fromfile(os.path.join(GOLDEN_DIR, name), dtype=np.uint32)
+    ninst, blocks = 11, [64, 200, 3, 130]
+    frames = sum(blocks)
+    IN_S, IN_B, OUT_S, OUT_B = 16, 8, 32, 0
+    xs = np.stack([pb.lcg_input(frames, IN_S, False, seed=40 + i) for i in range(ninst)])
+    xs[2] = xs[9]
+    r = rt.Runtime(2, prog, fs=48000, random=3, dither=24)
+    r.set_instances(ninst)
+    got = np.zeros((ninst, frames, OUT_S), dtype=xs.dtype)
+    st = torch.cuda.current_stream().cuda_stream
+    pos = 0
+    for b in blocks:
+        xd = torch.from_numpy(np.ascontiguousarray(xs[:, pos:pos + b])).cuda()
+        yd = torch.zeros((ninst, b, OUT_S), dtype=xd.dtype, device="cuda")
+        r.run_block_all_instances_device(xd.data_ptr(), IN_S, IN_B, b * IN_S, yd.data_ptr(), OUT_S, OUT_B, b * OUT_S, b, st)
+        torch.cuda.synchronize()
+        got[:, pos:pos + b] = yd.cpu().numpy()
+        pos += b
+    for i in range(ninst):
+        o = po.OracleProgram(2, prog, fs=48000, random=3, dither=24)
+        frame = np.zeros(4096, dtype=np.uint32)
+        pos = 0
+        for b in blocks:
+            want = o.run_block(xs[i, pos:pos + b], OUT_S, IN_B, OUT_B, block=b, frame=frame)
+            bad = np.nonzero((got[i, pos:pos + b].view(np.uint32) != want.view(np.uint32)).any(axis=0))[0]
+            assert bad.size == 0, f"{name} instance {i}, block at {pos}: output columns {list(bad)} differ"
+            pos += b
+        assert (r.instance_state(i) == o.state).all(), f"{name} instance {i}: data area differs"
+    assert (got[2] == got[9]).all()
     r.release()
 
 

@@ -20,9 +20,12 @@ ap.add_argument("--prog", default="crossoverLV6.bin")
 ap.add_argument("--instances", type=int, nargs="*", default=[1, 64, 256, 1024, 4096])
 ap.add_argument("--frames", type=int, default=4096)
 ap.add_argument("--blocks", type=int, default=10)
+ap.add_argument("--windows", type=int, nargs=4, default=None, metavar=("IN_STRIDE", "IN_BASE", "OUT_STRIDE", "OUT_BASE"),
+                help="the call's windows (default: crossoverLV6's own IOs, 2 16 8 24, which share no IO number; 16 8 32 0 are the goldens' windows, "
+                     "which do -- whole rows move then and the pieces of a level run one after the other: dacdiy1.bin needs that)")
 args = ap.parse_args()
 prog = np.fromfile(os.path.join(ROOT, "tests", "golden", args.prog), dtype=np.uint32)
-IN_STRIDE, IN_BASE, OUT_STRIDE, OUT_BASE = 2, 16, 8, 24      # crossoverLV6: inputs IO 16, 17, outputs IO 25 .. 29 (windows that share no IO number)
+IN_STRIDE, IN_BASE, OUT_STRIDE, OUT_BASE = args.windows or (2, 16, 8, 24)      # crossoverLV6: inputs IO 16, 17, outputs IO 25 .. 29 (windows that share no IO number)
 used_in = bin(int(prog[9])).count("1")              # header.usedInputs (word 9): the channels the program really reads
 B = args.frames
 x1 = pb.lcg_input(B, IN_STRIDE, False, seed=5)

@@ -9,4 +9,6 @@ bash tools/profile_tool.sh r04_interp tools/extras_bench.py program > /dev/null 
 python3 tools/fir_timeline.py cfg4 --fir-impl 1 --blocks 200 2>&1 | grep -v amdgpu.ids > gpurun_out/r04_cfg4_timeline.txt
 python3 tools/fir_timeline.py cfg4 --fir-impl 1 --fir-split 1 --blocks 200 2>&1 | grep -v amdgpu.ids > gpurun_out/r04_cfg4_split_timeline.txt
 python3 tools/fir_timeline.py north --fir-impl 1 --blocks 200 2>&1 | grep -v amdgpu.ids > gpurun_out/r04_north_timeline.txt
+python3 tools/fir_timeline.py north --fir-impl 4 --blocks 200 2>&1 | grep -v amdgpu.ids > gpurun_out/r04_north_flow_timeline.txt
+python3 tools/fir_timeline.py cfg4 --fir-impl 4 --blocks 200 2>&1 | grep -v amdgpu.ids > gpurun_out/r04_cfg4_flow_timeline.txt
 ls gpurun_out | grep r04_

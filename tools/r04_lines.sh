@@ -17,5 +17,7 @@ run --ready-words 1; run --ready-words 1 --shard 0/8
 run --fir-launch 0 --profile-stride 1000; run --fir-launch 0 --shard 0/8 --profile-stride 1000
 run --workload cfg4 --fir-split 1 --no-verify
 run --workload cfg3 --profile-stride 1
+run --fir-impl 4 --profile-stride 1000; run --fir-impl 4 --workload cfg4 --profile-stride 1000; run --fir-impl 4 --shard 0/8 --profile-stride 1000
+run --fir-lean 0 --profile-stride 1000; run --fir-lean 1 --shard 0/8 --profile-stride 1000
 run --host-buffers
 wc -l $L
