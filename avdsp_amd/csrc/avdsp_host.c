@@ -97,7 +97,7 @@ typedef struct avdsp_ctx {
     int             shard_rank, shard_world;               /* dspRuntimeSetShard: this process's slice of every chain core */
     int             numfreq_at_init;                       /* dspChangeFormat's view of the rate count (see dspRuntimeInit) */
     int             opt_profile_stride;
-    int             opt_overlap, opt_fir_rows, opt_host_split, opt_host_pin, opt_ready_words, opt_lane_hw, opt_fir_split, opt_fir_launch, opt_fir_launch_set, opt_fir_lean, opt_fir_lean_set; /* launch arrangement of the chain kernels (avdsp_hip_prog_set_option) */
+    int             opt_overlap, opt_fir_rows, opt_host_split, opt_host_pin, opt_ready_words, opt_lane_hw, opt_fir_split, opt_fir_launch, opt_fir_launch_set, opt_fir_lean, opt_fir_lean_set, opt_ring_wait; /* launch arrangement of the chain kernels (avdsp_hip_prog_set_option) */
     arrangement     arr[MAX_ARRANGEMENTS]; int arr_next;   /* how the cores / pieces go to the device: [0] whole program, [1..] single cores */
     int             biquad_freq_skip, mantissa;            /* this program's dspBiquadFreqSkip / dspMantissa */
     int             device_ordinal;                        /* the GPU its device copy lives on (-1: none yet) */
@@ -105,7 +105,7 @@ typedef struct avdsp_ctx {
 } avdsp_ctx;
 
 /* no program loaded: options set now are the defaults every program starts from (and keeps following, see dspRuntimeSetOption) */
-static avdsp_ctx g_template = { .opt_lane_hw = 1, .opt_fir_impl = 1, .opt_biquad_impl = 1, .opt_device = -1, .opt_interp_impl = 1, .opt_strand_split = 1, .opt_strand_lanes = 1, .shard_world = 1,
+static avdsp_ctx g_template = { .opt_lane_hw = 1, .opt_ring_wait = 1, .opt_ready_words = -1, .opt_fir_impl = 1, .opt_biquad_impl = 1, .opt_device = -1, .opt_interp_impl = 1, .opt_strand_split = 1, .opt_strand_lanes = 1, .shard_world = 1,
                                 .mantissa = DSP_MANT, .device_ordinal = -1 };
 #define MAX_PROGRAMS 64
 static avdsp_ctx *g_ctx[MAX_PROGRAMS];
@@ -263,6 +263,11 @@ static int set_option_here(const char *key, int value)
         G.opt_fir_lean = value; G.opt_fir_lean_set = 1;
         return 0;
     }
+    if (!strcmp(key, "ring_wait")) {
+        if (G.dev && avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_RING_WAIT, value)) return fail(-10, "%s", avdsp_hip_last_error());
+        G.opt_ring_wait = value != 0;
+        return 0;
+    }
     if (!strcmp(key, "fir_launch")) {
         if (G.dev && avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_FIR_LAUNCH, value)) return fail(-10, "%s", avdsp_hip_last_error());
         G.opt_fir_launch = value; G.opt_fir_launch_set = 1;
@@ -316,6 +321,7 @@ int dspRuntimeGetOption(const char *key)
     if (!strcmp(key, "fir_split"))   return G.opt_fir_split;
     if (!strcmp(key, "fir_launch"))  return G.opt_fir_launch_set ? G.opt_fir_launch : -1;
     if (!strcmp(key, "fir_lean"))    return G.opt_fir_lean_set ? G.opt_fir_lean : -1;
+    if (!strcmp(key, "ring_wait"))   return G.opt_ring_wait;
     if (!strncmp(key, "timing_pairs_", 13) && key[13] >= '0' && key[13] <= '7' && !key[14])      /* of the latest dspRuntimeKernelTime(kind) */
         return G.dev ? avdsp_hip_profile_last_pairs(G.dev, key[13] - '0') : 0;
     if (!strcmp(key, "ready_timeouts")) { device_current(); return G.dev ? avdsp_hip_ready_timeouts(G.dev) : 0; }
@@ -440,7 +446,7 @@ int dspRuntimeInit(opcode_t *codePtr, int maxSize, const int fs, int random, int
         const avdsp_ctx *o = &g_template;
         c->opt_fir_impl = o->opt_fir_impl; c->opt_biquad_impl = o->opt_biquad_impl; c->opt_device = o->opt_device; c->opt_profile = o->opt_profile;
         c->opt_generic = o->opt_generic; c->opt_interp_impl = o->opt_interp_impl; c->opt_strand_split = o->opt_strand_split; c->opt_strand_lanes = o->opt_strand_lanes;
-        c->opt_profile_stride = o->opt_profile_stride; c->opt_overlap = o->opt_overlap; c->opt_fir_rows = o->opt_fir_rows; c->opt_host_split = o->opt_host_split; c->opt_host_pin = o->opt_host_pin; c->opt_ready_words = o->opt_ready_words; c->opt_lane_hw = o->opt_lane_hw; c->opt_fir_split = o->opt_fir_split; c->opt_fir_launch = o->opt_fir_launch; c->opt_fir_launch_set = o->opt_fir_launch_set; c->opt_fir_lean = o->opt_fir_lean; c->opt_fir_lean_set = o->opt_fir_lean_set;
+        c->opt_profile_stride = o->opt_profile_stride; c->opt_overlap = o->opt_overlap; c->opt_fir_rows = o->opt_fir_rows; c->opt_host_split = o->opt_host_split; c->opt_host_pin = o->opt_host_pin; c->opt_ready_words = o->opt_ready_words; c->opt_lane_hw = o->opt_lane_hw; c->opt_fir_split = o->opt_fir_split; c->opt_fir_launch = o->opt_fir_launch; c->opt_fir_launch_set = o->opt_fir_launch_set; c->opt_fir_lean = o->opt_fir_lean; c->opt_fir_lean_set = o->opt_fir_lean_set; c->opt_ring_wait = o->opt_ring_wait;
         c->shard_rank = o->shard_rank; c->shard_world = o->shard_world;
         c->mantissa = DSP_MANT; c->device_ordinal = -1;
         c->code = codePtr;
@@ -1258,7 +1264,7 @@ static core_plan *get_plan_range(int format, opcode_t *core, int end_word)
         avdsp_hip_profile_enable(G.dev, G.opt_profile);
         if (avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_PROFILE_STRIDE, G.opt_profile_stride > 0 ? G.opt_profile_stride : 1) ||
             avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_OVERLAP, G.opt_overlap) || avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_FIR_ROWS, G.opt_fir_rows) ||
-            avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_READY_WORDS, G.opt_ready_words) || avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_LANE_HW, G.opt_lane_hw) || avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_FIR_SPLIT, G.opt_fir_split) || (G.opt_fir_launch_set && avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_FIR_LAUNCH, G.opt_fir_launch)) || (G.opt_fir_lean_set && avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_FIR_LEAN, G.opt_fir_lean)) ||
+            avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_READY_WORDS, G.opt_ready_words) || avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_LANE_HW, G.opt_lane_hw) || avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_FIR_SPLIT, G.opt_fir_split) || (G.opt_fir_launch_set && avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_FIR_LAUNCH, G.opt_fir_launch)) || (G.opt_fir_lean_set && avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_FIR_LEAN, G.opt_fir_lean)) || avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_RING_WAIT, G.opt_ring_wait) ||
             avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_HOST_SPLIT, G.opt_host_split) || avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_HOST_PIN, G.opt_host_pin) ||
             (G.ninst > 1 && avdsp_hip_set_instances(G.dev, G.ninst))) {
             fail(-10, "%s", avdsp_hip_last_error()); lowered_free(&L); drop_device(); return 0;

@@ -32,6 +32,8 @@
  */
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <chrono>
+#include <thread>
 
 #include <cstdarg>
 #include <cstdio>
@@ -279,7 +281,7 @@ __device__ __forceinline__ void chain_ready_publish(unsigned *ready, int cid, un
 {
     __hip_atomic_store(ready + cid, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void chain_ready_wait(unsigned *ready, int cid, unsigned seq, unsigned *timeouts)
+__device__ __forceinline__ void chain_ready_wait(unsigned *ready, int cid, unsigned seq, unsigned *timeouts, bool acquire = true)
 {
     unsigned spins = 0;
     while ((int)(__hip_atomic_load(ready + cid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0) {
@@ -289,7 +291,10 @@ __device__ __forceinline__ void chain_ready_wait(unsigned *ready, int cid, unsig
             break;
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    /* (the acquire invalidates the XCD's L2 for every wave that passes here -- 20 us on every launch, measured.  Where the word was
+     * set by a kernel BEHIND the cascade, nothing of the block can be in this XCD's L2 from before the cascade's write-back: no wave
+     * reads a chain's new ring positions before it has seen the chain's word, and the launch began with an invalidate of its own) */
+    if (acquire) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
 struct BlockIO {
@@ -915,7 +920,7 @@ __global__ __launch_bounds__(kBlock) void biquad_row(const BiquadArgs a)
     const bool dosat = FMT == 6 && c_sat && !to_ring;
     unsigned ooff = 0;
     const bool wt = a.ready != nullptr;               /* the launch's rings are handed over through ready words: write-through stores (ring_put) */
-    auto store_lean = [&](unsigned w) __attribute__((always_inline)) {
+    auto store_lean = [&](unsigned w, auto wide_c) __attribute__((always_inline)) {
         const unsigned v = dosat ? __float_as_uint(__builtin_amdgcn_fmed3f(__uint_as_float(w), -1.0f, 1.0f)) : w;     /* = saturate_f32_0db for every value but a NaN (the replay's business) */
         if (have_chain) {
             if (wt) {
@@ -925,7 +930,7 @@ __global__ __launch_bounds__(kBlock) void biquad_row(const BiquadArgs a)
                 *reinterpret_cast<unsigned *>(obase + ooff) = v;
                 if (any_ring) *reinterpret_cast<unsigned *>(obase + ooff + omirror) = v;
             }
-            if (any_wide && wbase) {
+            if (decltype(wide_c)::value && wbase) {
                 const unsigned woff8 = ((ooff + 12u) & owrap) * 2u;          /* (frame position + 3) mod R, in doubles */
                 const double wd = mulop(__uint_as_float(v));
                 if (wt) {
@@ -1049,17 +1054,17 @@ __global__ __launch_bounds__(kBlock) void biquad_row(const BiquadArgs a)
     };
     /* six steady batches with every queue slot and both register sets under names of their own (a queue that shifts moves
      * registers that loads are still in flight to: see biquad_pipe) */
-    auto batch_named = [&](int b, const unsigned (&x)[16], unsigned (&xn)[16], unsigned &rslot, auto lean_c) __attribute__((always_inline)) {
+    auto batch_named = [&](int b, const unsigned (&x)[16], unsigned (&xn)[16], unsigned &rslot, auto lean_c, auto wide_c) __attribute__((always_inline)) {
         if (b >= 12 && b < 36) BQ_STAMP(2 + b - 12);
         stage((b + 1) & 1, rslot);                      /* the raw word of batch b+1 leaves its slot, the fetch of b+4 takes it */
         rslot = fetch_next();
         take((b + 1) & 1, xn);
         const unsigned w = steady_steps(x);
-        if constexpr (decltype(lean_c)::value) store_lean(w); else flush(16 * b, w);
+        if constexpr (decltype(lean_c)::value) store_lean(w, wide_c); else flush(16 * b, w);
     };
-    auto six = [&](int b, auto lean_c) __attribute__((always_inline)) {
-        batch_named(b, xa, xb, r1, lean_c);     batch_named(b + 1, xb, xa, r2, lean_c); batch_named(b + 2, xa, xb, r3, lean_c);
-        batch_named(b + 3, xb, xa, r1, lean_c); batch_named(b + 4, xa, xb, r2, lean_c); batch_named(b + 5, xb, xa, r3, lean_c);
+    auto six = [&](int b, auto lean_c, auto wide_c) __attribute__((always_inline)) {
+        batch_named(b, xa, xb, r1, lean_c, wide_c);     batch_named(b + 1, xb, xa, r2, lean_c, wide_c); batch_named(b + 2, xa, xb, r3, lean_c, wide_c);
+        batch_named(b + 3, xb, xa, r1, lean_c, wide_c); batch_named(b + 4, xa, xb, r2, lean_c, wide_c); batch_named(b + 5, xb, xa, r3, lean_c, wide_c);
     };
     const int first_steady = (2 * L + 1 + 15) / 16;     /* batches with 16 b >= 2 L + 1 ... */
     const int end_steady = B >= 16 ? (B - 16) / 16 + 1 : 0;      /* ... and 16 b + 15 <= B - 1 */
@@ -1071,9 +1076,11 @@ __global__ __launch_bounds__(kBlock) void biquad_row(const BiquadArgs a)
         if (lean) {
             const int n0 = 16 * b + rp - (1 + 2 * L);   /* >= 0 from the first steady batch on */
             ooff = to_ring ? ((unsigned)(ring_l.wpos + n0) & (unsigned)(ring_l.R - 1)) * 4u : (unsigned)n0 * (unsigned)io_l.out_stride * 4u;
-            for (; b + 6 <= end_steady; b += 6) six(b, std::true_type{});
+            /* (the operand ring's stores are a loop of their own: where no plan keeps one -- the default -- the steady loop is the plain one) */
+            if (any_wide) { for (; b + 6 <= end_steady; b += 6) six(b, std::true_type{}, std::true_type{}); }
+            else for (; b + 6 <= end_steady; b += 6) six(b, std::true_type{}, std::false_type{});
         } else
-            for (; b + 6 <= end_steady; b += 6) six(b, std::false_type{});
+            for (; b + 6 <= end_steady; b += 6) six(b, std::false_type{}, std::false_type{});
     }
     BQ_STAMP(27);
     for (; b < nb; b++) batch_canon(b);
@@ -1621,6 +1628,7 @@ struct FirTileArgs {
     const double *taps64; int pitch64;       /* f64 copy of the taps, [chain id][pitch64] */
     BlockIO io;
     unsigned *ready; unsigned seq; unsigned *timeouts;      /* chain_ready_wait: null = the launch is ordered behind its cascades by the stream / an event */
+    int ready_acquire;                                      /* 0: the words were set by a kernel behind the cascade (no acquire needed, chain_ready_wait) */
 #ifdef AVDSP_FIR_STAMPS
     unsigned long long *stamps;              /* diagnostic build (tools/fir_timeline.py): 32 s_memtime stamps per wave */
 #endif
@@ -1710,7 +1718,7 @@ __global__ __launch_bounds__(kBlock, 2) void fir_tile(const FirTileArgs a)
     const int cid = __builtin_amdgcn_readfirstlane(a.group[slot]);
     const avdsp_chain c = a.chains[cid];
     const int T = __builtin_amdgcn_readfirstlane(c.fir_taps);
-    if (a.ready && c.nsec) chain_ready_wait(a.ready, cid, a.seq, a.timeouts);       /* the chain's cascade of this launch has left its block in the ring */
+    if (a.ready && c.nsec) chain_ready_wait(a.ready, cid, a.seq, a.timeouts, a.ready_acquire != 0);       /* the chain's cascade of this launch has left its block in the ring */
     double *hs = lds + (size_t)wv * G::LDS_DOUBLES, *ws = hs + 2 * G::HLEN;     /* taps images at hs and hs + HLEN */
     const double *hbuf = a.taps64 + (size_t)cid * a.pitch64;
     const float *ringrow = ring_row(a.ring, cid);
@@ -2314,7 +2322,7 @@ __global__ __launch_bounds__(kBlock, BIG ? 1 : 2) void fir_flow(const FirTileArg
     const int cid = __builtin_amdgcn_readfirstlane(a.group[slot]);
     const avdsp_chain c = a.chains[cid];
     const int T = __builtin_amdgcn_readfirstlane(c.fir_taps);
-    if (a.ready && c.nsec) chain_ready_wait(a.ready, cid, a.seq, a.timeouts);
+    if (a.ready && c.nsec) chain_ready_wait(a.ready, cid, a.seq, a.timeouts, a.ready_acquire != 0);
     double *hs = lds + (size_t)wv * G::LDS_DOUBLES, *ws = hs + 2 * G::HLEN;
     const double *hbuf = a.taps64 + (size_t)cid * a.pitch64;
     const char *ring8 = reinterpret_cast<const char *>(wide_row(a.ring, cid));
@@ -3318,6 +3326,7 @@ struct avdsp_hip_prog {
     unsigned *d_alias = nullptr; size_t alias_cap = 0;    /* copy of the input block of an in-place device call (avdsp_hip_run_block) */
     /* N instances of the program (avdsp_hip_run_levels_instances): copies 1 .. N-1 of the device state; instance 0 is the program's own */
     int inst_n = 1; bool inst_valid = false;
+    bool ring_wait_host = true;              /* "ring_wait": the host (1), not the cascades' stream (0), waits for the FIR three blocks back (launch_all) */
     bool call_shown = false;                 /* inside a dspRuntimeBlockAll call whose shared window columns have been copied (show_through) */
     int *d_inst_buf = nullptr; TpdfGlobals *d_inst_tpdf = nullptr; unsigned *d_inst_frame = nullptr; int *d_inst_seq = nullptr;
     int inst_frame_words = 0, inst_seq_frames = 0;
@@ -3363,7 +3372,10 @@ struct avdsp_hip_prog {
     hipEvent_t launch_ev[16] = {};       /* ... mode 2: a small ring of start / stop event pairs */
     unsigned launch_ev_next = 0;
     int lane_hw = 1;                     /* formats 3 / 5: the hardware's toward-zero product where it is the reference's (fir_lane_hw, chain_rows' fast steps); 0: the integer products throughout */
-    int ready_words = 0;                 /* "overlap": the FIR waits for its cascades through the plans' ready words (in the kernel) instead of an event between the two queues: measured slower, off by default */
+    int ready_words = -1;                /* "overlap": how the FIR of a block finds its cascades' block in the rings: 0 an event between the two queues, 1 ready words published by
+                                            the cascade's waves (slower everywhere), 2 ready words set by a kernel behind the cascade; -1 (default): 2 where the FIR is the
+                                            bound, else 0 (launch_all) */
+    int ready_mode_now = 0;              /* (the mode of the launch being made) */
     unsigned *d_ready_timeouts = nullptr;        /* waves whose bounded wait for a ready word ran out (never, see chain_ready_wait) */
     int *d_tag_prev = nullptr;           /* tagoutput: the plugin's `previoussample` */
     /* host-pointer block calls: the caller's buffers pinned in place (cache), copies and kernels on three streams */
@@ -3512,7 +3524,8 @@ int launch_biquad(avdsp_hip_prog *prog, Plan &pl, const Plan::Group &g, const in
     BiquadArgs a{};
     a.buf = prog->d_buf; a.chains = pl.d_chains; a.sec_coef = pl.d_sec_coef; a.sec_state = pl.d_sec_state;
     a.group = ids; a.ngroup = n; a.nsec = g.nsec; a.ring = plan_ring(pl); a.io = io;
-    a.ready = with_ready ? pl.d_ready : nullptr; a.seq = pl.seq;      /* (a launch whose FIR waits for the words; its ring stores are then write-through) */
+    a.ready = with_ready ? pl.d_ready : nullptr; a.seq = pl.seq;
+      /* (a launch whose FIR waits for the words; its ring stores are then write-through) */
 #ifdef AVDSP_BQ_STAMPS
     {
         static unsigned long long *d_stamps = nullptr;
@@ -3572,7 +3585,7 @@ int launch_fir_tile(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, Block
     FirTileArgs a{};
     a.buf = prog->d_buf; a.chains = pl.d_chains; a.group = ids; a.ngroup = n;
     a.ring = plan_ring(pl); a.io = io; a.taps64 = pl.d_taps64; a.pitch64 = pl.pitch64;
-    if (wait_ready) { a.ready = pl.d_ready; a.seq = pl.seq; a.timeouts = prog->d_ready_timeouts; }
+    if (wait_ready) { a.ready = pl.d_ready; a.seq = pl.seq; a.timeouts = prog->d_ready_timeouts; a.ready_acquire = prog->ready_mode_now != 2; }
     const int nwg = (n * TileGeom<R, BIG>::WPC * (SPLIT ? 2 : 1) + 3) / 4;
     a.per_xcd = (nwg + 7) / 8;
     const size_t lds = (size_t)4 * TileGeom<R, BIG>::LDS_DOUBLES * sizeof(double) + 64;      /* + the four words the waves exchange at the end */
@@ -3638,7 +3651,7 @@ int launch_fir_flow(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, Block
     FirTileArgs a{};
     a.buf = prog->d_buf; a.chains = pl.d_chains; a.group = ids; a.ngroup = n;
     a.ring = plan_ring(pl); a.io = io; a.taps64 = pl.d_taps64; a.pitch64 = pl.pitch64;
-    if (wait_ready) { a.ready = pl.d_ready; a.seq = pl.seq; a.timeouts = prog->d_ready_timeouts; }
+    if (wait_ready) { a.ready = pl.d_ready; a.seq = pl.seq; a.timeouts = prog->d_ready_timeouts; a.ready_acquire = prog->ready_mode_now != 2; }
     const int nwg = (n * FlowGeom<R, BIG>::WPC + 3) / 4;
     a.per_xcd = (nwg + 7) / 8;
     const size_t lds = (size_t)4 * FlowGeom<R, BIG>::LDS_DOUBLES * sizeof(double) + 64;
@@ -3736,6 +3749,16 @@ int launch_fir(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, BlockIO io
  *                 everything the caller enqueues after the call (it may overwrite the input block).
  * Only when every cascade feeds a FIR (a cascade that stores straight to the output block would write it from the
  * side stream).                                                                                                */
+/* "ready_words" 2: the words of a launch's FIR chains set by a kernel of its own BEHIND the cascade on the cascades' stream -- the
+ * kernel boundary in front of it is the release (the cascade's ring stores are written back and visible), so the cascade pays
+ * nothing (mode 1: write-through stores and a drain per wave), and the FIR's stream carries no wait packet: a FIR follows the
+ * previous one like any kernel of a queue, its waves look at their chain's word (long set: the cascades run a block ahead). */
+__global__ void ready_set(unsigned *ready, const int *ids, int n, unsigned seq)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) ready[ids[i]] = seq;
+}
+
 static int overlap_ready(avdsp_hip_prog *prog)
 {
     if (prog->s_bq) return 0;
@@ -3757,13 +3780,46 @@ int launch_all(avdsp_hip_prog *prog, Plan &pl, BlockIO io, int fir_impl, int biq
     if (under) {
         if (overlap_ready(prog)) return -1;
         /* fir_tile finds its cascades' blocks through the ready words; the other FIR kernels wait for the cascades' event */
-        const bool words = prog->ready_words && fir_impl == 1 && pl.d_ready && prog->d_ready_timeouts;
+        const bool can_words = (fir_impl == 1 || fir_impl == 4) && pl.d_ready && prog->d_ready_timeouts;
+        /* Mode 2 takes the wait packet off the FIRs' stream (a FIR follows the previous one like any kernel of a queue): 4096 chains
+         * 0.5025 -> 0.4980 ms per step.  Where the cascades are the bound that packet's ~9 us are bubbles they live on: 2048 chains
+         * 0.2594 -> 0.2686, 512 chains 0.0864 -> 0.0933 (one box) -- so by default only where a launch is more than one round of waves */
+        const int rw = prog->ready_words >= 0 ? prog->ready_words : ((long long)pl.n_fir * pl.max_taps >= 12000000ll ? 2 : 0);
+        const bool behind = rw == 2 && can_words;                            /* a kernel behind the cascade publishes */
+        const bool words = (rw == 1 && fir_impl == 1 && can_words) || behind;      /* the FIR looks at the words: no event wait on its stream */
+        prog->ready_mode_now = behind ? 2 : words ? 1 : 0;
+        const bool wt = words && !behind;                                  /* the cascade's own waves publish: write-through ring stores */
         const int slot = (int)(prog->blk % avdsp_hip_prog::kAhead);
-        if (prog->ev_fir_set[slot]) HIP_TRY(hipStreamWaitEvent(prog->s_bq, prog->ev_fir[slot], 0));   /* FIR k-3 */
+        if (prog->ev_fir_set[slot]) {                           /* FIR k-3: the ring positions this block's cascade appends are free once it has read its window */
+            /* The HOST waits for it ("ring_wait" 1, the default), not the cascades' stream.  A wait packet costs a queue ~9 us even when
+             * its signal is long down, and the cascades' stream of a small shard has none to spare: a cascade beside an MFMA stream
+             * lasts about a step, so with the packet in front of every cascade that stream's period -- not the FIRs' -- was the step
+             * (512 chains: cascade 88.7 + packet ~9 = the 98 us measured; tools/step_gaps.py), and a run settled in that state or in
+             * the one where the cascades are a block ahead (86 us) by chance.  The host is the natural place: it only has to stay
+             * within three blocks of the device, and in steady state that IS this wait.  Bounded (1 ms), then the packet after all:
+             * a caller whose stream waits on something it will enqueue later must not hang here. */
+            bool done = false;
+            if (prog->ring_wait_host) {
+                const auto t0 = std::chrono::steady_clock::now();
+                for (;;) {
+                    const hipError_t q = hipEventQuery(prog->ev_fir[slot]);
+                    if (q == hipSuccess) { done = true; break; }
+                    (void)hipGetLastError();
+                    if (q != hipErrorNotReady) break;
+                    if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(1)) break;
+                    std::this_thread::yield();
+                }
+            }
+            if (!done) HIP_TRY(hipStreamWaitEvent(prog->s_bq, prog->ev_fir[slot], 0));
+        }
         if (prog->input_ready) HIP_TRY(hipStreamWaitEvent(prog->s_bq, prog->input_ready, 0));           /* (queued host blocks: the copy of this block) */
         for (size_t gi = 0; gi < pl.bq.size(); gi++) {        /* (the last group's kernel carries the event: the stream is in order) */
             auto &g = pl.bq[gi];
-            if (launch_biquad<FMT>(prog, pl, g, g.d_ids, g.n, io, biquad_impl, prog->s_bq, !words && gi + 1 == pl.bq.size() ? prog->ev_bq[slot] : nullptr, words)) return -1;
+            if (launch_biquad<FMT>(prog, pl, g, g.d_ids, g.n, io, biquad_impl, prog->s_bq, !words && gi + 1 == pl.bq.size() ? prog->ev_bq[slot] : nullptr, wt)) return -1;
+        }
+        if (behind) {
+            hipLaunchKernelGGL(ready_set, dim3((unsigned)((pl.n_fir + kBlock - 1) / kBlock)), dim3(kBlock), 0, prog->s_bq, pl.d_ready, pl.d_fir_ids, pl.n_fir, pl.seq);
+            HIP_TRY(hipGetLastError());
         }
         if (prog->overlap >= 2) {
             /* the FIRs of consecutive blocks on two streams of the library's own, in turn: FIR k+1 needs nothing of FIR k, and on one
@@ -5260,10 +5316,11 @@ int avdsp_hip_prog_set_option(avdsp_hip_prog *prog, int key, int value)
     HIP_TRY(hipDeviceSynchronize());                    /* nothing in flight when the launch arrangement changes */
     switch (key) {
     case AVDSP_OPT_OVERLAP:  prog->overlap = value; for (bool &f : prog->ev_fir_set) f = false; return 0;
-    case AVDSP_OPT_READY_WORDS: prog->ready_words = value != 0; return 0;
+    case AVDSP_OPT_READY_WORDS: if (value < -1 || value > 2) return set_err("ready_words: -1 (by plan), 0 (events), 1 (the cascade's waves publish) or 2 (a kernel behind the cascade publishes)"); prog->ready_words = value; return 0;
     case AVDSP_OPT_LANE_HW: prog->lane_hw = value != 0; return 0;
     case AVDSP_OPT_FIR_SPLIT: prog->fir_split = value != 0; return 0;
     case AVDSP_OPT_FIR_LEAN: if (value < -1 || value > 1) return set_err("fir_lean: -1 (auto), 0 or 1"); prog->fir_lean = value; return 0;
+    case AVDSP_OPT_RING_WAIT: prog->ring_wait_host = value != 0; return 0;
     case AVDSP_OPT_FIR_LAUNCH: if (value < -1 || value > 2) return set_err("fir_launch: -1 (auto), 0, 1 or 2"); prog->fir_launch_mode = value; return 0;
     case AVDSP_OPT_FIR_ROWS: if (value != 0 && value != 1 && value != 2 && value != 4) return set_err("fir_tile row tiles: 0 (auto), 1, 2 or 4");
                              prog->fir_rows = value; return 0;

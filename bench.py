@@ -250,8 +250,9 @@ def main():
     ap.add_argument("--fir-impl", type=int, default=1, help="0 the reference's tap loop, 1 fir_tile (default), 2 fir_mfma (round 1), 3 fir_stream, 4 fir_flow (DESIGN.md 4.2)")
     ap.add_argument("--biquad-impl", type=int, default=1)
     ap.add_argument("--overlap", type=int, default=1, help="cascade of the next block under the FIR of this one (the blocks are resident in HBM, which is that mode's contract): 0 off, 1 on, 2 also the FIRs of consecutive blocks on two streams in turn")
-    ap.add_argument("--ready-words", type=int, default=0, help="under --overlap: 1 the FIR waits for its cascades through per-chain ready words inside the kernel, 0 (default) through an event between the two queues")
+    ap.add_argument("--ready-words", type=int, default=-1, help="under --overlap, how a block's FIR finds its cascades' block: 0 an event between the two queues, 1 per-chain ready words published by the cascade's waves, 2 ready words set by a kernel behind the cascade (no wait packet on the FIRs' stream); -1 (default) the library's choice by plan: 2 where the FIR is the bound, else 0")
     ap.add_argument("--fir-launch", type=int, default=-1, help="how the overlap mode enqueues its FIR launches: -1 the library's choice (default), 0 plain + recorded event, 1 the event on the dispatch's completion signal, 2 start and stop events on the dispatch")
+    ap.add_argument("--ring-wait", type=int, default=1, help="under --overlap: who waits for the FIR three blocks back before a cascade reuses its ring positions: 1 the host (default), 0 the cascades' stream (a wait packet in front of every cascade)")
     ap.add_argument("--fir-lean", type=int, default=-1, help="fir_tile's lean chunk boundary: -1 the library's choice by plan (default), 0 never, 1 always")
     ap.add_argument("--fir-split", type=int, default=0, help="1: fir_tile launches of at most a tile per SIMD (cfg4) cut every tile's taps over two waves -- sums within 1e-6, NOT the reference's bits (so --no-verify's hash check is replaced by nothing: use for the A/B only)")
     ap.add_argument("--fir-rows", type=int, default=-1, help="fir_tile row tiles per wave: 0 auto, 1, 2, 4")
@@ -318,6 +319,7 @@ def main():
             rr.set_option("fir_launch", args.fir_launch)
         if args.fir_lean >= 0:
             rr.set_option("fir_lean", args.fir_lean)
+        rr.set_option("ring_wait", args.ring_wait)
         if args.fir_rows >= 0:
             rr.set_option("fir_rows", args.fir_rows)
         if args.host_split >= 0:
@@ -589,7 +591,7 @@ def main():
             "config": {"workload": f"{args.workload}: {C} ch x ({S} biquads + {T}-tap FIR), block {B} frames, "
                                    f"DSP_FORMAT {fmt}; {shard_txt}, no data-path collective",
                        "channels": C, "channels_per_gpu": Cl, "sections": S, "taps": T, "block": B, "format": fmt,
-                       "overlap": r.get_option("overlap"), "ready_words": r.get_option("ready_words"), "fir_split": r.get_option("fir_split"), "fir_launch": r.get_option("fir_launch"), "fir_lean": r.get_option("fir_lean"), "settle_s": args.settle, "profile_stride": stride},
+                       "overlap": r.get_option("overlap"), "ready_words": r.get_option("ready_words"), "fir_split": r.get_option("fir_split"), "fir_launch": r.get_option("fir_launch"), "fir_lean": r.get_option("fir_lean"), "ring_wait": r.get_option("ring_wait"), "settle_s": args.settle, "profile_stride": stride},
             "roofline": roof,
             "hbm_frac_step": step_bytes / step_s / 1e9 / PEAK_HBM_GBS,
             "kernels_ms": {"biquad": bq_raw, "fir": fir_raw, "event_pair": pair_ms,

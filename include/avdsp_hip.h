@@ -218,7 +218,7 @@ int avdsp_hip_plan_strands(const avdsp_hip_prog *prog, int plan);      /* strand
  * block k (side stream; see launch_all in avdsp_kernels.hip) -- the caller then guarantees that a block's input is
  * complete in memory when the call is made.                                                                     */
 enum { AVDSP_OPT_OVERLAP = 0, AVDSP_OPT_PROFILE_STRIDE = 1, AVDSP_OPT_FIR_ROWS = 3, AVDSP_OPT_HOST_SPLIT = 4, AVDSP_OPT_HOST_PIN = 5,
-       AVDSP_OPT_READY_WORDS = 6, AVDSP_OPT_LANE_HW = 7, AVDSP_OPT_FIR_SPLIT = 8, AVDSP_OPT_FIR_LAUNCH = 9, AVDSP_OPT_FIR_LEAN = 10 };
+       AVDSP_OPT_READY_WORDS = 6, AVDSP_OPT_LANE_HW = 7, AVDSP_OPT_FIR_SPLIT = 8, AVDSP_OPT_FIR_LAUNCH = 9, AVDSP_OPT_FIR_LEAN = 10, AVDSP_OPT_RING_WAIT = 11 };
 /* FIR_LEAN: fir_tile's chunk boundary with a third of the vector instructions: -1 by the plan (default), 0 never, 1 always. */
 /* FIR_LAUNCH: how the overlap mode enqueues a FIR launch (avdsp_hip_prog::fir_launch_mode): -1 auto (default), 0, 1, 2. */
 /* FIR_SPLIT 1 (opt-in; default 0): a fir_tile launch that leaves a SIMD one wave at most (256 chains x 4096 taps) cuts every tile's taps

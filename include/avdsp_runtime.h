@@ -210,7 +210,12 @@ int dspRuntimeStrandInfo(int format, opcode_t *core, int *strands, int *ops_per_
  * (stream order no longer covers it); 2 = also the FIRs of consecutive blocks on two streams in turn, so that one starts while the other's
  * last workgroups leave (worth 5 % on a 4096-channel program, a loss below ~2000 channels) -- the caller then also guarantees that the
  * OUTPUT block of a call is not one an earlier call's FIR may still be writing (the caller's stream still waits for every block's end).
- * Results are identical in every mode.                                                          */
+ * Results are identical in every mode.  Under "overlap": "ring_wait" 1 (default) = the HOST waits (at most 1 ms, then it leaves it to the
+ * stream after all) until the FIR three blocks back has ended before it enqueues a block's cascade -- the call then returns no more than
+ * three blocks ahead of the device, and the cascades' stream carries no wait packet (worth 10 % on a 512-channel shard); 0 = that stream
+ * waits.  "ready_words" = how a block's FIR finds its cascades' block: 0 an event between the two queues, 1 words published by the
+ * cascade's waves and polled by the FIR's (slower), 2 words set by a kernel behind the cascade (no wait packet on the FIRs' stream),
+ * -1 (default) = 2 where the FIR is the bound, else 0.                                              */
 int dspRuntimeSetOption(const char *key, int value);
 int dspRuntimeGetOption(const char *key);
 

@@ -304,13 +304,16 @@ def test_overlap_mode_is_bit_identical(fmt, C, S, T, fir_impl):
     o = po.OracleProgram(fmt, prog)
     want = o.run_block(x, C, C, block=B)
     # overlap 2: also the FIRs of consecutive blocks on two streams in turn.  ready_words 1: fir_tile finds its cascades' blocks through
-    # the per-chain ready words, polled in the kernel; 0 (the default): through an event between the two queues
-    for overlap, ready_words in ((2, 1), (2, 0), (1, 1), (1, 0), (0, 1)):
+    # the per-chain ready words, polled in the kernel, published by the cascade's waves; 2: set by a kernel behind the cascade (no
+    # wait packet on the FIRs' stream: the library's choice where the FIR is the bound); 0: an event between the two queues;
+    # ring_wait 0 / 1: the cascades' stream / the host waits for the FIR three blocks back
+    for overlap, ready_words, ring_wait in ((2, 1, 1), (2, 0, 1), (1, 1, 1), (1, 0, 1), (1, 2, 1), (1, 2, 0), (2, 2, 1), (1, 0, 0), (1, -1, 1), (0, 1, 1)):
         r = rt.Runtime(fmt, prog)
         r.set_option("fir_impl", fir_impl)                    # fir_tile / fir_stream (the cascade then feeds the operand ring as well)
         r.set_option("overlap", overlap)
         r.set_option("ready_words", ready_words)
-        assert r.get_option("overlap") == overlap and r.get_option("ready_words") == ready_words
+        r.set_option("ring_wait", ring_wait)
+        assert r.get_option("overlap") == overlap and r.get_option("ready_words") == ready_words and r.get_option("ring_wait") == ring_wait
         xd = [torch.from_numpy(x[k * B:(k + 1) * B].copy()).cuda() for k in range(nb)]
         yd = [torch.zeros((B, C), dtype=xd[0].dtype, device="cuda") for _ in range(nb)]
         torch.cuda.synchronize()                             # the mode's contract: inputs complete when the call is made
@@ -319,7 +322,7 @@ def test_overlap_mode_is_bit_identical(fmt, C, S, T, fir_impl):
             r.run_block_device(xd[k].data_ptr(), C, C, yd[k].data_ptr(), C, 0, B, st)
         torch.cuda.synchronize()
         got = np.concatenate([y.cpu().numpy() for y in yd])
-        assert (words(got) == words(want)).all(), f"overlap={overlap} ready_words={ready_words}"
+        assert (words(got) == words(want)).all(), f"overlap={overlap} ready_words={ready_words} ring_wait={ring_wait}"
         assert (r.sync_state() == o.state).all()
         assert r.get_option("ready_timeouts") == 0            # no wave ever gave up waiting for a ready word
         r.release()
@@ -330,6 +333,7 @@ def test_overlap_mode_is_bit_identical(fmt, C, S, T, fir_impl):
         r.set_option("fir_impl", fir_impl)
         r.set_option("overlap", overlap)
         r.set_option("ready_words", ready_words)
+        r.set_option("ring_wait", ring_wait)
         y1 = torch.zeros((B, C), dtype=xd[0].dtype, device="cuda")
         outs = []
         for k in range(nb):
@@ -339,7 +343,8 @@ def test_overlap_mode_is_bit_identical(fmt, C, S, T, fir_impl):
         got = np.concatenate([y.cpu().numpy() for y in outs])
         assert (words(got) == words(want)).all(), f"overlap={overlap} ready_words={ready_words}, one output buffer"
         r.set_option("overlap", 0)
-        r.set_option("ready_words", 0)
+        r.set_option("ready_words", -1)
+        r.set_option("ring_wait", 1)
         r.set_option("fir_impl", 1)
         r.release()
 

@@ -14,6 +14,8 @@ run --workload cfg2; run --workload cfg3; run --workload cfg3i; run --workload c
 run --workload cfg2 --profile-stride 1000; run --workload cfg3 --profile-stride 1000; run --workload cfg4 --profile-stride 1000
 run --overlap 2
 run --ready-words 1; run --ready-words 1 --shard 0/8
+run --ready-words 0 --ring-wait 0 --profile-stride 1000; run --ready-words 0 --ring-wait 0 --shard 0/8 --profile-stride 1000; run --ready-words 0 --ring-wait 0 --shard 0/8 --profile-stride 1000
+run --ready-words 2 --shard 0/8 --profile-stride 1000; run --ready-words 2 --shard 0/2 --profile-stride 1000; run --ready-words 0 --profile-stride 1000
 run --fir-launch 0 --profile-stride 1000; run --fir-launch 0 --shard 0/8 --profile-stride 1000
 run --workload cfg4 --fir-split 1 --no-verify
 run --workload cfg3 --profile-stride 1
