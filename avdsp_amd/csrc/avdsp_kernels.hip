@@ -3784,7 +3784,9 @@ int launch_all(avdsp_hip_prog *prog, Plan &pl, BlockIO io, int fir_impl, int biq
         /* Mode 2 takes the wait packet off the FIRs' stream (a FIR follows the previous one like any kernel of a queue): 4096 chains
          * 0.5025 -> 0.4980 ms per step.  Where the cascades are the bound that packet's ~9 us are bubbles they live on: 2048 chains
          * 0.2594 -> 0.2686, 512 chains 0.0864 -> 0.0933 (one box) -- so by default only where a launch is more than one round of waves */
-        const int rw = prog->ready_words >= 0 ? prog->ready_words : ((long long)pl.n_fir * pl.max_taps >= 12000000ll ? 2 : 0);
+        /* (not with "overlap" 2: two FIRs in flight, the later one's waves would sit on their SIMDs looking at words of a cascade that
+         * both of them starve -- 0.496 -> 0.547 ms) */
+        const int rw = prog->ready_words >= 0 ? prog->ready_words : (prog->overlap == 1 && (long long)pl.n_fir * pl.max_taps >= 12000000ll ? 2 : 0);
         const bool behind = rw == 2 && can_words;                            /* a kernel behind the cascade publishes */
         const bool words = (rw == 1 && fir_impl == 1 && can_words) || behind;      /* the FIR looks at the words: no event wait on its stream */
         prog->ready_mode_now = behind ? 2 : words ? 1 : 0;
