@@ -4412,13 +4412,11 @@ static int launch_generic(avdsp_hip_prog *prog, Plan &pl, BlockIO io, hipStream_
     a.rows_whole = rows_whole(pl, io);
     if (tpdf_seq_for(prog, a, io.nframes)) return -1;
     if (windows_overlap(io) && !needs_whole(pl) && !strands_take(pl, io)) {
-        /* the frame-parallel kernel with slot lists behind the copy of the shared columns, where the core fits it that way */
-        GenericArgs b = a;
-        b.rows_whole = 0;
-        if (wave_plan_fits(prog, pl, io, b)) {
-            if (!prog->call_shown && launch_show_through(io, stream)) return -1;
-            a = b;
-        }
+        /* behind the copy of the shared columns either interpreter kernel delivers its core's slots only.  (Both: inside a
+         * dspRuntimeBlockAll call the pieces of a level run side by side, and a frame-by-frame piece that wrote whole rows back would
+         * overwrite what its neighbours store meanwhile -- found by the overlapping-window sweep, tests/dev/gpu_wave_sweep.py.) */
+        if (!prog->call_shown && launch_show_through(io, stream)) return -1;
+        a.rows_whole = 0;
     }
     if (strands_take(pl, io)) {
         ProfileScope scope(prog, stream, AVDSP_KERNEL_STRANDS); scope.begin();

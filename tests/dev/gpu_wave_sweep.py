@@ -11,6 +11,9 @@ frames = int(sys.argv[3]) if len(sys.argv) > 3 else 300
 use_all = len(sys.argv) > 4 and sys.argv[4] == "all"
 import os
 BLOCKS = [int(b) for b in os.environ.get("AVDSP_SWEEP_BLOCKS", "1,64,0").split(",")]      # 0 = all frames in one block
+# AVDSP_SWEEP_OVERLAP=1: an output window IO 0 .. 47 that contains the input window (IO 32 .. 39): the shared columns show the input
+# unless the program stores them (show_through in front of the call's launches)
+OUT_STRIDE = 48 if os.environ.get("AVDSP_SWEEP_OVERLAP") == "1" else N_OUT
 levels_hist = {}
 bad = n = wave = scalar = 0
 for seed in range(int(sys.argv[1]), int(sys.argv[2])):
@@ -25,12 +28,12 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
         r.set_option("profile", 1)
         if use_all:
             block = max(block, 2)
-            want = o.run_block(x, N_OUT, IN_BASE, 0, block=block, frame=np.zeros(4096, dtype=np.uint32))
-            got = r.run_block_all(x, N_OUT, IN_BASE, 0, block=block)
+            want = o.run_block(x, OUT_STRIDE, IN_BASE, 0, block=block, frame=np.zeros(4096, dtype=np.uint32))
+            got = r.run_block_all(x, OUT_STRIDE, IN_BASE, 0, block=block)
             key = (r.get_option("cores"), r.get_option("levels")); levels_hist[key] = levels_hist.get(key, 0) + 1
         else:
-            want = o.run_block(x, N_OUT, IN_BASE, 0, scratch_len=48, block=block)
-            got = r.run_block(x, N_OUT, IN_BASE, 0, block=block)
+            want = o.run_block(x, OUT_STRIDE, IN_BASE, 0, scratch_len=48, block=block)
+            got = r.run_block(x, OUT_STRIDE, IN_BASE, 0, block=block)
         r.sync_state(); nn = int(prog[1]) + int(prog[2]); n += 1
         w = r.kernel_time(5)[1]; s = r.kernel_time(3)[1]
         wave += w; scalar += s

@@ -30,3 +30,36 @@ def test_random_strand_shapes_slice(lo):
     from tests.dev.gpu_strand_sweep import run
     n, bad, _ = run(lo, lo + 20)
     assert n > 0 and not bad, bad
+
+
+@pytest.mark.parametrize("lo", [0, 240, 260, 280, 300, 480, 560, 620, 820, 880, 940])      # (seeds 241 ... 956: programs with a frame-by-frame piece beside frame-parallel ones,
+def test_random_programs_with_windows_that_share_io_numbers(lo):                          #  which a first version of show_through got wrong: a whole-row write-back beside its neighbours)
+    """random multi-core programs (tests/fuzz_programs.py) through dspRuntimeBlockAll with an output window IO 0 .. 47 that contains
+    the input window IO 32 .. 39: the shared columns show the input unless the program stores them (the reference's one samples[]
+    frame; on the device: show_through in front of the call's launches, every launch moves its core's slots only).  Five formats,
+    blocks of 2 / 64 / all frames, outputs and the whole data area against the oracle."""
+    import numpy as np
+    from avdsp_amd import progbuilder as pb
+    from oracle import pyoracle as po
+    from tests.fuzz_programs import IN_BASE, N_IN, random_program
+    frames, out_stride = 200, 48
+    n = 0
+    for seed in range(lo, lo + 20):
+        for fmt in (2, 3, 4, 5, 6):
+            prog = random_program(seed, fmt)
+            fs, block = [48000, 48000, 96000][seed % 3], [2, 64, frames][seed % 3]
+            x = pb.lcg_input(frames, N_IN, fmt in (5, 6), seed=seed)
+            r = rt.Runtime(fmt, prog, fs=fs, random=seed, dither=24)
+            if r.rc < 0:
+                continue
+            o = po.OracleProgram(fmt, prog, fs=fs, random=seed, dither=24)
+            want = o.run_block(x, out_stride, IN_BASE, 0, block=block, frame=np.zeros(4096, dtype=np.uint32))
+            got = r.run_block_all(x, out_stride, IN_BASE, 0, block=block)
+            r.sync_state()
+            nn = int(prog[1]) + int(prog[2])
+            cols = np.nonzero((got.view(np.uint32) != want.view(np.uint32)).any(axis=0))[0]
+            assert cols.size == 0, f"seed {seed} DSP_FORMAT {fmt} block {block}: output columns {list(cols)} differ"
+            assert (r.buf[12:nn] == o.buf[12:nn]).all(), f"seed {seed} DSP_FORMAT {fmt}: data area differs"
+            r.release()
+            n += 1
+    assert n > 0
