@@ -10,9 +10,15 @@ from oracle import pyoracle as po
 from tests.fuzz_programs import stress_input
 
 
+def _options():
+    """AVDSP_SWEEP_OPTIONS="fir_impl=4,fir_lean=1,...": library options set on every runtime of the sweep"""
+    return [(k, int(v)) for k, v in (kv.split("=") for kv in os.environ.get("AVDSP_SWEEP_OPTIONS", "").split(",") if kv)]
+
+
 def run(lo, hi, formats=(2, 4, 6)):
     """seeds lo .. hi-1; returns (runs, list of mismatch descriptions)"""
     bad, n = [], 0
+    opts = _options()
     for seed in range(lo, hi):
         rng = np.random.default_rng(seed + 7000)
         C = int(rng.choice([1, 2, 3, 5, 8, 17, 40])); S = int(rng.choice([0, 1, 2, 3, 7, 8, 9, 16, 17, 33, 70]))
@@ -23,6 +29,7 @@ def run(lo, hi, formats=(2, 4, 6)):
             if S == 0 and taps == 0: continue
             prog = pb.synth_program(fmt, C, S, taps, 5, 5, float(rng.choice([0.5, 1.0, 3.0])))
             o = po.OracleProgram(fmt, prog); r = rt.Runtime(fmt, prog)
+            for k, v in opts: r.set_option(k, v)
             ok = True
             for blk in range(2):
                 x = stress_input(rng, frames, C, fmt in (5, 6)) if rng.random() < 0.5 else pb.lcg_input(frames, C, fmt in (5, 6), seed=seed + blk)
@@ -32,6 +39,7 @@ def run(lo, hi, formats=(2, 4, 6)):
             n += 1
             if not ok:
                 bad.append(f"seed {seed} fmt {fmt} C {C} S {S} T {taps} frames {frames}")
+            for k, v in opts: r.set_option(k, {'fir_impl': 1, 'fir_lean': -1, 'biquad_impl': 1}.get(k, 0))
             r.release()
     return n, bad
 

@@ -63,3 +63,13 @@ def test_random_programs_with_windows_that_share_io_numbers(lo):                
             r.release()
             n += 1
     assert n > 0
+
+
+@pytest.mark.parametrize("lo", [0, 18, 36])
+def test_overlap_arrangements_on_random_shapes(lo):
+    """seeds lo .. lo + 17 of tests/dev/gpu_overlap_sweep.py: random cascade + FIR programs, 4 .. 9 device-resident blocks enqueued back to
+    back, through the overlap mode's arrangements in turn ("ready_words" 0 / 1 / 2 / by plan, "ring_wait" 0 / 1, "overlap" 2, both FIR
+    boundaries, fir_flow); every block's outputs and the final state against the oracle, and no bounded wait ran out"""
+    from tests.dev.gpu_overlap_sweep import run
+    n, bad = run(lo, lo + 18)
+    assert n == 18 and not bad, bad
