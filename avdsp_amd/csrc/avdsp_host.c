@@ -1411,9 +1411,10 @@ static int block_all(int format, int *rundata, const void *in, int in_stride, in
 /* an interpreted core goes to the device as its strand groups (block_all with that one core) */
 static int takes_pieces(const core_plan *cp, int nframes, int in_stride, int in_io_base, int out_stride, int out_io_base)
 {
-    /* windows that share IO numbers make every launch deliver whole rows, one after the other: the core in one piece then */
-    const int overlap = in_stride > 0 && out_stride > 0 && in_io_base < out_io_base + out_stride && out_io_base < in_io_base + in_stride;
-    return cp->total_chains == 0 && G.opt_strand_split && nframes > 1 && !overlap;
+    /* (windows that share IO numbers used to make every launch deliver whole rows, one after the other, and such a call kept its core in one
+     * piece; since the shared columns are copied in front of a call's launches -- show_through, avdsp_kernels.hip -- they are like any others) */
+    (void)in_stride; (void)in_io_base; (void)out_stride; (void)out_io_base;
+    return cp->total_chains == 0 && G.opt_strand_split && nframes > 1;
 }
 
 int dspRuntimeBlockDevice(int format, opcode_t *core, int *rundata,
