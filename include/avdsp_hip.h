@@ -220,6 +220,12 @@ int avdsp_hip_plan_strands(const avdsp_hip_prog *prog, int plan);      /* strand
 enum { AVDSP_OPT_OVERLAP = 0, AVDSP_OPT_PROFILE_STRIDE = 1, AVDSP_OPT_FIR_ROWS = 3, AVDSP_OPT_HOST_SPLIT = 4, AVDSP_OPT_HOST_PIN = 5,
        AVDSP_OPT_READY_WORDS = 6, AVDSP_OPT_LANE_HW = 7, AVDSP_OPT_FIR_SPLIT = 8, AVDSP_OPT_FIR_LAUNCH = 9, AVDSP_OPT_FIR_LEAN = 10, AVDSP_OPT_RING_WAIT = 11 };
 /* FIR_LEAN: fir_tile's chunk boundary with a third of the vector instructions: -1 by the plan (default), 0 never, 1 always. */
+/* READY_WORDS (under OVERLAP): how a block's FIR finds its cascades' block in the rings: 0 an event between the two queues, 1 per-chain
+ * words published by the cascade's waves (write-through stores) and polled by the FIR's, 2 the words set by a kernel behind the
+ * cascade on the cascades' stream (no wait packet on the FIRs' stream, no acquire in the FIR), -1 (default) 2 where the FIR is the
+ * bound (a launch of more than one round of waves), else 0. */
+/* RING_WAIT (under OVERLAP): who waits for the FIR three blocks back before a block's cascade may append to the rings: 1 (default) the
+ * host, polling that FIR's event for at most 1 ms before it enqueues the cascade (then the stream after all), 0 the cascades' stream. */
 /* FIR_LAUNCH: how the overlap mode enqueues a FIR launch (avdsp_hip_prog::fir_launch_mode): -1 auto (default), 0, 1, 2. */
 /* FIR_SPLIT 1 (opt-in; default 0): a fir_tile launch that leaves a SIMD one wave at most (256 chains x 4096 taps) cuts every tile's taps
  * over two waves and adds the two partial sums -- within BASELINE's 1e-6 of the reference, not its bits any more. */
