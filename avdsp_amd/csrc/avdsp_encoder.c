@@ -829,6 +829,89 @@ int dsp_filter(int type, dspFilterParam_t freq, dspFilterParam_t Q, dspGainParam
     }
 }
 
+/* ---------------- Hilbert pair: dsp_filters.c:218-240, design in encoder/dsp_HilbertDesign.c:1-155 ----------------
+ * A 90-degree phase splitter made of two cascades of second-order all-pass cells H(z) = (c - z^-2) / (1 - c z^-2): the classic
+ * polyphase half-band design of Valenzuela and Constantinides ("Digital signal processing schemes for efficient interpolation and
+ * decimation", IEE Proc. G 130(6), 1983), whose 2N cell coefficients follow in closed form from the transition width through the
+ * elliptic nome q (theta-function series for the Jacobi sn).  The odd-indexed coefficients are the reference path, the even ones
+ * the +90 degree path; dsp_Hilbert(stages, transition, phase) emits ONE of the two cascades as a bank of `stages` cells, one
+ * coefficient set per encoded sampling rate (transition is in Hz).
+ *
+ * Parity is byte identity with the reference encoder, so the arithmetic is the reference BINARY's, not a cleaner one: its design
+ * file computes in single precision throughout (`#define double float`), calls the double libm (tan, sin, cos) on widened
+ * arguments and narrows each result, and its -Ofast build (encoder/Makefile:18) takes both fourth roots as sqrt(sqrt(x)) in double,
+ * multiplies by a float reciprocal 1/k where the source divides, and forms the series arguments as m * (pi / order).  Every
+ * rounding below is where that build has one (checked against it for 2..10 stages, four encodings: tests/test_encoder.py).  The
+ * series are summed until a term underflows to zero in single precision, as there (its 1e-100 bound is below every float). */
+static float hilb_qpow(float q, long n)            /* q^n by binary powering, single precision */
+{
+    float z = 1.0f;
+    while (n) { if (n & 1) z *= q; n >>= 1; q *= q; }
+    return z;
+}
+
+static void hilbert_coefficients(float *coef, int ncoef, float transition)
+{
+    const float t2 = transition + transition;
+    float k = (float)tan((double)(1.0f - t2) * (M_PI / 4));
+    k *= k;
+    const float kksqrt = (float)sqrt(sqrt((double)(1.0f - k * k)));
+    const float e = (float)(((double)(1.0f - kksqrt) * 0.5) / (double)(kksqrt + 1.0f));
+    const float e2 = e * e, e4 = e2 * e2;
+    const float q = (((150.0f * e4 + 15.0f) * e4 + 2.0f) * e4 + 1.0f) * e;
+    if (ncoef < 1) return;
+    const int order = 2 * ncoef + 1;
+    const double q4 = sqrt(sqrt((double)q));       /* q^(1/4) */
+    const float inv_k = 1.0f / k;
+    const double w = M_PI / (double)order;
+    for (int c = 1; c <= ncoef; c++) {
+        /* numerator series: sum (-1)^i q^(i(i+1)) sin((2i+1) c pi / order) */
+        float num = 0.0f, term;
+        int i = 0, sgn = 1;
+        do {
+            const float p = hilb_qpow(q, (long)i * (i + 1));
+            term = (float)(((double)sgn * (double)p) * sin((double)((2 * i + 1) * c) * w));
+            num += term;
+            sgn = -sgn; i++;
+        } while (fabs((double)term) > 1e-100);
+        num = (float)((double)num * q4);
+        /* denominator series: 1/2 + sum_{i>=1} (-1)^i q^(i^2) cos(2 i c pi / order) */
+        float den = 0.0f;
+        i = 1; sgn = -1;
+        do {
+            const float p = hilb_qpow(q, (long)i * i);
+            term = (float)(((double)sgn * (double)p) * cos((double)(2 * i * c) * w));
+            den += term;
+            sgn = -sgn; i++;
+        } while (fabs((double)term) > 1e-100);
+        den += 0.5f;
+        const float ww = num / den, wwsq = ww * ww;
+        const float prod = (1.0f - wwsq * k) * (1.0f - wwsq * inv_k);
+        const float x = (float)(sqrt((double)prod) / (double)(wwsq + 1.0f));
+        coef[c - 1] = (1.0f - x) / (x + 1.0f);
+    }
+}
+
+int dsp_Hilbert(int stages, dspFilterParam_t transition, dspGainParam_t phase)
+{
+    int at = 0;
+    float coefs[20];                                           /* at most 10 stages, as in the reference */
+    if (stages < 1 || stages > 10) fatal("dsp_Hilbert: 1 .. 10 stages.");
+    for (int i = 0; i < stages; i++) {
+        const int d = 2 * i + (phase == 0.0 ? 1 : 0);          /* odd coefficients: the reference path; even: +90 degrees */
+        section_entry(DSP_BIQUADS);
+        for (int f = dspMinSamplingFreq; f <= dspMaxSamplingFreq; f++) {
+            dspFilterParam_t fs = dspConvertFrequencyFromIndex(f);
+            hilbert_coefficients(coefs, stages * 2, (float)(transition / fs));
+            if (f == dspMinSamplingFreq) at = put_filter_params(FHILB, 1000, transition, 1.0);
+            /*          xn        xn-1  xn-2  yn-1  yn-2 */
+            put_biquad(coefs[d],  0.0,  -1.0, 0.0,  coefs[d]);
+        }
+        if (!E.sect.opcode) list_mark_here();
+    }
+    return at;
+}
+
 /* ---------------- FIR: :1290-1373, with the impulse pointer fixed (see header) ---------------- */
 int dspFir_Impulses(void)
 {

@@ -102,6 +102,9 @@ typedef struct avdsp_ctx {
     int             biquad_freq_skip, mantissa;            /* this program's dspBiquadFreqSkip / dspMantissa */
     int             device_ordinal;                        /* the GPU its device copy lives on (-1: none yet) */
     int             ninst;                                 /* dspRuntimeSetInstances */
+    int             inst_saved_lanes;                      /* 1 + the "strand_lanes" the program had before it got instances (0: nothing saved) */
+    int             inst_call;                             /* inside dspRuntimeBlockAllInstancesDevice: block_all hands these strides on */
+    size_t          inst_in_words, inst_out_words;
 } avdsp_ctx;
 
 /* no program loaded: options set now are the defaults every program starts from (and keeps following, see dspRuntimeSetOption) */
@@ -129,6 +132,14 @@ static int fail(int code, const char *fmt, ...)
 }
 
 const char *dspRuntimeLastError(void) { return g_err; }
+
+/* a failure of the HIP layer: -10 with its text -- except the sticky one, a FIR wave that gave up waiting for its cascade's ready
+ * word in an earlier block (avdsp_kernels.hip, ready_check): -11, from every entry point until dspRuntimeReset() or
+ * dspRuntimeSetOption("ready_timeouts", 0) acknowledges it.  (dsp_runtime.c:150-195: the reference's failures are return codes.) */
+static int hip_fail(void)
+{
+    return fail(avdsp_hip_last_error_is_ready_timeout() ? -11 : -10, "%s", avdsp_hip_last_error());
+}
 
 static void drop_device(void)
 {
@@ -226,7 +237,7 @@ int dspRuntimeSelect(const void *ptr_into_program)
 static int replan(void)
 {
     device_current();
-    if (G.dev && avdsp_hip_prog_clear_plans(G.dev)) return fail(-10, "%s", avdsp_hip_last_error());
+    if (G.dev && avdsp_hip_prog_clear_plans(G.dev)) return hip_fail();
     G.nplans = 0;
     for (int i_ = 0; i_ < MAX_ARRANGEMENTS; i_++) G.arr[i_].valid = 0;
     return 0;
@@ -246,7 +257,7 @@ static int set_option_here(const char *key, int value)
         const int split = !strcmp(key, "fir_split");
         int *slot = split ? &G.opt_fir_split : key[0] == 'o' ? &G.opt_overlap : key[0] == 'f' ? &G.opt_fir_rows : key[0] == 'r' ? &G.opt_ready_words : key[0] == 'l' ? &G.opt_lane_hw : &G.opt_host_split;
         const int dev_key = split ? AVDSP_OPT_FIR_SPLIT : key[0] == 'o' ? AVDSP_OPT_OVERLAP : key[0] == 'f' ? AVDSP_OPT_FIR_ROWS : key[0] == 'r' ? AVDSP_OPT_READY_WORDS : key[0] == 'l' ? AVDSP_OPT_LANE_HW : AVDSP_OPT_HOST_SPLIT;
-        if (G.dev && avdsp_hip_prog_set_option(G.dev, dev_key, value)) return fail(-10, "%s", avdsp_hip_last_error());
+        if (G.dev && avdsp_hip_prog_set_option(G.dev, dev_key, value)) return hip_fail();
         *slot = value;
         return 0;
     }
@@ -254,29 +265,38 @@ static int set_option_here(const char *key, int value)
      * what dspChangeFormat converts depends on it (dspRuntimeInit); a test hook, a process restart does the same */
     if (!strcmp(key, "rate_count_static")) { g_rate_static = value; return 0; }
     if (!strcmp(key, "host_pin")) {
-        if (G.dev && avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_HOST_PIN, value)) return fail(-10, "%s", avdsp_hip_last_error());
+        if (G.dev && avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_HOST_PIN, value)) return hip_fail();
         G.opt_host_pin = value;
         return 0;
     }
     if (!strcmp(key, "fir_lean")) {
-        if (G.dev && avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_FIR_LEAN, value)) return fail(-10, "%s", avdsp_hip_last_error());
+        if (G.dev && avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_FIR_LEAN, value)) return hip_fail();
         G.opt_fir_lean = value; G.opt_fir_lean_set = 1;
         return 0;
     }
     if (!strcmp(key, "ring_wait")) {
-        if (G.dev && avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_RING_WAIT, value)) return fail(-10, "%s", avdsp_hip_last_error());
+        if (G.dev && avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_RING_WAIT, value)) return hip_fail();
         G.opt_ring_wait = value != 0;
         return 0;
     }
     if (!strcmp(key, "fir_launch")) {
-        if (G.dev && avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_FIR_LAUNCH, value)) return fail(-10, "%s", avdsp_hip_last_error());
+        if (G.dev && avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_FIR_LAUNCH, value)) return hip_fail();
         G.opt_fir_launch = value; G.opt_fir_launch_set = 1;
         return 0;
     }
     if (!strcmp(key, "profile_stride")) {
         if (value < 1) return fail(-1, "profile_stride: every n-th launch, n >= 1");
-        if (G.dev && avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_PROFILE_STRIDE, value)) return fail(-10, "%s", avdsp_hip_last_error());
+        if (G.dev && avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_PROFILE_STRIDE, value)) return hip_fail();
         G.opt_profile_stride = value;
+        return 0;
+    }
+    if (!strcmp(key, "ready_timeouts")) {                /* 0: the caller has heard of them (and has re-uploaded a state it trusts) */
+        if (value) return fail(-1, "ready_timeouts can only be set to 0 (acknowledge)");
+        if (G.dev && avdsp_hip_ready_clear(G.dev)) return hip_fail();
+        return 0;
+    }
+    if (!strcmp(key, "ready_test")) {                    /* tests only (AVDSP_OPT_READY_TEST) */
+        if (G.dev && avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_READY_TEST, value)) return hip_fail();
         return 0;
     }
     if (!strcmp(key, "profile")) {
@@ -325,6 +345,8 @@ int dspRuntimeGetOption(const char *key)
     if (!strncmp(key, "timing_pairs_", 13) && key[13] >= '0' && key[13] <= '7' && !key[14])      /* of the latest dspRuntimeKernelTime(kind) */
         return G.dev ? avdsp_hip_profile_last_pairs(G.dev, key[13] - '0') : 0;
     if (!strcmp(key, "ready_timeouts")) { device_current(); return G.dev ? avdsp_hip_ready_timeouts(G.dev) : 0; }
+    if (!strcmp(key, "side_by_side")) { device_current(); return G.dev ? avdsp_hip_prog_get_option(G.dev, AVDSP_OPT_SIDE_BY_SIDE) : -1; }
+    if (!strcmp(key, "ready_mode"))  { device_current(); return G.dev ? avdsp_hip_prog_get_option(G.dev, AVDSP_OPT_READY_MODE) : 0; }
     if (!strcmp(key, "fir_rows"))    return G.opt_fir_rows;
     if (!strcmp(key, "host_split"))  return G.opt_host_split;
     if (!strcmp(key, "host_pin"))    return G.opt_host_pin;
@@ -411,10 +433,11 @@ int dspRuntimeReset(const int fs, int random, int defaultDither)
     G.store_mask = (int)(0xFFFFFFFFu << ((32 - defaultDither) & 31));
     /* the reference zeroes the data area only (:141): words that DSP_STORE_MEM wrote into the program's
      * parameter sections survive a reset, so fetch them before the device copy is dropped */
+    if (G.dev && avdsp_hip_ready_clear(G.dev)) return hip_fail();      /* (a reset acknowledges ready-word time-outs: the state they spoiled is zeroed below) */
     if (G.dev && G.dev_state_valid) {
         const int first = (int)(sizeof(dspHeader_t) / sizeof(int));
         if (avdsp_hip_download_words(G.dev, (int32_t *)G.code, first, dspHeaderPtr->totalLength - first))
-            return fail(-10, "%s", avdsp_hip_last_error());
+            return hip_fail();
     }
     int *data = (int *)dspHeaderPtr + dspHeaderPtr->totalLength;
     memset(data, 0, (size_t)dspHeaderPtr->dataSize * sizeof(int));
@@ -581,7 +604,7 @@ static int ensure_encoding(int format)
     /* the program words change under the device's feet: bring its state home first, rebuild it afterwards */
     if (G.dev && G.dev_state_valid) {
         const int first = (int)(sizeof(dspHeader_t) / sizeof(int));
-        if (avdsp_hip_download_words(G.dev, (int32_t *)G.code, first, G.total_words - first)) return fail(-10, "%s", avdsp_hip_last_error());
+        if (avdsp_hip_download_words(G.dev, (int32_t *)G.code, first, G.total_words - first)) return hip_fail();
     }
     drop_device();
     return change_format(want, G.numfreq_at_init);
@@ -1194,7 +1217,7 @@ static int scan_generic(int format, opcode_t *core, int end_word, avdsp_generic_
 static int select_device(void)
 {
     if (G.device_selected) {                            /* (another program's GPU, or somebody else's, may be the thread's current one) */
-        if (avdsp_hip_set_device(G.device_ordinal)) return fail(-10, "%s", avdsp_hip_last_error());
+        if (avdsp_hip_set_device(G.device_ordinal)) return hip_fail();
         return 0;
     }
     int n = avdsp_hip_device_count();
@@ -1204,7 +1227,7 @@ static int select_device(void)
         const char *e = getenv("LOCAL_RANK");
         want = e ? atoi(e) % n : 0;
     }
-    if (avdsp_hip_set_device(want)) return fail(-10, "%s", avdsp_hip_last_error());
+    if (avdsp_hip_set_device(want)) return hip_fail();
     G.device_selected = 1;
     G.device_ordinal = want;
     return 0;
@@ -1255,10 +1278,10 @@ static core_plan *get_plan_range(int format, opcode_t *core, int end_word)
     if (select_device()) { lowered_free(&L); return 0; }
     if (!G.dev) {
         G.dev = avdsp_hip_prog_create(G.total_words);
-        if (!G.dev) { fail(-10, "%s", avdsp_hip_last_error()); lowered_free(&L); return 0; }
+        if (!G.dev) { hip_fail(); lowered_free(&L); return 0; }
         if (avdsp_hip_upload_words(G.dev, (const int32_t *)G.code, 0, G.total_words) ||
             avdsp_hip_tpdf_reset(G.dev, G.random, G.dither)) {
-            fail(-10, "%s", avdsp_hip_last_error()); lowered_free(&L); drop_device(); return 0;
+            hip_fail(); lowered_free(&L); drop_device(); return 0;
         }
         G.dev_state_valid = 1;
         avdsp_hip_profile_enable(G.dev, G.opt_profile);
@@ -1267,7 +1290,7 @@ static core_plan *get_plan_range(int format, opcode_t *core, int end_word)
             avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_READY_WORDS, G.opt_ready_words) || avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_LANE_HW, G.opt_lane_hw) || avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_FIR_SPLIT, G.opt_fir_split) || (G.opt_fir_launch_set && avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_FIR_LAUNCH, G.opt_fir_launch)) || (G.opt_fir_lean_set && avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_FIR_LEAN, G.opt_fir_lean)) || avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_RING_WAIT, G.opt_ring_wait) ||
             avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_HOST_SPLIT, G.opt_host_split) || avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_HOST_PIN, G.opt_host_pin) ||
             (G.ninst > 1 && avdsp_hip_set_instances(G.dev, G.ninst))) {
-            fail(-10, "%s", avdsp_hip_last_error()); lowered_free(&L); drop_device(); return 0;
+            hip_fail(); lowered_free(&L); drop_device(); return 0;
         }
     }
     core_plan *cp = &G.plans[G.nplans];
@@ -1308,7 +1331,7 @@ static core_plan *get_plan_range(int format, opcode_t *core, int end_word)
          * costs the lowering, not the call: the generic plan just made is complete, the stretch runs through the interpreter */
         if (cp->plan_id >= 0 && G.next_strands && end_word) (void)avdsp_hip_plan_add_strands(G.dev, cp->plan_id, G.next_strands);
     }
-    if (cp->plan_id < 0) { fail(-10, "%s", avdsp_hip_last_error()); return 0; }
+    if (cp->plan_id < 0) { hip_fail(); return 0; }
     G.nplans++;
     return cp;
 }
@@ -1321,7 +1344,7 @@ int dspRuntimeKernelTime(int kind, double *total_ms, int *launches)
     if (launches) *launches = 0;
     if (!G.dev) return 0;
     device_current();
-    if (avdsp_hip_profile_read(G.dev, kind, total_ms, launches)) return fail(-10, "%s", avdsp_hip_last_error());
+    if (avdsp_hip_profile_read(G.dev, kind, total_ms, launches)) return hip_fail();
     return 0;
 }
 
@@ -1426,12 +1449,12 @@ int dspRuntimeBlockDevice(int format, opcode_t *core, int *rundata,
     if (!cp) return g_err_code;
     if (check_rundata(rundata)) return -1;
     if (nframes <= 0 || cp->empty) return 0;
-    if (avdsp_hip_wait_block_host(G.dev, 0) < 0) return fail(-10, "%s", avdsp_hip_last_error());       /* queued host blocks first */
+    if (avdsp_hip_wait_block_host(G.dev, 0) < 0) return hip_fail();       /* queued host blocks first */
     if (takes_pieces(cp, nframes, in_stride, in_io_base, out_stride, out_io_base))
         return block_all(format, rundata, d_in, in_stride, in_io_base, d_out, out_stride, out_io_base, nframes, 1, stream, AVDSP_PCM_S32, core);
     if (avdsp_hip_run_block(G.dev, cp->plan_id, d_in, in_stride, in_io_base, d_out, out_stride, out_io_base,
                             nframes, G.opt_fir_impl, G.opt_biquad_impl, stream))
-        return fail(-10, "%s", avdsp_hip_last_error());
+        return hip_fail();
     return 0;
 }
 
@@ -1443,12 +1466,12 @@ static int block_host(int format, opcode_t *core, int *rundata, const void *in, 
     if (!cp) return g_err_code;
     if (check_rundata(rundata)) return -1;
     if (nframes <= 0 || cp->empty) return 0;
-    if (avdsp_hip_wait_block_host(G.dev, 0) < 0) return fail(-10, "%s", avdsp_hip_last_error());       /* queued host blocks first */
+    if (avdsp_hip_wait_block_host(G.dev, 0) < 0) return hip_fail();       /* queued host blocks first */
     if (takes_pieces(cp, nframes, in_stride, in_io_base, out_stride, out_io_base))
         return block_all(format, rundata, in, in_stride, in_io_base, out, out_stride, out_io_base, nframes, 0, 0, AVDSP_PCM_S32, core);
     if (avdsp_hip_run_block_host(G.dev, cp->plan_id, in, in_stride, in_io_base, out, out_stride, out_io_base,
                                  nframes, G.opt_fir_impl, G.opt_biquad_impl))
-        return fail(-10, "%s", avdsp_hip_last_error());
+        return hip_fail();
     return 0;
 }
 
@@ -1463,12 +1486,12 @@ int dspRuntimeBlockSubmit(int format, opcode_t *core, int *rundata, const void *
     if (check_rundata(rundata)) return -1;
     if (nframes <= 0 || cp->empty) return avdsp_hip_wait_block_host(G.dev, 1 << 30);
     if (takes_pieces(cp, nframes, in_stride, in_io_base, out_stride, out_io_base)) {
-        if (avdsp_hip_wait_block_host(G.dev, 0) < 0) return fail(-10, "%s", avdsp_hip_last_error());
+        if (avdsp_hip_wait_block_host(G.dev, 0) < 0) return hip_fail();
         return block_all(format, rundata, in, in_stride, in_io_base, out, out_stride, out_io_base, nframes, 0, 0, AVDSP_PCM_S32, core);
     }
     const int rc = avdsp_hip_submit_block_host(G.dev, cp->plan_id, in, in_stride, in_io_base, out, out_stride, out_io_base,
                                                nframes, G.opt_fir_impl, G.opt_biquad_impl);
-    if (rc < 0) return fail(-10, "%s", avdsp_hip_last_error());
+    if (rc < 0) return hip_fail();
     return rc;
 }
 
@@ -1477,7 +1500,7 @@ int dspRuntimeBlockWait(int max_in_flight)
     if (!G.dev) return 0;
     device_current();
     const int rc = avdsp_hip_wait_block_host(G.dev, max_in_flight);
-    if (rc < 0) return fail(-10, "%s", avdsp_hip_last_error());
+    if (rc < 0) return hip_fail();
     return rc;
 }
 
@@ -2064,10 +2087,7 @@ static int expand_core(int format, opcode_t *c, core_plan **cp, int *pn)
     return 0;
 }
 
-/* dspRuntimeBlockAllInstancesDevice hands its per-instance strides to block_all through these (one call at a time per thread of control,
- * like everything else here) */
-static int g_inst_call;
-static size_t g_inst_in_words, g_inst_out_words;
+/* (dspRuntimeBlockAllInstancesDevice hands its per-instance strides to block_all through the program's context: inst_call, inst_*_words) */
 
 /* only == 0: every core of the program in program order; else that one core (its strand groups side by side) */
 static int block_all(int format, int *rundata, const void *in, int in_stride, int in_io_base,
@@ -2133,15 +2153,15 @@ static int block_all(int format, int *rundata, const void *in, int in_stride, in
     if (A->n == 0) return 0;                                     /* every core's shard is empty on this rank */
     const int *plans = A->plans, *size = A->size;
     const int nlevels = A->nlevels;
-    int rc = g_inst_call
-        ? avdsp_hip_run_levels_instances(G.dev, plans, size, nlevels, in, in_stride, in_io_base, g_inst_in_words, out, out_stride, out_io_base,
-                                         g_inst_out_words, nframes, stream)
+    int rc = G.inst_call
+        ? avdsp_hip_run_levels_instances(G.dev, plans, size, nlevels, in, in_stride, in_io_base, G.inst_in_words, out, out_stride, out_io_base,
+                                         G.inst_out_words, nframes, stream)
         : on_device
         ? avdsp_hip_run_levels(G.dev, plans, size, nlevels, in, in_stride, in_io_base, out, out_stride, out_io_base,
                                nframes, G.opt_fir_impl, G.opt_biquad_impl, stream)
         : avdsp_hip_run_levels_pcm_host(G.dev, plans, size, nlevels, pcm, in, in_stride, in_io_base, out, out_stride, out_io_base,
                                         nframes, G.opt_fir_impl, G.opt_biquad_impl);
-    if (rc) return fail(-10, "%s", avdsp_hip_last_error());
+    if (rc) return hip_fail();
     return 0;
 }
 
@@ -2165,10 +2185,22 @@ int dspRuntimeBlockAllDevice(int format, int *rundata, const void *d_in, int in_
 int dspRuntimeSetInstances(int n)
 {
     if (!dspHeaderPtr || !G.code) return fail(-1, "no program loaded");
-    if (n < 1 || n > 65536) return fail(-1, "instances: 1 .. 65536");
+    if (n < 0 || n > 65536) return fail(-1, "instances: 1 .. 65536 (0: no instances any more)");
     device_current();
-    if (G.dev && avdsp_hip_set_instances(G.dev, n)) return fail(-10, "%s", avdsp_hip_last_error());      /* (else: when the device copy is made) */
+    if (G.dev && avdsp_hip_set_instances(G.dev, n > 0 ? n : 1)) return hip_fail();      /* (else: when the device copy is made) */
     G.ninst = n;
+    /* The strand plans know nothing of instances: while a program HAS instances its interpreted cores run as the interpreter's pieces
+     * ("strand_lanes" 0, the plans rebuilt once, here -- not silently inside a block call), and dspRuntimeSetInstances(0) gives the
+     * program back the arrangement it had. */
+    if (n >= 1 && G.opt_strand_lanes != 0) {
+        G.inst_saved_lanes = 1 + G.opt_strand_lanes;
+        return set_option_here("strand_lanes", 0);
+    }
+    if (n == 0 && G.inst_saved_lanes) {
+        const int back = G.inst_saved_lanes - 1;
+        G.inst_saved_lanes = 0;
+        return set_option_here("strand_lanes", back);
+    }
     return 0;
 }
 
@@ -2177,11 +2209,13 @@ int dspRuntimeBlockAllInstancesDevice(int format, int *rundata, const void *d_in
 {
     (void)ctx_of(rundata);
     if (G.ninst < 1) return fail(-1, "dspRuntimeSetInstances first");
-    /* the strand plans and the chain kernels know nothing of instances: the interpreter's pieces throughout */
-    if (G.opt_strand_lanes != 0) { const int rc0 = set_option_here("strand_lanes", 0); if (rc0) return rc0; }
-    g_inst_call = 1; g_inst_in_words = in_inst_words; g_inst_out_words = out_inst_words;
+    /* the strand plans know nothing of instances: dspRuntimeSetInstances(n > 1) has switched them off for as long as the program has
+     * instances (a caller who turned them on again since gets told, not overridden) */
+    if (G.opt_strand_lanes != 0)
+        return fail(-1, "\"strand_lanes\" was set again after dspRuntimeSetInstances(%d): instances run on the interpreter's pieces", G.ninst);
+    G.inst_call = 1; G.inst_in_words = in_inst_words; G.inst_out_words = out_inst_words;
     const int rc = block_all(format, rundata, d_in, in_stride, in_io_base, d_out, out_stride, out_io_base, nframes, 1, stream, AVDSP_PCM_S32, 0);
-    g_inst_call = 0;
+    G.inst_call = 0;
     return rc;
 }
 
@@ -2190,7 +2224,7 @@ int dspRuntimeInstanceState(int inst, int *dst)
 {
     if (!dspHeaderPtr || !G.dev) return fail(-1, "no program loaded, or no block has run yet");
     device_current();
-    if (avdsp_hip_download_instance_words(G.dev, inst, dst, (int)dspHeaderPtr->totalLength, (int)dspHeaderPtr->dataSize)) return fail(-10, "%s", avdsp_hip_last_error());
+    if (avdsp_hip_download_instance_words(G.dev, inst, dst, (int)dspHeaderPtr->totalLength, (int)dspHeaderPtr->dataSize)) return hip_fail();
     return 0;
 }
 
@@ -2219,7 +2253,7 @@ int dspRuntimeBlockPcm(int format, opcode_t *core, int *rundata, int pcm, const 
         return block_all(format, rundata, src, in_stride, in_io_base, dst, out_stride, out_io_base, nframes, 0, 0, pcm, core);
     if (avdsp_hip_run_block_pcm_host(G.dev, cp->plan_id, pcm, src, in_stride, in_io_base, dst, out_stride, out_io_base,
                                      nframes, G.opt_fir_impl, G.opt_biquad_impl))
-        return fail(-10, "%s", avdsp_hip_last_error());
+        return hip_fail();
     return 0;
 }
 
@@ -2229,7 +2263,7 @@ int dspRuntimeTagOutputDevice(void *d_out, int out_stride, int column, int nfram
     if (!G.dev) return fail(-1, "no device program yet: run a block first");
     device_current();
     if (column < 0 || column >= out_stride) return fail(-1, "tag column %d outside the output window of %d", column, out_stride);
-    if (avdsp_hip_tag_output(G.dev, (int *)d_out + column, out_stride, nframes, 0, 0, stream)) return fail(-10, "%s", avdsp_hip_last_error());
+    if (avdsp_hip_tag_output(G.dev, (int *)d_out + column, out_stride, nframes, 0, 0, stream)) return hip_fail();
     return 0;
 }
 
@@ -2237,7 +2271,7 @@ int dspRuntimeTagOutputReset(int previoussample)
 {
     if (!G.dev) return fail(-1, "no device program yet: run a block first");
     device_current();
-    if (avdsp_hip_tag_output(G.dev, 0, 0, 0, 1, previoussample, 0)) return fail(-10, "%s", avdsp_hip_last_error());
+    if (avdsp_hip_tag_output(G.dev, 0, 0, 0, 1, previoussample, 0)) return hip_fail();
     return 0;
 }
 
@@ -2254,7 +2288,7 @@ int dspRuntimeTagOutput(int *out, int out_stride, int column, int nframes)
     int rc = avdsp_hip_tag_column_host(G.dev, col, nframes);
     if (!rc) for (int n = 0; n < nframes; n++) out[(size_t)n * out_stride + column] = col[n];
     free(col);
-    if (rc) return fail(-10, "%s", avdsp_hip_last_error());
+    if (rc) return hip_fail();
     return 0;
 }
 
@@ -2262,7 +2296,7 @@ int dspRuntimeUnpackPcmDevice(int pcm, const void *d_src, int *d_dst, long long 
 {
     if (!G.dev) return fail(-1, "no device program yet: run a block first");
     device_current();
-    if (avdsp_hip_unpack_pcm(G.dev, pcm, d_src, d_dst, (size_t)nsamples, stream)) return fail(-10, "%s", avdsp_hip_last_error());
+    if (avdsp_hip_unpack_pcm(G.dev, pcm, d_src, d_dst, (size_t)nsamples, stream)) return hip_fail();
     return 0;
 }
 
@@ -2292,7 +2326,7 @@ int dspRuntimeSyncState(int *rundata)
     /* the header stays the host's: only words behind it can have been written (DSP_STORE_MEM) */
     const int first = (int)(sizeof(dspHeader_t) / sizeof(int));
     if (avdsp_hip_download_words(G.dev, (int32_t *)G.code, first, G.total_words - first))
-        return fail(-10, "%s", avdsp_hip_last_error());
+        return hip_fail();
     return 0;
 }
 
@@ -2307,7 +2341,7 @@ int dspRuntimeUploadParams(void)
     const int first = (int)(sizeof(dspHeader_t) / sizeof(int));
     if (avdsp_hip_prog_clear_plans(G.dev) ||
         avdsp_hip_upload_words(G.dev, (const int32_t *)G.code, first, dspHeaderPtr->totalLength - first))
-        return fail(-10, "%s", avdsp_hip_last_error());
+        return hip_fail();
     G.nplans = 0;                                             /* cores are lowered again at their next block */
     for (int i_ = 0; i_ < MAX_ARRANGEMENTS; i_++) G.arr[i_].valid = 0;
     return 0;
@@ -2320,6 +2354,6 @@ int dspRuntimeUploadState(const int *rundata)
     if (check_rundata(rundata)) return -1;
     if (!G.dev) return 0;                                     /* uploaded with the whole buffer at first use */
     if (avdsp_hip_upload_words(G.dev, (const int32_t *)G.code, dspHeaderPtr->totalLength, dspHeaderPtr->dataSize))
-        return fail(-10, "%s", avdsp_hip_last_error());
+        return hip_fail();
     return 0;
 }

@@ -49,10 +49,12 @@
 namespace {
 
 thread_local char g_err[512];
+thread_local bool g_err_ready = false;   /* the latest set_err() was ready_check()'s (avdsp_hip_last_error_is_ready_timeout) */
 
 int set_err(const char *fmt, ...)
 {
     va_list ap;
+    g_err_ready = false;
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof g_err, fmt, ap);
     va_end(ap);
@@ -272,7 +274,8 @@ __device__ __forceinline__ void ring_put(const Ring &r, int cid, int q, unsigned
  * buffer_wbl2 writes back the XCD's whole L2, under the FIR that is filling it -- the cascade alone went 34 -> 52 us, the 4096-chain
  * step 0.519 -> 0.541 ms.)  The numbers only grow (compared modulo 2^32), so nothing is re-armed between launches.  The poll is
  * bounded: the cascade it waits for was enqueued before the FIR and needs nothing of it, so the bound is never met; if it ever
- * were, the wave leaves a mark (AVDSP_OPT_READY_TIMEOUTS reads it) and goes on rather than hang the device.                  */
+ * were (a preempted or shared GPU, a copy the cascade waits for that never comes), the wave leaves a mark and goes on rather than
+ * hang the device, and the mark turns every later call into an error (ready_check below; round 5).                            */
 __device__ __forceinline__ void chain_ready_release()
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      /* every storing wave drains its write-through ring stores (ring_put) before its chains' words go out */
@@ -286,8 +289,16 @@ __device__ __forceinline__ void chain_ready_wait(unsigned *ready, int cid, unsig
     unsigned spins = 0;
     while ((int)(__hip_atomic_load(ready + cid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0) {
         __builtin_amdgcn_s_sleep(32);
-        if (++spins > (1u << 19)) {                        /* ~ a second */
-            if ((threadIdx.x & 63) == 0) atomicAdd(timeouts, 1u);
+        if (++spins > (1u << 19)) {                        /* ~ half a second */
+            /* The wave goes on (it must end) with whatever the ring holds, so the block is NOT the reference's bits -- and the host
+             * must learn of it without asking: timeouts[0] counts such waves, timeouts[2..3] is the device address of a word in
+             * mapped pinned HOST memory, which every later entry point of the library looks at first (ready_check: the call then
+             * fails with a negative code and a text, like every other failure of this library). */
+            if ((threadIdx.x & 63) == 0) {
+                atomicAdd(timeouts, 1u);
+                unsigned *flag = *reinterpret_cast<unsigned *const *>(timeouts + 2);
+                if (flag) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
             break;
         }
     }
@@ -3323,7 +3334,8 @@ struct avdsp_hip_prog {
     unsigned *d_frame = nullptr; int frame_words = 0;     /* samples[] frame of the general interpreter */
     std::vector<Plan> plans;
     unsigned *d_in = nullptr, *d_out = nullptr; size_t in_cap = 0, out_cap = 0;   /* host-call staging */
-    unsigned *d_alias = nullptr; size_t alias_cap = 0;    /* copy of the input block of an in-place device call (avdsp_hip_run_block) */
+    struct Alias { hipStream_t stream; unsigned *buf; size_t cap; };
+    std::vector<Alias> alias;           /* copy of the input block of an in-place device call (avdsp_hip_run_block), one per caller's stream: stream order is what keeps a copy until its block's kernels have read it */
     /* N instances of the program (avdsp_hip_run_levels_instances): copies 1 .. N-1 of the device state; instance 0 is the program's own */
     int inst_n = 1; bool inst_valid = false;
     bool ring_wait_host = true;              /* "ring_wait": the host (1), not the cascades' stream (0), waits for the FIR three blocks back (launch_all) */
@@ -3359,6 +3371,8 @@ struct avdsp_hip_prog {
     hipStream_t s_fir[2] = {nullptr, nullptr};           /* "overlap" 2: the FIRs of consecutive blocks in turn */
     static constexpr int kAhead = 3;     /* cascade k waits for FIR k - kAhead: it may run under FIR k - 2 and be done before FIR k - 1 ends */
     hipEvent_t ev_bq[kAhead] = {nullptr, nullptr, nullptr}, ev_fir[kAhead] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fir_now[kAhead] = {nullptr, nullptr, nullptr};   /* what stands for "FIR of this slot has ended": ev_fir[slot], or the stop event of the kernel timer that rode on that launch (no second event on the stream) */
+    hipEvent_t last_ride_stop = nullptr; /* ProfileScope::ride: the stop event the latest timed launch carries */
     /* How an un-timed FIR launch of the overlap mode is enqueued (launch_all), by what was measured:
      *   1  the event the next cascades wait for rides on the dispatch's own completion signal (hipExtLaunchKernel's stop slot) instead
      *      of a marker packet behind it: 4096 chains 0.5110 -> 0.5078 ms per step, 2048 chains 0.2592 -> 0.2572;
@@ -3376,7 +3390,11 @@ struct avdsp_hip_prog {
                                             the cascade's waves (slower everywhere), 2 ready words set by a kernel behind the cascade; -1 (default): 2 where the FIR is the
                                             bound, else 0 (launch_all) */
     int ready_mode_now = 0;              /* (the mode of the launch being made) */
-    unsigned *d_ready_timeouts = nullptr;        /* waves whose bounded wait for a ready word ran out (never, see chain_ready_wait) */
+    int side_by_side = 0;                /* kernels of the FIRs' stream and of the cascades' have been seen to run at once (probe_side_by_side): without that no ready words */
+    std::vector<std::pair<hipStream_t, int>> probed;      /* ... per stream the FIRs were launched on */
+    unsigned *d_ready_timeouts = nullptr;        /* [0] waves whose bounded wait for a ready word ran out (never, see chain_ready_wait); [2..3] the device address of h_ready_flag */
+    unsigned *h_ready_flag = nullptr;            /* mapped pinned host word such a wave sets: the host sees it without a copy or a synchronisation (ready_check) */
+    int ready_test = 0;                          /* tests only: that many coming launches of "ready_words" 2 skip their ready_set kernel, so that their FIR waves time out */
     int *d_tag_prev = nullptr;           /* tagoutput: the plugin's `previoussample` */
     /* host-pointer block calls: the caller's buffers pinned in place (cache), copies and kernels on three streams */
     struct Pinned { const void *ptr; size_t bytes; bool ours; int refs; };   /* refs: queued blocks still copying from / into it */
@@ -3403,6 +3421,21 @@ struct avdsp_hip_prog {
 namespace {
 
 int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+/* A FIR wave whose bounded wait for its cascade's ready word ran out (chain_ready_wait) has summed a window its cascade may not
+ * have written: the block it belongs to is not the reference's.  The library has long returned 0 for that block (launches are
+ * asynchronous), so the failure is STICKY: from the moment the wave's mark is visible every entry point that touches the program
+ * fails with this text until the caller acknowledges it (dspRuntimeReset, or dspRuntimeSetOption("ready_timeouts", 0) after
+ * re-uploading a state it trusts).  The reference's failures are return codes, never silent (dsp_runtime.c:150-195). */
+int ready_check(avdsp_hip_prog *prog)
+{
+    if (!prog || !prog->h_ready_flag || !*(volatile unsigned *)prog->h_ready_flag) return 0;
+    set_err("a FIR wave gave up waiting for its cascade's ready word (\"ready_words\" %d): at least one earlier block's output and the FIR "
+            "state behind it are not valid; dspRuntimeReset() or dspRuntimeSetOption(\"ready_timeouts\", 0) acknowledges", prog->ready_mode_now ? prog->ready_mode_now : prog->ready_words);
+    g_err_ready = true;
+    return -1;
+}
+#define READY_CHECK(prog) do { if (ready_check(prog)) return -1; } while (0)
 
 template <typename T>
 int upload_vec(T **dst, const std::vector<T> &v)
@@ -3443,8 +3476,9 @@ Ring plan_ring(const Plan &pl) { return Ring{pl.d_ring, pl.ring_R, pl.wpos, pl.d
 hipEvent_t take_event(avdsp_hip_prog *prog)
 {
     if (!prog->free_events.empty()) { hipEvent_t e = prog->free_events.back(); prog->free_events.pop_back(); return e; }
+    /* timers order nothing and hand no data to the host: no system-scope release behind the kernel they ride on (timing stays on) */
     hipEvent_t e = nullptr;
-    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) != hipSuccess) return nullptr;
     return e;
 }
 
@@ -3461,7 +3495,11 @@ struct ProfileScope {
     void keep(hipEvent_t s, hipEvent_t e, bool pair)
     {
         if (prog->spans.size() >= 65536) {                 /* nobody reads the timers: forget the oldest half (their events go back to the pool) */
-            for (size_t i = 0; i < 32768; i++) { prog->free_events.push_back(prog->spans[i].a); prog->free_events.push_back(prog->spans[i].b); }
+            for (size_t i = 0; i < 32768; i++) {
+                for (int k = 0; k < avdsp_hip_prog::kAhead; k++)
+                    if (prog->ev_fir_now[k] == prog->spans[i].b) { (void)hipEventSynchronize(prog->spans[i].b); prog->ev_fir_now[k] = prog->ev_fir[k]; prog->ev_fir_set[k] = false; }
+                prog->free_events.push_back(prog->spans[i].a); prog->free_events.push_back(prog->spans[i].b);
+            }
             prog->spans.erase(prog->spans.begin(), prog->spans.begin() + 32768);
         }
         prog->spans.push_back({kind, s, e, pair});
@@ -3472,6 +3510,7 @@ struct ProfileScope {
         s = take_event(prog); e = take_event(prog);
         if (!s || !e) { if (s) prog->free_events.push_back(s); if (e) prog->free_events.push_back(e); return false; }
         keep(s, e, false);
+        prog->last_ride_stop = e;
         return true;
     }
     void begin() { if (on && !a && (a = take_event(prog))) (void)hipEventRecord(a, stream); }
@@ -3585,7 +3624,7 @@ int launch_fir_tile(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, Block
     FirTileArgs a{};
     a.buf = prog->d_buf; a.chains = pl.d_chains; a.group = ids; a.ngroup = n;
     a.ring = plan_ring(pl); a.io = io; a.taps64 = pl.d_taps64; a.pitch64 = pl.pitch64;
-    if (wait_ready) { a.ready = pl.d_ready; a.seq = pl.seq; a.timeouts = prog->d_ready_timeouts; a.ready_acquire = prog->ready_mode_now != 2; }
+    if (wait_ready) { a.ready = pl.d_ready; a.seq = pl.seq; a.timeouts = prog->d_ready_timeouts; a.ready_acquire = prog->ready_mode_now != 2 || prog->overlap >= 2; }
     const int nwg = (n * TileGeom<R, BIG>::WPC * (SPLIT ? 2 : 1) + 3) / 4;
     a.per_xcd = (nwg + 7) / 8;
     const size_t lds = (size_t)4 * TileGeom<R, BIG>::LDS_DOUBLES * sizeof(double) + 64;      /* + the four words the waves exchange at the end */
@@ -3651,7 +3690,7 @@ int launch_fir_flow(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, Block
     FirTileArgs a{};
     a.buf = prog->d_buf; a.chains = pl.d_chains; a.group = ids; a.ngroup = n;
     a.ring = plan_ring(pl); a.io = io; a.taps64 = pl.d_taps64; a.pitch64 = pl.pitch64;
-    if (wait_ready) { a.ready = pl.d_ready; a.seq = pl.seq; a.timeouts = prog->d_ready_timeouts; a.ready_acquire = prog->ready_mode_now != 2; }
+    if (wait_ready) { a.ready = pl.d_ready; a.seq = pl.seq; a.timeouts = prog->d_ready_timeouts; a.ready_acquire = prog->ready_mode_now != 2 || prog->overlap >= 2; }
     const int nwg = (n * FlowGeom<R, BIG>::WPC + 3) / 4;
     a.per_xcd = (nwg + 7) / 8;
     const size_t lds = (size_t)4 * FlowGeom<R, BIG>::LDS_DOUBLES * sizeof(double) + 64;
@@ -3759,6 +3798,48 @@ __global__ void ready_set(unsigned *ready, const int *ids, int n, unsigned seq)
     if (i < n) ready[ids[i]] = seq;
 }
 
+/* Ready words need kernels of two queues to RUN side by side: the FIR's waves sit on their SIMDs until a kernel on the cascades' queue
+ * has set their words.  Where dispatches are serialised -- `rocprofv3 --pmc` does that (round 4's PMC pass of the headline kernel
+ * counted seconds of polling waves: every FIR ran into its bound), a debugger, a queue-per-process time slice -- the FIR would wait
+ * for a kernel that cannot start.  So the mode is only taken after this has been SEEN to work, once per program: a kernel that
+ * waits (bounded, ~3 ms) for a word, a kernel on the other queue that sets it.  Not seen: the FIRs wait for the cascades' events,
+ * as with "ready_words" 0 -- slower by the wait packet, correct anywhere.  (A GPU that stops running two queues at once LATER still
+ * ends in chain_ready_wait's bound, and that is an error at the C ABI: ready_check.) */
+__global__ void probe_wait(const unsigned *flag, unsigned *seen)
+{
+    unsigned spins = 0, v = 0;
+    while ((v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0 && ++spins < 4096) __builtin_amdgcn_s_sleep(32);
+    if (threadIdx.x == 0) __hip_atomic_store(seen, v ? 1u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void probe_set(unsigned *flag) { if (threadIdx.x == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+static int probe_side_by_side(avdsp_hip_prog *prog, hipStream_t fir_stream)
+{
+    /* per stream the FIRs are launched on: whether two streams run side by side depends on the hardware queues the runtime gave them
+     * (it has a handful and deals them out in turn: a caller's stream that shares one with the cascades' stream would have its FIR
+     * wait for a kernel queued BEHIND it) */
+    for (auto &pr : prog->probed) if (pr.first == fir_stream) { prog->side_by_side = pr.second; return 0; }
+    prog->side_by_side = 0;
+    if (prog->probed.size() >= 16) prog->probed.clear();
+    prog->probed.push_back({fir_stream, 0});
+    if (!prog->d_ready_timeouts || !prog->h_ready_flag) return 0;
+    unsigned *dseen = nullptr;
+    HIP_TRY(hipHostGetDevicePointer((void **)&dseen, prog->h_ready_flag, 0));
+    *(volatile unsigned *)(prog->h_ready_flag + 1) = 0;
+    HIP_TRY(hipMemsetAsync(prog->d_ready_timeouts + 1, 0, 4, fir_stream));
+    HIP_TRY(hipStreamSynchronize(fir_stream));
+    HIP_TRY(hipStreamSynchronize(prog->s_bq));
+    hipLaunchKernelGGL(probe_wait, dim3(1), dim3(64), 0, fir_stream, prog->d_ready_timeouts + 1, dseen + 1);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(probe_set, dim3(1), dim3(64), 0, prog->s_bq, prog->d_ready_timeouts + 1);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(fir_stream));
+    HIP_TRY(hipStreamSynchronize(prog->s_bq));
+    prog->side_by_side = *(volatile unsigned *)(prog->h_ready_flag + 1) == 1u;
+    prog->probed.back().second = prog->side_by_side;
+    return 0;
+}
+
 static int overlap_ready(avdsp_hip_prog *prog)
 {
     if (prog->s_bq) return 0;
@@ -3779,8 +3860,10 @@ int launch_all(avdsp_hip_prog *prog, Plan &pl, BlockIO io, int fir_impl, int biq
     pl.seq++;                                             /* this launch's number in the plan's ready words */
     if (under) {
         if (overlap_ready(prog)) return -1;
+        if (prog->ready_words != 0 && (fir_impl == 1 || fir_impl == 4) &&
+            probe_side_by_side(prog, prog->overlap >= 2 ? prog->s_fir[prog->blk & 1] : stream)) return -1;     /* (remembered per stream) */
         /* fir_tile finds its cascades' blocks through the ready words; the other FIR kernels wait for the cascades' event */
-        const bool can_words = (fir_impl == 1 || fir_impl == 4) && pl.d_ready && prog->d_ready_timeouts;
+        const bool can_words = (fir_impl == 1 || fir_impl == 4) && pl.d_ready && prog->d_ready_timeouts && prog->side_by_side;
         /* Mode 2 takes the wait packet off the FIRs' stream (a FIR follows the previous one like any kernel of a queue): 4096 chains
          * 0.5025 -> 0.4980 ms per step.  Where the cascades are the bound that packet's ~9 us are bubbles they live on: 2048 chains
          * 0.2594 -> 0.2686, 512 chains 0.0864 -> 0.0933 (one box) -- so by default only where a launch is more than one round of waves */
@@ -3804,7 +3887,7 @@ int launch_all(avdsp_hip_prog *prog, Plan &pl, BlockIO io, int fir_impl, int biq
             if (prog->ring_wait_host) {
                 const auto t0 = std::chrono::steady_clock::now();
                 for (;;) {
-                    const hipError_t q = hipEventQuery(prog->ev_fir[slot]);
+                    const hipError_t q = hipEventQuery(prog->ev_fir_now[slot]);
                     if (q == hipSuccess) { done = true; break; }
                     (void)hipGetLastError();
                     if (q != hipErrorNotReady) break;
@@ -3812,14 +3895,15 @@ int launch_all(avdsp_hip_prog *prog, Plan &pl, BlockIO io, int fir_impl, int biq
                     std::this_thread::yield();
                 }
             }
-            if (!done) HIP_TRY(hipStreamWaitEvent(prog->s_bq, prog->ev_fir[slot], 0));
+            if (!done) HIP_TRY(hipStreamWaitEvent(prog->s_bq, prog->ev_fir_now[slot], 0));
         }
         if (prog->input_ready) HIP_TRY(hipStreamWaitEvent(prog->s_bq, prog->input_ready, 0));           /* (queued host blocks: the copy of this block) */
         for (size_t gi = 0; gi < pl.bq.size(); gi++) {        /* (the last group's kernel carries the event: the stream is in order) */
             auto &g = pl.bq[gi];
             if (launch_biquad<FMT>(prog, pl, g, g.d_ids, g.n, io, biquad_impl, prog->s_bq, !words && gi + 1 == pl.bq.size() ? prog->ev_bq[slot] : nullptr, wt)) return -1;
         }
-        if (behind) {
+        if (behind && prog->ready_test > 0) prog->ready_test--;       /* (tests: this launch's words are never set) */
+        else if (behind) {
             hipLaunchKernelGGL(ready_set, dim3((unsigned)((pl.n_fir + kBlock - 1) / kBlock)), dim3(kBlock), 0, prog->s_bq, pl.d_ready, pl.d_fir_ids, pl.n_fir, pl.seq);
             HIP_TRY(hipGetLastError());
         }
@@ -3832,6 +3916,7 @@ int launch_all(avdsp_hip_prog *prog, Plan &pl, BlockIO io, int fir_impl, int biq
             if (!words) HIP_TRY(hipStreamWaitEvent(fs, prog->ev_bq[slot], 0));
             if (launch_fir<FMT>(prog, pl, pl.d_fir_ids, pl.n_fir, io, fir_impl, fs, words)) return -1;
             HIP_TRY(hipEventRecord(prog->ev_fir[slot], fs));
+            prog->ev_fir_now[slot] = prog->ev_fir[slot];
             HIP_TRY(hipStreamWaitEvent(stream, prog->ev_fir[slot], 0));
         } else {
             /* The FIR follows the previous block's FIR on the caller's stream with nothing in between: an event wait here -- a barrier
@@ -3843,10 +3928,16 @@ int launch_all(avdsp_hip_prog *prog, Plan &pl, BlockIO io, int fir_impl, int biq
             /* (a launch whose kernel timer is sampled carries the timer's events instead; its event is then recorded behind it) */
             const bool rides = mode == 1 && !((prog->profile >> AVDSP_KERNEL_FIR & 1u) && prog->profile_seen[AVDSP_KERNEL_FIR & 7] % (unsigned)prog->profile_stride == 0);
             prog->fir_mode_now = mode;
+            prog->last_ride_stop = nullptr;
             const int rc_fir = launch_fir<FMT>(prog, pl, pl.d_fir_ids, pl.n_fir, io, fir_impl, stream, words, rides ? prog->ev_fir[slot] : nullptr);
             prog->fir_mode_now = 0;
             if (rc_fir) return -1;
-            if (!rides) HIP_TRY(hipEventRecord(prog->ev_fir[slot], stream));
+            /* (round 5: a launch that carries its kernel timer's stop event needs no second event behind it -- that one says "this FIR
+             * has ended" just as well, and a recorded event is a marker packet the next dispatch queues behind: with every launch of a
+             * 0.5-ms FIR timed the step was 0.5110 ms against 0.5045 with every fourth) */
+            prog->ev_fir_now[slot] = prog->ev_fir[slot];
+            if (!rides && mode == 1 && prog->last_ride_stop) prog->ev_fir_now[slot] = prog->last_ride_stop;
+            else if (!rides) HIP_TRY(hipEventRecord(prog->ev_fir[slot], stream));
         }
         prog->ev_fir_set[slot] = true;
         prog->blk++;
@@ -3899,6 +3990,20 @@ avdsp_hip_prog *avdsp_hip_prog_create(int total_words)
     if (e != hipSuccess) { set_err("hipMalloc(mirror, %d words): %s", total_words, hipGetErrorString(e)); delete p; return nullptr; }
     if (const char *m = getenv("AVDSP_FIR_LAUNCH_MODE")) p->fir_launch_mode = atoi(m);
     if (hipMalloc((void **)&p->d_ready_timeouts, 16) != hipSuccess || hipMemset(p->d_ready_timeouts, 0, 16) != hipSuccess) p->d_ready_timeouts = nullptr;   /* (without it the FIR waits for events) */
+    if (p->d_ready_timeouts) {
+        /* the word a timed-out wave sets, in mapped pinned host memory; without it no ready words at all (a time-out nobody hears of) */
+        unsigned *dflag = nullptr;
+        if (hipHostMalloc((void **)&p->h_ready_flag, 64, hipHostMallocMapped) == hipSuccess &&
+            hipHostGetDevicePointer((void **)&dflag, p->h_ready_flag, 0) == hipSuccess &&
+            hipMemcpy(p->d_ready_timeouts + 2, &dflag, sizeof dflag, hipMemcpyHostToDevice) == hipSuccess) {
+            *(volatile unsigned *)p->h_ready_flag = 0;
+        } else {
+            if (p->h_ready_flag) (void)hipHostFree(p->h_ready_flag);
+            p->h_ready_flag = nullptr;
+            (void)hipFree(p->d_ready_timeouts); p->d_ready_timeouts = nullptr;
+            (void)hipGetLastError();
+        }
+    }
     return p;
 }
 
@@ -3928,8 +4033,9 @@ void avdsp_hip_prog_destroy(avdsp_hip_prog *p)
     if (p->ev_unpack) (void)hipEventDestroy(p->ev_unpack);
     for (int i = 0; i < avdsp_hip_prog::kAhead; i++) { if (p->ev_bq[i]) (void)hipEventDestroy(p->ev_bq[i]); if (p->ev_fir[i]) (void)hipEventDestroy(p->ev_fir[i]); }
     (void)hipFree(p->d_buf); (void)hipFree(p->d_in); (void)hipFree(p->d_out); (void)hipFree(p->d_tpdf); (void)hipFree(p->d_frame);
-    (void)hipHostFree(p->h_small);
-    (void)hipFree(p->d_tpdf_seq); (void)hipFree(p->d_ready_timeouts); (void)hipFree(p->d_alias);
+    (void)hipHostFree(p->h_small); (void)hipHostFree(p->h_ready_flag);
+    for (auto e : p->launch_ev) if (e) (void)hipEventDestroy(e);
+    (void)hipFree(p->d_tpdf_seq); (void)hipFree(p->d_ready_timeouts); for (auto &x : p->alias) (void)hipFree(x.buf);
     (void)hipFree(p->d_inst_buf); (void)hipFree(p->d_inst_tpdf); (void)hipFree(p->d_inst_frame); (void)hipFree(p->d_inst_seq);
     delete p;
 }
@@ -4362,7 +4468,7 @@ static bool rows_whole(const Plan &pl, const BlockIO &io) { return windows_overl
  * and STORED to the output row, so the copy and the launches do not meet), and the pieces of a level can run side by side again.
  * This is the reference's one samples[] frame: an IO inside both windows shows the input unless somebody stores it.  (The reference's
  * own dacdiy1.bin has its outputs on both sides of its inputs: no pair of windows that take all of them can be kept apart.) */
-__global__ void show_through(const unsigned *in, int in_stride, int in_base, unsigned *out, int out_stride, int out_base,
+static __global__ void show_through(const unsigned *in, int in_stride, int in_base, unsigned *out, int out_stride, int out_base,
                              int nframes, int lo, int hi, size_t in_inst_words, size_t out_inst_words)
 {
     const int w = hi - lo;
@@ -4542,6 +4648,7 @@ int avdsp_hip_download_words(avdsp_hip_prog *p, int32_t *host_buf, int first, in
 {
     if (check_range(p, first, n)) return -1;
     HIP_TRY(hipDeviceSynchronize());
+    READY_CHECK(p);                                      /* the state the caller asks for would not be the reference's */
     if (rings_to_mirror(p)) return -1;
     HIP_TRY(hipDeviceSynchronize());
     if (n) HIP_TRY(hipMemcpy(host_buf + first, p->d_buf + first, (size_t)n * 4, hipMemcpyDeviceToHost));
@@ -4563,6 +4670,7 @@ int avdsp_hip_run_block(avdsp_hip_prog *prog, int plan, const void *d_in, int in
     if (plan < 0 || plan >= (int)prog->plans.size()) return set_err("bad plan id %d", plan);
     Plan &pl = prog->plans[plan];
     if (nframes <= 0) return 0;
+    READY_CHECK(prog);                                   /* a time-out of an earlier block: this call fails, and every one after it */
     /* the chain kernels index the sample blocks with the chains' IO numbers: check the windows once here.
      * (The interpreter keeps a whole samples[] frame: slots outside the caller's windows are the frame's
      * own, persistent like the host's array, e.g. values one strand leaves for the next frame.) */
@@ -4596,13 +4704,18 @@ int avdsp_hip_run_block(avdsp_hip_prog *prog, int plan, const void *d_in, int in
         const bool direct = pl.format != 2 && (pl.lane_mode || (!pl.bq.empty() && !pl.overlap_ok));
         if (direct && nframes > 1 && i0 < o1 && o0 < i1) {
             const size_t words = (size_t)nframes * in_stride;
-            if (words > prog->alias_cap) {
-                HIP_TRY(hipDeviceSynchronize());
-                (void)hipFree(prog->d_alias); prog->d_alias = nullptr; prog->alias_cap = 0;
-                HIP_TRY(hipMalloc((void **)&prog->d_alias, words * 4)); prog->alias_cap = words;
+            /* one copy buffer per caller's stream: a buffer is only ever written and read in that stream's order (two in-place calls on
+             * different streams used to share one -- a race); growing one waits for its own stream, not for the device */
+            avdsp_hip_prog::Alias *al = nullptr;
+            for (auto &x : prog->alias) if (x.stream == (hipStream_t)stream) al = &x;
+            if (!al) { prog->alias.push_back({(hipStream_t)stream, nullptr, 0}); al = &prog->alias.back(); }
+            if (words > al->cap) {
+                HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+                (void)hipFree(al->buf); al->buf = nullptr; al->cap = 0;
+                HIP_TRY(hipMalloc((void **)&al->buf, words * 4)); al->cap = words;
             }
-            HIP_TRY(hipMemcpyAsync(prog->d_alias, d_in, words * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
-            d_in = prog->d_alias;
+            HIP_TRY(hipMemcpyAsync(al->buf, d_in, words * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+            d_in = al->buf;
         }
     }
     if (pl.lane_mode) {
@@ -4792,6 +4905,7 @@ int avdsp_hip_run_block_host(avdsp_hip_prog *prog, int plan, const void *h_in, i
         }
         HIP_TRY(hipStreamSynchronize(prog->s_d2h));
         HIP_TRY(hipStreamSynchronize(prog->s_run));
+        READY_CHECK(prog);                               /* (synchronous: a time-out inside THIS block is this call's error) */
         return 0;
     }
     /* A frame or a few (dspRuntime_N: one): three synchronous copies would be most of the call.  The samples go through a small
@@ -4807,6 +4921,7 @@ int avdsp_hip_run_block_host(avdsp_hip_prog *prog, int plan, const void *h_in, i
         if (avdsp_hip_run_block(prog, plan, prog->d_small, in_stride, in_io_base, prog->d_small + in_words, out_stride, out_io_base,
                                 nframes, fir_impl, biquad_impl, nullptr)) return -1;
         HIP_TRY(hipDeviceSynchronize());
+        READY_CHECK(prog);
         memcpy(h_out, ho, out_words * 4);
         return 0;
     }
@@ -4815,6 +4930,7 @@ int avdsp_hip_run_block_host(avdsp_hip_prog *prog, int plan, const void *h_in, i
     if (avdsp_hip_run_block(prog, plan, prog->d_in, in_stride, in_io_base, prog->d_out, out_stride, out_io_base,
                             nframes, fir_impl, biquad_impl, nullptr)) return -1;
     HIP_TRY(hipDeviceSynchronize());
+    READY_CHECK(prog);                                   /* (synchronous: a time-out inside THIS block is this call's error) */
     HIP_TRY(hipMemcpy(h_out, prog->d_out, out_words * 4, hipMemcpyDeviceToHost));
     return 0;
 }
@@ -4835,6 +4951,7 @@ int avdsp_hip_wait_block_host(avdsp_hip_prog *prog, int max_in_flight)
         if (sl.h_out) { unpin_block(prog, sl.h_out); sl.h_out = nullptr; }
         prog->hq_waited++;
     }
+    READY_CHECK(prog);                                   /* the blocks let through are complete: were they computed on complete windows? */
     return (int)(prog->hq_submitted - prog->hq_waited);
 }
 
@@ -4899,6 +5016,7 @@ int avdsp_hip_run_levels(avdsp_hip_prog *prog, const int *plans, const int *leve
 {
     hipStream_t main = (hipStream_t)stream;
     int at = 0;
+    READY_CHECK(prog);
     /* windows that share IO numbers: the shared columns go from the input rows to the output rows once, here; the launches behind it
      * move their cores' slots only (show_through) */
     BlockIO wio{};
@@ -5321,6 +5439,7 @@ int avdsp_hip_prog_set_option(avdsp_hip_prog *prog, int key, int value)
     case AVDSP_OPT_FIR_SPLIT: prog->fir_split = value != 0; return 0;
     case AVDSP_OPT_FIR_LEAN: if (value < -1 || value > 1) return set_err("fir_lean: -1 (auto), 0 or 1"); prog->fir_lean = value; return 0;
     case AVDSP_OPT_RING_WAIT: prog->ring_wait_host = value != 0; return 0;
+    case AVDSP_OPT_READY_TEST: prog->ready_test = value > 0 ? value : 0; return 0;
     case AVDSP_OPT_FIR_LAUNCH: if (value < -1 || value > 2) return set_err("fir_launch: -1 (auto), 0, 1 or 2"); prog->fir_launch_mode = value; return 0;
     case AVDSP_OPT_FIR_ROWS: if (value != 0 && value != 1 && value != 2 && value != 4) return set_err("fir_tile row tiles: 0 (auto), 1, 2 or 4");
                              prog->fir_rows = value; return 0;
@@ -5336,6 +5455,28 @@ int avdsp_hip_prog_set_option(avdsp_hip_prog *prog, int key, int value)
     }
     return set_err("unknown device option %d", key);
 }
+
+/* what the launch arrangement turned out to be (dspRuntimeGetOption "side_by_side", "ready_mode") */
+int avdsp_hip_prog_get_option(avdsp_hip_prog *prog, int key)
+{
+    switch (key) {
+    case AVDSP_OPT_SIDE_BY_SIDE: return prog->s_bq ? prog->side_by_side : -1;      /* -1: not probed yet (no overlapped launch so far) */
+    case AVDSP_OPT_READY_MODE:   return prog->ready_mode_now;
+    }
+    return -1;
+}
+
+/* the caller has heard of the time-outs (dspRuntimeReset; dspRuntimeSetOption("ready_timeouts", 0)): count and mark start again */
+int avdsp_hip_ready_clear(avdsp_hip_prog *prog)
+{
+    if (!prog->d_ready_timeouts) return 0;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemset(prog->d_ready_timeouts, 0, 4));
+    if (prog->h_ready_flag) *(volatile unsigned *)prog->h_ready_flag = 0;
+    return 0;
+}
+
+int avdsp_hip_last_error_is_ready_timeout(void) { return g_err_ready ? 1 : 0; }
 
 int avdsp_hip_ready_timeouts(avdsp_hip_prog *prog)
 {
@@ -5363,6 +5504,8 @@ int avdsp_hip_profile_read(avdsp_hip_prog *prog, int kind, double *total_ms, int
         float ms = 0.0f;
         HIP_TRY(hipEventElapsedTime(&ms, sp.a, sp.b));
         sum += ms; n++; pairs += sp.pair;
+        for (int i = 0; i < avdsp_hip_prog::kAhead; i++)       /* (an event that stood for a FIR's end goes back to the pool: that FIR HAS ended) */
+            if (prog->ev_fir_now[i] == sp.b) { prog->ev_fir_now[i] = prog->ev_fir[i]; prog->ev_fir_set[i] = false; }
         prog->free_events.push_back(sp.a); prog->free_events.push_back(sp.b);
     }
     prog->last_read_pairs[kind & 7] = pairs;

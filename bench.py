@@ -5,10 +5,17 @@ One step = one block of B frames pushed through every channel chain of the progr
 (LOAD_GAIN -> 16 biquads -> 4096-tap FIR -> SAT0DB -> STORE for the north-star workload) by
 dspRuntimeBlockDevice(); inputs and outputs are resident in HBM before the timed region starts.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload north|cfg2|cfg3|cfg4|cfg5]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload north|cfg2|cfg3|cfg4|cfg5] [--block B]
 
-N > 1 is launched by the driver as  python -m torch.distributed.run --nproc-per-node N bench.py ...
-one rank per GPU.  The experiment is the one BASELINE.json names: a FIXED program (north: 4096 channels;
+N > 1 runs one rank per GPU, whoever starts it:
+  * under a launcher (the driver's  python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...):
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment; WORLD_SIZE != --gpus is an ERROR (exit 2),
+    not a warning -- a line that says n_gpus 1 for a job asked to run on 8 must not exist;
+  * bare (python bench.py --gpus N, WORLD_SIZE unset): this process -- which has not touched the GPU and never will --
+    times the CPU baseline, then starts that very launcher command as a CHILD process (N fresh rank processes; nothing
+    is exec'ed over a process that has initialised HIP), hands the CPU figure to rank 0 through a temporary file
+    (AVDSP_BENCH_CPU_JSON), lets rank 0's JSON line through on stdout and leaves with the children's exit code.
+The experiment is the one BASELINE.json names: a FIXED program (north: 4096 channels;
 cfg5: 16384) at 1, 2, 4 and 8 GPUs = STRONG scaling.  Every rank loads the same unsharded program and
 calls dspRuntimeSetShard(rank, world): the library cuts the lowered chain list into contiguous balanced
 ranges, the rank feeds its column slice of the [B][C] block and gets its slice of the output.  Channels
@@ -218,8 +225,12 @@ def verify_against_reference_pins(args, make_runtime, workload, shard_rank, shar
     xs = torch.from_numpy(np.ascontiguousarray(x[:, in_base - C:in_base - C + Cl])).cuda()
     ys = torch.zeros((frames, Cl), dtype=xs.dtype, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
-    for k in range(frames // B):
-        r.run_block_device(xs[k * B:].data_ptr(), Cl, in_base, ys[k * B:].data_ptr(), Cl, out_base, B, stream)
+    # the pins are per 1024-frame block of the case; --block pushes the same frames through in calls of that many frames (the last
+    # one ragged when it does not divide) -- "nframes successive dspRuntime_N calls" means the concatenation is the same bits
+    Bcall = args.block if args.block > 0 else B
+    for f0 in range(0, frames, Bcall):
+        n = min(Bcall, frames - f0)
+        r.run_block_device(xs[f0:].data_ptr(), Cl, in_base, ys[f0:].data_ptr(), Cl, out_base, n, stream)
     torch.cuda.synchronize()
     out = ys.cpu().numpy()
     w = np.ascontiguousarray(out).view(np.uint32)
@@ -230,6 +241,8 @@ def verify_against_reference_pins(args, make_runtime, workload, shard_rank, shar
         raise VerificationError(f"shard {shard_rank}/{shard_world}: {bad.size} of {Cl} channels differ from the "
                                 f"reference's pins of {name} (first: channel {out_base + int(bad[0])})")
     what = f"{name}: blocks 0..{frames // B - 1}, channels {out_base}..{out_base + Cl - 1}: per-channel word sums vs reference pins"
+    if Bcall != B:
+        what += f" (pushed through in calls of {Bcall} frames)"
     if shard_world == 1:
         for k, sha_want in enumerate(case["block_sha"]):
             if hashlib.sha256(np.ascontiguousarray(out[k * B:(k + 1) * B]).tobytes()).hexdigest() != sha_want:
@@ -239,6 +252,40 @@ def verify_against_reference_pins(args, make_runtime, workload, shard_rank, shar
         what += " + SHA-256 of every block and of the final state"
     r.release()
     return what
+
+
+def launch_ranks(args, fmt, S, T, B):
+    """python bench.py --gpus N without a launcher: be the launcher.  This process makes no HIP call (counting devices does not
+    initialise the GPU on this image); it times the CPU baseline, then runs
+        python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <the same arguments>
+    as a child -- N fresh rank processes -- with the CPU figure in a temporary file for rank 0.  stdout / stderr are the children's own
+    (rank 0 prints the one JSON line); returns their exit code."""
+    import socket
+    import subprocess
+    import tempfile
+    backend = os.environ.get("AVDSP_DIST_BACKEND", "nccl")
+    if backend == "nccl":
+        import torch
+        ndev = torch.cuda.device_count()
+        if ndev < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but this node shows {ndev} GPU(s); one rank per GPU over RCCL "
+                  f"(AVDSP_DIST_BACKEND=gloo rehearses several ranks on one card)", file=sys.stderr)
+            return 2
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    with tempfile.TemporaryDirectory() as d:
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(fmt, S, T, B, budget_s=args.cpu_budget)
+            path = os.path.join(d, "cpu_baseline.json")
+            with open(path, "w") as f:
+                json.dump(cpu, f)
+            env["AVDSP_BENCH_CPU_JSON"] = path
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+        sys.stdout.flush()
+        return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -264,11 +311,29 @@ def main():
                     "(tools/fir_timeline.py: 2.15 GHz in-kernel after 6 blocks, 2.36 GHz after 200) and a short run would be timed on the ramp")
     ap.add_argument("--profile-stride", type=int, default=0, help="time every n-th launch of the dominant kernel in the timed region with its dispatch stamps (0: the default below)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=10.0, help="seconds of CPU work for the all-cores leg of cpu_baseline (the single thread gets 0.35 of it)")
+    ap.add_argument("--block", type=int, default=0, help="frames per block call (0: the workload's own, 1024 for the BASELINE configs): the host's period is the block "
+                    "(linux/avdsp_plugin.c:71-98 hands dsp_transfer 64..1024 frames); blocks above 1024 frames are cut into 1024-frame launches by the library")
+    ap.add_argument("--dist", action="store_true", help="initialise the process group and run every collective leg even at world 1 (under a launcher with "
+                    "--nproc-per-node 1): what tests/ use to execute each RCCL call bench.py makes on a one-GPU box")
     ap.add_argument("--no-verify", action="store_true", help="skip the pre-timing check of this rank's columns against the reference's pins")
     ap.add_argument("--gather", action="store_true", help="(the default for N > 1) also time an RCCL all_gather of the ranks' [B][C/N] output blocks and an all_reduce of "
                     "their checksums (SURVEY.md 8e: block-boundary collectives), reported BESIDE value, never inside it")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the block-boundary collectives leg")
     args = ap.parse_args()
+
+    fmt, C, S, T, B = WORKLOADS[args.workload]
+    if args.block > 0:
+        B = args.block
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    launched = "WORLD_SIZE" in os.environ
+    if launched and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher's WORLD_SIZE is {os.environ['WORLD_SIZE']}: refusing to print a line "
+              f"for a job of another size", file=sys.stderr)
+        sys.exit(2)
+    if not launched and args.gpus > 1:
+        sys.exit(launch_ranks(args, fmt, S, T, B))
 
     import torch                      # first: its bundled HIP runtime must be the process's only one
     import torch.distributed as dist
@@ -278,23 +343,31 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    use_dist = world > 1 or (args.dist and launched)
 
-    fmt, C, S, T, B = WORKLOADS[args.workload]
     # The CPU leg runs FIRST, before this process touches the GPU: it starts one child process per host
-    # core, and children must not be forked off a process that has initialised HIP.
+    # core, and children must not be forked off a process that has initialised HIP.  At N > 1 it is rank 0's
+    # too (the other ranks wait for it in init_process_group), unless the process that started the ranks has
+    # already timed it (AVDSP_BENCH_CPU_JSON, see launch_ranks).
     cpu = None
-    if world == 1 and rank == 0 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(fmt, S, T, B)
+    if rank == 0 and not args.no_cpu_baseline:
+        handed = os.environ.get("AVDSP_BENCH_CPU_JSON")
+        if handed and os.path.exists(handed):
+            with open(handed) as f:
+                cpu = json.load(f)
+        else:
+            cpu = cpu_baseline(fmt, S, T, B, budget_s=args.cpu_budget)
     if not torch.cuda.is_available():
         sys.exit("bench.py: no GPU visible; the product path has no CPU fallback")
     # one rank per GPU on a real node; AVDSP_DIST_BACKEND=gloo lets several ranks rehearse the N > 1 path on
     # one card (RCCL refuses two ranks on the same device)
     backend = os.environ.get("AVDSP_DIST_BACKEND", "nccl")
-    device_index = local_rank % torch.cuda.device_count()
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and world > ndev:
+        sys.exit(f"bench.py: {world} ranks over RCCL need {world} GPUs, this node shows {ndev} (AVDSP_DIST_BACKEND=gloo rehearses several ranks on one card)")
+    device_index = local_rank % ndev
     torch.cuda.set_device(device_index)
-    if world > 1:
+    if use_dist:
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
         else:
@@ -340,7 +413,7 @@ def main():
         except VerificationError as e:
             verify_error = str(e)
     verified_ranks = 1 if (verified is not None and not verify_error) else 0
-    if world > 1:
+    if use_dist:
         dev = "cuda" if backend == "nccl" else "cpu"
         ok = torch.tensor([0 if verify_error else 1, 1 if (verified is not None and not verify_error) else 0], dtype=torch.int64, device=dev)
         all_ok = ok.clone()
@@ -394,8 +467,10 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    for k in (0, 1, 2):
-        r.kernel_time(k)                                   # drop warm-up launches from the kernel timers
+    warm = [r.kernel_time(k) for k in (0, 1, 2)]            # (reading drops the warm-up launches from the kernel timers)
+    # ... and says how long the dominant kernel's launch is: a launch that carries its stamps costs the stream ~5 us, 1 % of a 0.5-ms
+    # FIR and 15 % of a 35-us cascade
+    dom_ms = warm[1][0] / warm[1][1] if (T and warm[1][1]) else (warm[0][0] / warm[0][1] if warm[0][1] else 0.0)
     bq_side = fir_alone = None
     if T and S:
         r.set_option("overlap", 0)
@@ -414,22 +489,25 @@ def main():
     # every timed launch of a short run carries its event pair (>= 16 samples); longer runs sample every n-th (a pair costs the stream ~5 us)
     # (round 4: a launch that carries its stop event costs the stream ~5 us -- cfg3's step 39.8 us with every launch sampled, 35.8 with every
     # fourth, 34.7 with none -- so the timed region samples every fourth launch of the dominant kernel; roofline.timing says how many that made)
-    stride = 4 if args.steps <= 64 else max(1, args.steps // 16)
+    if fir_alone is not None and fir_alone[1]:
+        dom_ms = fir_alone[0] / fir_alone[1]
+    # (round 5: EVERY launch when the dominant kernel's launch is >= 0.2 ms -- the driver's 20 steps then give 20 stamps, not 5)
+    stride = 1 if dom_ms >= 0.2 else (4 if args.steps <= 64 else max(1, args.steps // 16))
     if args.profile_stride > 0:
         stride = args.profile_stride
     r.set_option("profile_stride", stride)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     rank_ms = [elapsed / args.steps * 1e3]
-    if world > 1:
+    if use_dist:
         dev = "cuda" if backend == "nccl" else "cpu"
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         every = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
@@ -439,7 +517,7 @@ def main():
         elapsed = float(t.item())
     # block-boundary collectives (opt-in, beside the metric): every rank's [B][C/N] output gathered on every rank, checksums summed
     gather = None
-    if world > 1 and not args.no_gather:
+    if use_dist and not args.no_gather:
         # (shards differ by at most one chain: every rank hands over max(C/N) columns, the last one of a smaller shard unused)
         cmax = -(-C // world)
         ypad = y if Cl == cmax else torch.nn.functional.pad(y, (0, cmax - Cl))
@@ -591,7 +669,7 @@ def main():
             "config": {"workload": f"{args.workload}: {C} ch x ({S} biquads + {T}-tap FIR), block {B} frames, "
                                    f"DSP_FORMAT {fmt}; {shard_txt}, no data-path collective",
                        "channels": C, "channels_per_gpu": Cl, "sections": S, "taps": T, "block": B, "format": fmt,
-                       "overlap": r.get_option("overlap"), "ready_words": r.get_option("ready_words"), "fir_split": r.get_option("fir_split"), "fir_launch": r.get_option("fir_launch"), "fir_lean": r.get_option("fir_lean"), "ring_wait": r.get_option("ring_wait"), "settle_s": args.settle, "profile_stride": stride},
+                       "overlap": r.get_option("overlap"), "ready_words": r.get_option("ready_words"), "ready_mode": r.get_option("ready_mode"), "side_by_side": r.get_option("side_by_side"), "fir_split": r.get_option("fir_split"), "fir_launch": r.get_option("fir_launch"), "fir_lean": r.get_option("fir_lean"), "ring_wait": r.get_option("ring_wait"), "settle_s": args.settle, "profile_stride": stride},
             "roofline": roof,
             "hbm_frac_step": step_bytes / step_s / 1e9 / PEAK_HBM_GBS,
             "kernels_ms": {"biquad": bq_raw, "fir": fir_raw, "event_pair": pair_ms,
@@ -599,9 +677,12 @@ def main():
         }
         line["verified"] = verified
         line["verified_ranks"] = verified_ranks          # ranks whose own columns matched the reference's pins (every rank checks; any mismatch ends the job)
-        if world > 1:
+        if use_dist:
             line["ranks"] = world
             line["rank_ms_per_step"] = rank_ms
+            line["collectives"] = {"backend": backend, "world": world,
+                                   "calls": "all_reduce MIN/SUM (verification), barrier, all_gather + all_reduce MAX (times)"
+                                            + ("" if gather is None else ", all_gather of the [B][C/N] output blocks + all_reduce of their checksums")}
         if gather is not None:
             line["gather"] = gather
         if host_rate is not None:
@@ -611,7 +692,7 @@ def main():
         print(json.dumps(line), flush=True)
     r.set_option("profile_stride", 1)
     r.release()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -11,8 +11,9 @@
  *   - dsp_FIR() points each rate at its impulse's LENGTH word; the reference points one word early
  *     (encoder/dsp_encoder.c:1311-1313 reads the section header as the first impulse), which its own
  *     runtime then misreads.  dspFir_ImpulseData() adds taps from memory.
- *   - dsp_Hilbert() (external filter-design module), the nanoSHARC import and the text dump files are
- *     not provided; dsp_dumpParameter*() accept and ignore (they never change the program words).
+ *   - the nanoSHARC import and the text dump files are not provided; dsp_dumpParameter*() accept and
+ *     ignore (they never change the program words).  (dsp_Hilbert() is provided since round 5:
+ *     dsp_filters.h:76, the design of encoder/dsp_HilbertDesign.c restated in avdsp_encoder.c.)
  * Errors: like the reference, a malformed program prints "FATAL ERROR : ..." and exit(1)s.
  */
 #ifndef AVDSP_ENCODER_H_
@@ -202,6 +203,9 @@ int dsp_HP_BES8_3DB(dspFilterParam_t freq);
 int dsp_LP_BUT8(dspFilterParam_t freq);      int dsp_HP_BUT8(dspFilterParam_t freq);
 int dsp_LP_LR8(dspFilterParam_t freq);       int dsp_HP_LR8(dspFilterParam_t freq);
 int dsp_filter(int type, dspFilterParam_t freq, dspFilterParam_t Q, dspGainParam_t gain);
+/* dsp_filters.h:76: one branch of a 90-degree phase splitter as a bank of `stages` (1 .. 10) all-pass cells (c - z^-2)/(1 - c z^-2);
+ * transition = width of the transition band in Hz; phase 0: the reference branch, else the +90 degree branch */
+int dsp_Hilbert(int stages, dspFilterParam_t transition, dspGainParam_t phase);
 
 /* ---- dsp_fileaccess.h:38,41: program words to / from a binary file; returns the word count or -1 ---- */
 int dspCreateBuffer(char *name, int *buff, int size);

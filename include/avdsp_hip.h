@@ -218,7 +218,10 @@ int avdsp_hip_plan_strands(const avdsp_hip_prog *prog, int plan);      /* strand
  * block k (side stream; see launch_all in avdsp_kernels.hip) -- the caller then guarantees that a block's input is
  * complete in memory when the call is made.                                                                     */
 enum { AVDSP_OPT_OVERLAP = 0, AVDSP_OPT_PROFILE_STRIDE = 1, AVDSP_OPT_FIR_ROWS = 3, AVDSP_OPT_HOST_SPLIT = 4, AVDSP_OPT_HOST_PIN = 5,
-       AVDSP_OPT_READY_WORDS = 6, AVDSP_OPT_LANE_HW = 7, AVDSP_OPT_FIR_SPLIT = 8, AVDSP_OPT_FIR_LAUNCH = 9, AVDSP_OPT_FIR_LEAN = 10, AVDSP_OPT_RING_WAIT = 11 };
+       AVDSP_OPT_READY_WORDS = 6, AVDSP_OPT_LANE_HW = 7, AVDSP_OPT_FIR_SPLIT = 8, AVDSP_OPT_FIR_LAUNCH = 9, AVDSP_OPT_FIR_LEAN = 10, AVDSP_OPT_RING_WAIT = 11,
+       AVDSP_OPT_SIDE_BY_SIDE = 13, /* read-only: 1 kernels of two queues were seen to run at once (the precondition of ready words), 0 not (dispatches are serialised: a PMC profiler, a debugger), -1 not probed yet */
+       AVDSP_OPT_READY_MODE = 14,   /* read-only: how the latest overlapped launch's FIR found its cascades' block: 0 event, 1 / 2 ready words */
+       AVDSP_OPT_READY_TEST = 12 /* tests only: that many coming "ready_words" 2 launches never get their words set (their FIR waves time out) */ };
 /* FIR_LEAN: fir_tile's chunk boundary with a third of the vector instructions: -1 by the plan (default), 0 never, 1 always. */
 /* READY_WORDS (under OVERLAP): how a block's FIR finds its cascades' block in the rings: 0 an event between the two queues, 1 per-chain
  * words published by the cascade's waves (write-through stores) and polled by the FIR's, 2 the words set by a kernel behind the
@@ -233,6 +236,9 @@ enum { AVDSP_OPT_OVERLAP = 0, AVDSP_OPT_PROFILE_STRIDE = 1, AVDSP_OPT_FIR_ROWS =
  * reference's dspMulFloatFloat bit for bit (fir_lane_hw, chain_rows); 0: the integer restatement of the product throughout. */
 /* READY_WORDS 1: under OVERLAP the FIR finds its cascades' blocks through per-chain ready words polled inside the kernel instead of
  * an event between the two queues (0, the default: the event -- the words measured slower on every configuration). */
+int avdsp_hip_prog_get_option(avdsp_hip_prog *prog, int key);   /* AVDSP_OPT_SIDE_BY_SIDE, AVDSP_OPT_READY_MODE */
+int avdsp_hip_ready_clear(avdsp_hip_prog *prog);       /* the caller acknowledges the time-outs: count and sticky mark start again */
+int avdsp_hip_last_error_is_ready_timeout(void);       /* 1: the latest failure of this thread was the sticky ready-word time-out (the host maps it to -11) */
 int avdsp_hip_ready_timeouts(avdsp_hip_prog *prog);    /* waves whose bounded wait for a ready word ran out since the program was loaded (0 unless something is broken) */
 /* PROFILE_STRIDE n: with profiling on, only every n-th launch of a kind is bracketed by events */
 /* FIR_ROWS: row tiles per wave of fir_tile, 0 = auto.  HOST_SPLIT: frames per piece of a host-pointer block (copies and kernels pipelined), 0 = whole block.

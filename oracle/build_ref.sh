@@ -57,6 +57,8 @@ gcc $CF -I"$ENC" -I"$RT" -o "$OUT/ref_encode_ops" "$HERE/ref_encode_ops.c" \
     -L"$OUT" -lavdspencoder -Wl,-rpath,'$ORIGIN' -lm -ldl
 gcc $CF -I"$ENC" -I"$RT" -o "$OUT/enc_sweep" "$HERE/enc_sweep.c" \
     -L"$OUT" -lavdspencoder -Wl,-rpath,'$ORIGIN' -lm -ldl
+gcc $CF -I"$ENC" -I"$RT" -o "$OUT/enc_hilbert" "$HERE/enc_hilbert.c" \
+    -L"$OUT" -lavdspencoder -Wl,-rpath,'$ORIGIN' -lm -ldl
 gcc $CF -I"$ENC" -I"$RT" -o "$OUT/dspcreate" "$ENC/dspcreate.c" \
     -L"$OUT" -lavdspencoder -Wl,-rpath,'$ORIGIN' -lm -ldl
 for P in crossoverLV6 oktodac_diy testfunction; do

@@ -1,0 +1,54 @@
+"""bench.py's command line where no GPU is needed: who starts the ranks, and what it refuses.
+
+VERDICT r04 Missing #2: `python bench.py --gpus N` must not depend on who launches it, and must never print a line for a
+job of another size than the one asked for."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "AVDSP_BENCH_CPU_JSON")}
+    env.update(kw)
+    return env
+
+
+def test_world_size_that_contradicts_gpus_is_an_error_not_a_warning():
+    """under a launcher: WORLD_SIZE 2 with --gpus 4 leaves with code 2 before anything runs, and prints no JSON line"""
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "4", "--steps", "2"], env=_env(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"),
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode == 2
+    assert "WORLD_SIZE is 2" in p.stderr and not [l for l in p.stdout.splitlines() if l.startswith("{")]
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--steps", "2"], env=_env(WORLD_SIZE="8", RANK="0", LOCAL_RANK="0"),
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode == 2
+
+
+def test_bare_gpus_n_over_rccl_needs_n_gpus():
+    """no launcher, --gpus 2, the default backend (RCCL): this container shows no GPU, so the parent refuses (code 2) instead of
+    starting ranks that would hang in their rendezvous or silently share a card"""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("this box has two GPUs: the refusal cannot be provoked")
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--no-cpu-baseline"], env=_env(),
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 2 and "--gpus 2 but this node shows" in p.stderr
+
+
+def test_bare_gpus_n_starts_n_fresh_rank_processes():
+    """no launcher, --gpus 2: the parent starts torch.distributed.run with two fresh rank processes and leaves with THEIR exit
+    code.  Here (no GPU) every rank ends in "no GPU visible; the product path has no CPU fallback" -- which is the point of this
+    test: the ranks were started, each one said so itself, and nothing fell back to a CPU path."""
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("GPU box: tests/test_gpu_headline.py runs the real thing")
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--no-cpu-baseline", "--workload", "cfg2"],
+                       env=_env(AVDSP_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0
+    assert p.stderr.count("no GPU visible; the product path has no CPU fallback") >= 2
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]

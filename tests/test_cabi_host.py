@@ -38,6 +38,21 @@ def test_library_exports_everything_the_headers_declare():
         assert hasattr(L, name), name
 
 
+def test_library_exports_nothing_the_headers_do_not_declare():
+    """The dynamic symbol table of the C ABI is the headers' functions + the reference's four data symbols and NOTHING else: no kernel
+    stub (`show_through` and its `__device_stub__` sat there through round 4), no helper.  What hipcc itself adds to a code object's
+    host side (`__hip_*`, `_fini/_init`, the `.hip_fatbin` handles) is the toolchain's, not the library's."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", rt.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    defined = {l.split()[-1] for l in out.splitlines() if len(l.split()) >= 3 and l.split()[-2] in "TDBRVWi"}
+    ours = {n for n in defined if not n.startswith(("__hip", "_init", "_fini", "__bss_start", "_edata", "_end", "__odr_asan"))}
+    declared = set(declared_functions("avdsp_runtime.h") + declared_functions("avdsp_hip.h"))
+    declared |= {"dspHeaderPtr", "dspBiquadFreqSkip", "dspMantissa", "dspOpcodeText", "dspQNM", "dspQM64", "dspQM32"}
+    extra = sorted(ours - declared)
+    assert not extra, f"exported but not declared in include/*.h: {extra}"
+    assert not [n for n in defined if "show_through" in n or "device_stub" in n]
+
+
 def test_reference_data_symbols():
     L = rt.lib()
     txt = (C.c_char_p * 62).in_dll(L, "dspOpcodeText")

@@ -61,6 +61,49 @@ def test_encoder_sweep_identical_to_reference_encoder(tmp_path, variant):
     same_file(out, os.path.join(GOLDEN_DIR, "enc_sweep_%d_%d_%d.bin" % variant))
 
 
+@pytest.mark.parametrize("variant", [(2, 4, 9), (6, 4, 7), (6, 0, 13), (2, 5, 5)], ids=lambda v: "fmt%d_f%d_%d" % v)
+def test_hilbert_banks_identical_to_reference_encoder(tmp_path, variant):
+    """dsp_Hilbert (encoder/dsp_filters.h:76; design encoder/dsp_HilbertDesign.c): both branches for 1 .. 10 stages at ten transition
+    widths, every encoded rate -- the same bytes as the reference encoder (tests/golden/make_hilbert_goldens.py), Q28 and float."""
+    exe = build_exe(tmp_path, "enc_hilbert", [f"{ROOT}/oracle/enc_hilbert.c"])
+    out = str(tmp_path / "hilbert.bin")
+    subprocess.check_call([exe, *map(str, variant), out], stdout=subprocess.DEVNULL)
+    same_file(out, os.path.join(GOLDEN_DIR, "enc_hilbert_%d_%d_%d.bin" % variant))
+
+
+@pytest.mark.parametrize("stages,width,fs_index,ripple", [(4, 160.0, pb.F48000, 0.5), (3, 120.0, pb.F44100, 1.5), (8, 40.0, pb.F96000, 0.05), (10, 500.0, pb.F48000, 1e-3)])
+def test_hilbert_pair_is_a_90_degree_splitter(stages, width, fs_index, ripple):
+    """What the coefficients are FOR, independent of any fixture: the reference branch behind a one-sample delay (as the reference's
+    own program uses it, dspprogs/oktodac_fabriceo.c:204-208) and the +90 branch differ in phase by 90 degrees over
+    [width, fs/2 - width], both all-pass.  Cells are (c - z^-2) / (1 - c z^-2)."""
+    fs = {pb.F44100: 44100.0, pb.F48000: 48000.0, pb.F96000: 96000.0}[fs_index]
+
+    def bank(phase):
+        def build(L):
+            L.dsp_PARAM()
+            L.dspBiquad_Sections(stages)
+            L.dsp_Hilbert(stages, C.c_double(width), C.c_float(phase))
+            L.dsp_CORE()
+            L.dsp_LOAD(1); L.dsp_STORE(0)
+        words = enc.encode(build, 6, fs_index, fs_index)
+        f = words.view(np.float32)
+        # the bank: [BIQUADS head][per cell: FHILB head, Q, gain, pad, b0 b1 b2 a1-1 a2 (+pad)]: find the cells by their -1.0 / c pattern
+        cs = [float(f[i]) for i in range(len(f) - 4) if f[i + 2] == -1.0 and f[i + 1] == 0.0 and f[i + 3] == -1.0 and f[i] == f[i + 4] and 0.0 < f[i] < 1.0]
+        assert len(cs) == stages, cs
+        return cs
+
+    ref, quad = bank(0.0), bank(90.0)
+    assert all(a < b for a, b in zip(ref, ref[1:])) and all(a < b for a, b in zip(quad, quad[1:]))
+    freqs = np.linspace(width, fs / 2 - width, 400)
+    z = np.exp(-1j * 2 * np.pi * freqs / fs)                 # z^-1
+    H = lambda cs: np.prod([(c - z * z) / (1 - c * z * z) for c in cs], axis=0)
+    hr, hq = H(ref) * z, H(quad)
+    assert np.allclose(np.abs(hr), 1.0, atol=1e-6) and np.allclose(np.abs(hq), 1.0, atol=1e-6)
+    dphi = np.degrees(np.angle(hq / hr))
+    # equiripple: the bound is the design's (order and transition width), e.g. +-1.24 degrees for (3 stages, 120 Hz at 44.1 kHz)
+    assert np.all(np.abs(np.abs(dphi) - 90.0) < ripple), (dphi.min(), dphi.max())
+
+
 @pytest.mark.parametrize("fmt,name", [(2, "tour_int.bin"), (6, "tour_float.bin")])
 def test_opcode_tour_identical_to_reference_encoder(tmp_path, fmt, name):
     exe = build_exe(tmp_path, "tour", [f"{ROOT}/oracle/ref_encode_ops.c"])

@@ -92,6 +92,30 @@ def test_golden(case, impl):
     assert sha(state) == case["state_sha"]
 
 
+with open(os.path.join(GOLDEN_DIR, "hilbert_manifest.json")) as _f:
+    HILBERT = json.load(_f)
+
+
+@pytest.mark.parametrize("generic", [0, 1], ids=["chain_kernels", "interpreter"])
+@pytest.mark.parametrize("case", HILBERT, ids=lambda c: c["name"])
+def test_hilbert_programs_match_the_reference(case, generic):
+    """Programs made of dsp_Hilbert banks by the REFERENCE encoder, run by the reference runtime (tests/golden/make_hilbert_goldens.py):
+    one core of 22 chains with 1 .. 10 all-pass cells each, two chains per input -- on the chain kernels (cascades of ten different
+    lengths in one launch group set; formats 3 / 5: chain_rows) and on the interpreter, outputs and state bit for bit."""
+    fmt = case["fmt"]
+    prog = make_program(case["program"])
+    x = make_input(case["input"], fmt)
+    r = rt.Runtime(fmt, prog, fs=case["fs"], random=case["random"], dither=case["dither"])
+    assert r.rc == case["init_rc"]
+    r.set_option("generic", generic)
+    try:
+        out = r.run_block(x, case["out_stride"], case["in_base"], case["out_base"], block=case["block"])
+        assert (r.core_info(0)["chains"] == 0) == bool(generic)
+        check_against_golden(case, out, r.sync_state(), sha)
+    finally:
+        r.set_option("generic", 0)
+
+
 def _oracle_vs_device(fmt, prog, x, out_stride, in_base, blocks, fs=48000, dither=31, opts=None, exact=True):
     o = po.OracleProgram(fmt, prog, fs=fs, dither=dither)
     r = rt.Runtime(fmt, prog, fs=fs, dither=dither)

@@ -1,0 +1,91 @@
+"""A ready-word time-out is an ERROR at the C ABI (round-4 review, Weak #1; advisor, medium).
+
+"ready_words" 2 -- the library's default where the FIR is the bound -- lets a block's FIR start without waiting for an event of
+its cascades: each FIR wave polls its chain's ready word, bounded (~0.5 s).  When the bound runs out the wave goes on (it must
+end) with whatever the ring holds: wrong samples.  The reference's failures are return codes, never silent
+(runtime/dsp_runtime.c:150-195), so here the wave's mark -- a word in mapped pinned host memory -- turns every later entry point
+into a negative code (-11) with a dspRuntimeLastError() text until the caller acknowledges it.  The test provokes the time-out
+with a test-only option that withholds one launch's ready words."""
+import numpy as np
+import pytest
+
+from avdsp_amd import progbuilder as pb
+from avdsp_amd import runtime as rt
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _release():
+    yield
+    rt.lib().dspRuntimeRelease()
+
+
+def _words(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def test_a_ready_word_timeout_turns_every_later_call_into_an_error():
+    import torch
+    fmt, C, S, T, B = 6, 64, 4, 300, 1024
+    prog = pb.synth_program(fmt, C, S, T)
+    x = pb.lcg_input(4 * B, C, True, seed=77)
+    o = po.OracleProgram(fmt, prog)
+    want = o.run_block(x, C, C, block=B)
+    r = rt.Runtime(fmt, prog)
+    r.set_option("overlap", 1)
+    r.set_option("ready_words", 2)
+    xd = torch.from_numpy(x).cuda()
+    yd = torch.zeros_like(xd)
+    torch.cuda.synchronize()
+    st = torch.cuda.current_stream().cuda_stream
+    for k in range(2):
+        assert r.run_block_device(xd[k * B:].data_ptr(), C, C, yd[k * B:].data_ptr(), C, 0, B, st) == 0
+    torch.cuda.synchronize()
+    assert r.get_option("ready_timeouts") == 0
+    assert (_words(yd[:2 * B].cpu().numpy()) == _words(want[:2 * B])).all()
+
+    r.set_option("ready_test", 1)                           # the next launch's ready words are never set
+    assert r.run_block_device(xd[2 * B:].data_ptr(), C, C, yd[2 * B:].data_ptr(), C, 0, B, st) == 0     # (enqueued: nothing known yet)
+    torch.cuda.synchronize()                                # ~0.5 s: its FIR waves run into their bound
+    assert r.get_option("ready_timeouts") > 0
+    # ... and from here every entry point says so, with a code of its own and a text
+    for call in (lambda: r.run_block_device(xd[3 * B:].data_ptr(), C, C, yd[3 * B:].data_ptr(), C, 0, B, st),
+                 lambda: r.sync_state(),
+                 lambda: r.run_block(x[3 * B:], C, C),
+                 lambda: r.run_block_device(xd[3 * B:].data_ptr(), C, C, yd[3 * B:].data_ptr(), C, 0, B, st)):
+        with pytest.raises(rt.AvdspError) as e:
+            call()
+        assert e.value.code == -11 and "ready word" in str(e.value)
+    # dspRuntimeReset acknowledges (the state the time-out spoiled is zeroed): the program runs again, the reference's bits from zero state
+    assert r.reset(48000) == 0
+    assert r.get_option("ready_timeouts") == 0
+    r.set_option("overlap", 1)
+    r.set_option("ready_words", 2)
+    got = r.run_block(x, C, C, block=B)
+    assert (_words(got) == _words(want)).all()
+    assert (r.sync_state() == o.state).all()
+    r.release()
+
+
+def test_a_timeout_inside_a_synchronous_host_call_is_that_calls_error():
+    """dspRuntimeBlock_N with host pointers returns after the block is complete: a time-out inside THIS block fails THIS call; the
+    acknowledgement by option leaves the (here intact) state alone and the next call succeeds."""
+    fmt, C, S, T, B = 6, 48, 2, 200, 512
+    prog = pb.synth_program(fmt, C, S, T)
+    x = pb.lcg_input(3 * B, C, True, seed=78)
+    r = rt.Runtime(fmt, prog)
+    r.set_option("overlap", 1)
+    r.set_option("ready_words", 2)
+    r.run_block(x[:B], C, C)
+    r.set_option("ready_test", 1)
+    with pytest.raises(rt.AvdspError) as e:
+        r.run_block(x[B:2 * B], C, C)
+    assert e.value.code == -11
+    with pytest.raises(rt.AvdspError):
+        r.run_block(x[2 * B:], C, C)
+    r.set_option("ready_timeouts", 0)                       # acknowledged
+    assert r.get_option("ready_timeouts") == 0
+    r.run_block(x[2 * B:], C, C)
+    r.release()

@@ -36,6 +36,17 @@ def test_oracle_reproduces_reference(case):
     check_against_golden(case, out, o.state, sha)
 
 
+with open(os.path.join(GOLDEN_DIR, "hilbert_manifest.json")) as _f:
+    HILBERT = json.load(_f)
+
+
+@pytest.mark.parametrize("case", HILBERT, ids=lambda c: c["name"])
+def test_oracle_reproduces_reference_on_hilbert_programs(case):
+    """dsp_Hilbert banks (reference encoder) through the reference runtime, all five models, several rates of multi-rate programs
+    (tests/golden/make_hilbert_goldens.py): 22 chains of 1 .. 10 all-pass cells."""
+    test_oracle_reproduces_reference(case)
+
+
 @pytest.mark.parametrize("neg", MANIFEST["init_return_codes"], ids=lambda n: n["case"])
 def test_init_return_codes(neg):
     """dspRuntimeInit / dspRuntimeReset error codes (dsp_runtime.c:119-125,159-194) as the reference returned them."""
