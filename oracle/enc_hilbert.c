@@ -22,7 +22,7 @@ int main(int argc, char **argv)
     opcode_t *buf = (opcode_t *)calloc((size_t)max, sizeof(opcode_t));
     static const double widths[] = { 160.0, 120.0, 40.0, 20.0, 500.0, 1000.0, 77.7, 250.0, 2000.0, 10.0 };
 
-    dspEncoderInit(buf, max, format, fmin, fmax, 24);
+    dspEncoderInit(buf, max, format, fmin, fmax, 32);
     dsp_PARAM();
     int ref[10], quad[10];
     for (int st = 1; st <= 10; st++) {
@@ -37,20 +37,20 @@ int main(int argc, char **argv)
     int fquad = dspBiquad_Sections_Flexible();
     dsp_Hilbert(4, 160.0, 90);
 
-    /* one core: input 8 + (st mod 2) through both branches of every pair -> outputs 0 .. 21 */
+    /* one core: input 24 + (st mod 2) through both branches of every pair -> outputs 0 .. 21 */
     dsp_CORE();
     for (int st = 1; st <= 10; st++) {
-        dsp_LOAD_GAIN_Fixed(8 + (st & 1), 0.5);
+        dsp_LOAD_GAIN_Fixed(24 + (st & 1), 0.5);
         dsp_BIQUADS(ref[st - 1]);
         dsp_SAT0DB();
         dsp_STORE(2 * (st - 1));
-        dsp_LOAD_GAIN_Fixed(8 + (st & 1), 0.5);
+        dsp_LOAD_GAIN_Fixed(24 + (st & 1), 0.5);
         dsp_BIQUADS(quad[st - 1]);
         dsp_SAT0DB();
         dsp_STORE(2 * (st - 1) + 1);
     }
-    dsp_LOAD_GAIN_Fixed(8, 0.5); dsp_BIQUADS(fref);  dsp_SAT0DB(); dsp_STORE(20);
-    dsp_LOAD_GAIN_Fixed(8, 0.5); dsp_BIQUADS(fquad); dsp_SAT0DB(); dsp_STORE(21);
+    dsp_LOAD_GAIN_Fixed(24, 0.5); dsp_BIQUADS(fref);  dsp_SAT0DB(); dsp_STORE(20);
+    dsp_LOAD_GAIN_Fixed(24, 0.5); dsp_BIQUADS(fquad); dsp_SAT0DB(); dsp_STORE(21);
 
     int size = dsp_END_OF_CODE();
     if (dspCreateBuffer(argv[4], (int *)buf, size) != size) { fprintf(stderr, "write failed\n"); return 1; }

@@ -38,8 +38,8 @@ def main():
     for fmt, fname, fs in ((2, "enc_hilbert_2_4_9.bin", 48000), (2, "enc_hilbert_2_4_9.bin", 96000),
                            (3, "enc_hilbert_6_4_7.bin", 48000), (4, "enc_hilbert_6_4_7.bin", 44100),
                            (5, "enc_hilbert_6_0_13.bin", 192000), (6, "enc_hilbert_6_0_13.bin", 8000), (6, "enc_hilbert_6_4_7.bin", 96000)):
-        run_case(f"hilbert_f{fmt}_fs{fs}", fmt, dict(kind="file", name=fname), lcg(600, 2, seed=31 + fmt), 22, 8, 0, fs=fs,
-                 random=0, dither=31, block=64, scratch=24, full=True, manifest=manifest)
+        run_case(f"hilbert_f{fmt}_fs{fs}", fmt, dict(kind="file", name=fname), lcg(600, 2, seed=31 + fmt), 22, 24, 0, fs=fs,
+                 random=0, dither=31, block=64, scratch=32, full=True, manifest=manifest)
     with open(os.path.join(OUT, "hilbert_manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1)
     print(f"{len(manifest)} runtime cases, {len(VARIANTS)} encoder fixtures")
