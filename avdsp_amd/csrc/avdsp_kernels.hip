@@ -3936,7 +3936,8 @@ int launch_all(avdsp_hip_prog *prog, Plan &pl, BlockIO io, int fir_impl, int biq
              * has ended" just as well, and a recorded event is a marker packet the next dispatch queues behind: with every launch of a
              * 0.5-ms FIR timed the step was 0.5110 ms against 0.5045 with every fourth) */
             prog->ev_fir_now[slot] = prog->ev_fir[slot];
-            if (!rides && mode == 1 && prog->last_ride_stop) prog->ev_fir_now[slot] = prog->last_ride_stop;
+            static const bool timer_doubles = !getenv("AVDSP_TIMER_DOUBLES") || atoi(getenv("AVDSP_TIMER_DOUBLES")) != 0;
+            if (!rides && mode == 1 && prog->last_ride_stop && timer_doubles) prog->ev_fir_now[slot] = prog->last_ride_stop;
             else if (!rides) HIP_TRY(hipEventRecord(prog->ev_fir[slot], stream));
         }
         prog->ev_fir_set[slot] = true;

@@ -612,6 +612,11 @@ def main():
         step_bytes = 8.0 * Cl * B + 68.0 * S * Cl + (8.0 * (T - 1) * Cl + 4.0 * T * Cl if T else 0.0)
         # several ranks: rank 0's shard, if that shard was profiled alone (profiles/traffic.json has north and cfg5 in 8)
         traffic_key = f"{args.workload} shard {args.shard}" if args.shard else (args.workload if world == 1 else f"{args.workload} shard 0/{world}")
+        fir_untimed = bool(T and not fir_n and fir_alone is not None and fir_alone[1])
+        if fir_untimed:
+            # --profile-stride beyond the run: no launch of the timed region carried its stamps (the un-sampled step); the roofline is
+            # then the kernel alone, from the ten untimed steps in front of the timed region, and says so
+            fir_raw, fir_n, fir_pairs = fir_alone[0] / fir_alone[1], fir_alone[1], 0
         if T and fir_n:
             # `frac` from the kernel's own start / end stamps of every timed launch (rocprofv3's kernel average of the same command
             # agrees, profiles/)
@@ -624,7 +629,8 @@ def main():
             fir_bytes = (4.0 * Cl * B + 4.0 * (T - 1 + B) * Cl + 4.0 * T * Cl) / launches_per_step   # out, window, taps
             roof = dict(bound="mfma", kernel=kname, achieved=ach,
                         peak=PEAK_F64_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_F64_TFLOPS,
-                        timing=timing_label(fir_n, fir_pairs),
+                        timing=(timing_label(fir_n, fir_pairs) if not fir_untimed else
+                                f"NO launch of the timed region was stamped (profile_stride {stride}): dispatch stamps of {fir_n} launches of the ten untimed steps in front of it, overlap off -- the kernel alone"),
                         traffic=pmc_traffic(traffic_key, kname), traffic_source="profiles/traffic.json (committed rocprofv3 --pmc passes of this command, not this run)",
                         hbm_frac=fir_bytes / per_launch / 1e9 / PEAK_HBM_GBS,
                         launch_ms=per_launch * 1e3, launches=fir_n)
