@@ -1079,9 +1079,50 @@ __global__ __launch_bounds__(kBlock) void biquad_row(const BiquadArgs a)
     };
     const int first_steady = (2 * L + 1 + 15) / 16;     /* batches with 16 b >= 2 L + 1 ... */
     const int end_steady = B >= 16 ? (B - 16) / 16 + 1 : 0;      /* ... and 16 b + 15 <= B - 1 */
+    /* Round 5 (tools/cascade_timeline.py --block 256): a canonical batch cost ~2 400 cycles whatever its sixteen steps were made of --
+     * masked steps of 21 instructions or, tried, steps of 12 -- because it ENDS with `r1 = r2; r2 = r3; r3 = rn`: the last of those
+     * moves a register that a load issued at the batch's own start is still in flight to, the compiler puts s_waitcnt vmcnt(0) in
+     * front of it, and a batch is shorter than a trip to memory.  So:
+     *   - the first three batches (the fill and one steady batch) are written out with named slots like the steady loop's: a fetched
+     *     word goes straight into the slot the staged one has left, nothing in flight is moved, and after three the slots hold
+     *     batches b + 1, b + 2, b + 3 in order again;
+     *   - the batches behind the steady loop fetch only frames the block HAS: the samples of the drain do not exist, and the words of
+     *     the few steady batches left over are in the queue already (a block of 96 n + 32 .. 96 n + 80 frames leaves up to two to fetch
+     *     the old way). */
+    const int nin = (B + 15) / 16;                      /* batches of input the block has */
+    auto batch_tail = [&](int bb) __attribute__((always_inline)) {
+        const int u0 = 16 * bb;
+        stage((bb + 1) & 1, r1);
+        unsigned rn = 0;
+        if (bb + 4 < nin) rn = fetch_next();
+        take((bb + 1) & 1, xb);
+        unsigned w;
+        if (u0 >= 2 * L + 1 && u0 + 15 <= B - 1) w = steady_steps(xa);
+        else w = edge_steps(u0, xa);
+        flush(u0, w);
+        r1 = r2; r2 = r3; r3 = rn;
+#pragma unroll
+        for (int k = 0; k < 16; k++) xa[k] = xb[k];
+    };
+    auto batch_head = [&](int bb, const unsigned (&x)[16], unsigned (&xn)[16], unsigned &rslot) __attribute__((always_inline)) {
+        const int u0 = 16 * bb;
+        stage((bb + 1) & 1, rslot);
+        rslot = fetch_next();
+        take((bb + 1) & 1, xn);
+        unsigned w;
+        if (u0 >= 2 * L + 1 && u0 + 15 <= B - 1) w = steady_steps(x);
+        else w = edge_steps(u0, x);
+        flush(u0, w);
+    };
     int b = 0;
     BQ_STAMP(1);
-    for (; b < nb && b < first_steady; b++) batch_canon(b);
+    if (B >= 96) {                                      /* (three batches and then some: shorter blocks take the plain loop) */
+        batch_head(0, xa, xb, r1); batch_head(1, xb, xa, r2); batch_head(2, xa, xb, r3);
+#pragma unroll
+        for (int k = 0; k < 16; k++) xa[k] = xb[k];
+        b = 3;
+    } else
+        for (; b < nb && b < first_steady; b++) batch_canon(b);
     BQ_STAMP(26);
     if (b + 6 <= end_steady) {
         if (lean) {
@@ -1094,7 +1135,7 @@ __global__ __launch_bounds__(kBlock) void biquad_row(const BiquadArgs a)
             for (; b + 6 <= end_steady; b += 6) six(b, std::false_type{}, std::false_type{});
     }
     BQ_STAMP(27);
-    for (; b < nb; b++) batch_canon(b);
+    for (; b < nb; b++) batch_tail(b);
     BQ_STAMP(28);
 #undef AVDSP_ROW_EDGE
 #undef AVDSP_ROW_BLOCK4
@@ -1362,9 +1403,42 @@ __global__ __launch_bounds__(kBlock) void biquad_row_i64(const BiquadArgs a)
     };
     const int first_steady = (2 * L + 1 + 15) / 16;
     const int end_steady = B >= 16 ? (B - 16) / 16 + 1 : 0;
+    /* (round 5, as in biquad_row: the first three batches with named slots, the batches behind the steady loop without fetches of
+     * frames the block does not have -- a canonical batch ends by moving a register its own fetch is still in flight to) */
+    const int nin = (B + 15) / 16;
+    auto batch_tail = [&](int bb) __attribute__((always_inline)) {
+        const int u0 = 16 * bb;
+        stage((bb + 1) & 1, r1);
+        unsigned rn = 0;
+        if (bb + 4 < nin) rn = fetch_next();
+        take((bb + 1) & 1, xb);
+        unsigned w;
+        if (u0 >= 2 * L + 1 && u0 + 15 <= B - 1) w = steady_checked(u0, xa);
+        else w = edge_steps(u0, xa);
+        flush(u0, w);
+        r1 = r2; r2 = r3; r3 = rn;
+#pragma unroll
+        for (int k = 0; k < 16; k++) xa[k] = xb[k];
+    };
+    auto batch_head = [&](int bb, const unsigned (&x)[16], unsigned (&xn)[16], unsigned &rslot) __attribute__((always_inline)) {
+        const int u0 = 16 * bb;
+        stage((bb + 1) & 1, rslot);
+        rslot = fetch_next();
+        take((bb + 1) & 1, xn);
+        unsigned w;
+        if (u0 >= 2 * L + 1 && u0 + 15 <= B - 1) w = steady_checked(u0, x);
+        else w = edge_steps(u0, x);
+        flush(u0, w);
+    };
     int b = 0;
     BQ_STAMP(1);
-    for (; b < nb && b < first_steady; b++) batch_canon(b);
+    if (B >= 96) {
+        batch_head(0, xa, xb, r1); batch_head(1, xb, xa, r2); batch_head(2, xa, xb, r3);
+#pragma unroll
+        for (int k = 0; k < 16; k++) xa[k] = xb[k];
+        b = 3;
+    } else
+        for (; b < nb && b < first_steady; b++) batch_canon(b);
     BQ_STAMP(26);
     if (b + 6 <= end_steady) {
         if (lean) {
@@ -1375,7 +1449,7 @@ __global__ __launch_bounds__(kBlock) void biquad_row_i64(const BiquadArgs a)
             for (; b + 6 <= end_steady; b += 6) six(b, std::false_type{});
     }
     BQ_STAMP(27);
-    for (; b < nb; b++) batch_canon(b);
+    for (; b < nb; b++) batch_tail(b);
     BQ_STAMP(28);
 #undef AVDSP_ROWI_EDGE
 #undef AVDSP_ROWI_BLOCK4
@@ -1640,6 +1714,10 @@ struct FirTileArgs {
     BlockIO io;
     unsigned *ready; unsigned seq; unsigned *timeouts;      /* chain_ready_wait: null = the launch is ordered behind its cascades by the stream / an event */
     int ready_acquire;                                      /* 0: the words were set by a kernel behind the cascade (no acquire needed, chain_ready_wait) */
+    int wpc_shift;                           /* fir_tile: log2 of the tiles (waves) a chain has in THIS launch: ceil(frames / tile), 1, 2 or 4, at most
+                                                TileGeom::WPC.  Round 5: a block of 256 frames is ONE tile of a one-row-tile wave, and with the waves of a
+                                                workgroup fixed at the four tiles of a 1024-frame block three of them left at once while the workgroup kept its
+                                                LDS -- two live waves per CU: 4096 chains x 256 frames took 289 us, eight rounds of 512 waves */
 #ifdef AVDSP_FIR_STAMPS
     unsigned long long *stamps;              /* diagnostic build (tools/fir_timeline.py): 32 s_memtime stamps per wave */
 #endif
@@ -1688,13 +1766,15 @@ __global__ __launch_bounds__(kBlock, 2) void fir_tile(const FirTileArgs a)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int B = a.io.nframes;
     const int blk = xcd_remap(blockIdx.x, a.per_xcd);
+    /* the tiles a chain has in this launch: 1 << wsh of the G::WPC a 1024-frame block needs (the workgroup: 4 >> wsh chains) */
+    const int wsh = SPLIT ? (G::WPC == 4 ? 2 : G::WPC == 2 ? 1 : 0) : a.wpc_shift;
     /* FIR-only chains: the FIR's input is (float)X of the load stage; the workgroup's chains get theirs appended first
      * (the waves of one chain sit in one workgroup) */
     {
         FirArgs fa{};
         fa.ring = a.ring; fa.io = a.io;
-        for (int q = 0; q < (SPLIT ? 1 : 4 / G::WPC); q++) {
-            const int sl = SPLIT ? blk >> 1 : blk * (4 / G::WPC) + q;      /* (SPLIT: the workgroup is two tiles of one chain) */
+        for (int q = 0; q < (SPLIT ? 1 : 4 >> wsh); q++) {
+            const int sl = SPLIT ? blk >> 1 : blk * (4 >> wsh) + q;      /* (SPLIT: the workgroup is two tiles of one chain) */
             if (sl < a.ngroup) {
                 const int ci = a.group[sl];
                 const avdsp_chain cc = a.chains[ci];
@@ -1705,7 +1785,7 @@ __global__ __launch_bounds__(kBlock, 2) void fir_tile(const FirTileArgs a)
     }
     const int unit = SPLIT ? (blk * 4 + wv) >> 1 : blk * 4 + wv;
     [[maybe_unused]] const int half = (blk * 4 + wv) & 1;
-    const int slot = unit / G::WPC, F0 = (unit % G::WPC) * G::FW;
+    const int slot = unit >> wsh, F0 = (unit & ((1 << wsh) - 1)) * G::FW;
     /* R = 4: the workgroup's four waves are four chains over the same frames, and their tiles leave together (one barrier, at
      * the very end); a wave without a unit only attends that barrier */
     [[maybe_unused]] int *xchg = reinterpret_cast<int *>(lds + (size_t)4 * G::LDS_DOUBLES);      /* [wave]: out_io of its chain, or -1 */
@@ -1937,7 +2017,8 @@ __global__ __launch_bounds__(kBlock, 2) void fir_tile(const FirTileArgs a)
          * LDS region, [frame / NR][NR + 1] so that neither side has bank conflicts, and after one barrier every thread sends
          * four frames x R channels.  Only when the chains store once each to R consecutive, aligned output columns; anything else
          * goes the plain way. */
-        constexpr int CH = R, WPC = G::WPC;                  /* channels per workgroup, waves (tiles) per channel */
+        constexpr int CH = R, WPC = G::WPC;                  /* channels per workgroup, waves (tiles) per channel -- of a 1024-frame block */
+        const bool four = R == 2 && wsh == 0;                 /* (R = 2, one 512-frame tile per chain: the workgroup is FOUR channels) */
         unsigned *mine = reinterpret_cast<unsigned *>(hs);
         unsigned w16[4 * R];
 #pragma unroll
@@ -1952,11 +2033,29 @@ __global__ __launch_bounds__(kBlock, 2) void fir_tile(const FirTileArgs a)
         if (lane == 0) xchg[wv] = c.n_out == 1 ? c.out_io[0] : -1;
         __syncthreads();
         const int o0 = xchg[0];
-        bool together = o0 >= 0 && ((o0 - a.io.out_base) & (CH - 1)) == 0 && (a.io.out_stride & (CH - 1)) == 0 &&
-                        (reinterpret_cast<size_t>(a.io.out) & (4 * CH - 1)) == 0;
+        const int chn = four ? 4 : CH;
+        bool together = o0 >= 0 && ((o0 - a.io.out_base) & (chn - 1)) == 0 && (a.io.out_stride & (chn - 1)) == 0 &&
+                        (reinterpret_cast<size_t>(a.io.out) & (4 * chn - 1)) == 0;
 #pragma unroll
-        for (int w = 1; w < 4; w++) together = together && xchg[w] == o0 + w / WPC;       /* wave w: channel w / WPC, tile w % WPC */
-        if (together) {
+        for (int w = 1; w < 4; w++) together = together && xchg[w] == o0 + (w >> wsh);       /* wave w: channel w >> wsh, tile w & (tiles - 1) */
+        if (together && four) {
+            /* four channels, one tile of <= 512 frames each: 16-byte pieces like R = 4 */
+            if constexpr (R == 2) {
+                const unsigned *reg = reinterpret_cast<const unsigned *>(lds);
+#pragma unroll
+                for (int qf = 0; qf < 2; qf++) {
+                    const int f = (int)threadIdx.x + 256 * qf;
+                    if (f < B) {
+                        const int at = (NR + 1) * (f / NR) + f % NR;
+                        unsigned o[4];
+#pragma unroll
+                        for (int j = 0; j < 4; j++) o[j] = reg[(size_t)j * (2 * G::LDS_DOUBLES) + at];
+                        unsigned *dst = a.io.out + (size_t)f * a.io.out_stride + (o0 - a.io.out_base);
+                        *reinterpret_cast<uint4 *>(dst) = make_uint4(o[0], o[1], o[2], o[3]);
+                    }
+                }
+            }
+        } else if (together) {
             const unsigned *reg = reinterpret_cast<const unsigned *>(lds);
 #pragma unroll
             for (int qf = 0; qf < 4; qf++) {
@@ -3625,7 +3724,16 @@ int launch_fir_tile(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, Block
     a.buf = prog->d_buf; a.chains = pl.d_chains; a.group = ids; a.ngroup = n;
     a.ring = plan_ring(pl); a.io = io; a.taps64 = pl.d_taps64; a.pitch64 = pl.pitch64;
     if (wait_ready) { a.ready = pl.d_ready; a.seq = pl.seq; a.timeouts = prog->d_ready_timeouts; a.ready_acquire = prog->ready_mode_now != 2 || prog->overlap >= 2; }
-    const int nwg = (n * TileGeom<R, BIG>::WPC * (SPLIT ? 2 : 1) + 3) / 4;
+    /* the tiles a chain has in this launch (a power of two, so that a chain's waves sit in one workgroup): a short block is fewer tiles
+     * than the TileGeom's 1024 frames, and waves without a tile would only hold their workgroup's LDS */
+    constexpr int kWpc = TileGeom<R, BIG>::WPC;
+    const int tiles = (io.nframes + TileGeom<R, BIG>::FW - 1) / TileGeom<R, BIG>::FW;
+    /* (BIG -- at most a wave per SIMD -- keeps the four-quarters arrangement: there a wave that leaves at once frees nothing anybody waits
+     * for, and its workgroup's other waves sit on CUs of their own: 256 chains x 4096 taps at 64 .. 512 frames 36.3-37.6 us against
+     * 38.1-38.8 regrouped) */
+    const int wpc = (SPLIT || BIG) ? kWpc : tiles <= 1 ? 1 : tiles <= 2 ? std::min(2, kWpc) : kWpc;
+    a.wpc_shift = wpc == 4 ? 2 : wpc == 2 ? 1 : 0;
+    const int nwg = (n * wpc * (SPLIT ? 2 : 1) + 3) / 4;
     a.per_xcd = (nwg + 7) / 8;
     const size_t lds = (size_t)4 * TileGeom<R, BIG>::LDS_DOUBLES * sizeof(double) + 64;      /* + the four words the waves exchange at the end */
 #ifdef AVDSP_FIR_STAMPS
@@ -3691,6 +3799,7 @@ int launch_fir_flow(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, Block
     a.buf = prog->d_buf; a.chains = pl.d_chains; a.group = ids; a.ngroup = n;
     a.ring = plan_ring(pl); a.io = io; a.taps64 = pl.d_taps64; a.pitch64 = pl.pitch64;
     if (wait_ready) { a.ready = pl.d_ready; a.seq = pl.seq; a.timeouts = prog->d_ready_timeouts; a.ready_acquire = prog->ready_mode_now != 2 || prog->overlap >= 2; }
+    a.wpc_shift = FlowGeom<R, BIG>::WPC == 4 ? 2 : FlowGeom<R, BIG>::WPC == 2 ? 1 : 0;      /* (fir_flow keeps the 1024-frame arrangement) */
     const int nwg = (n * FlowGeom<R, BIG>::WPC + 3) / 4;
     a.per_xcd = (nwg + 7) / 8;
     const size_t lds = (size_t)4 * FlowGeom<R, BIG>::LDS_DOUBLES * sizeof(double) + 64;

@@ -204,3 +204,18 @@ def test_both_chunk_boundaries_every_row_count(rows, fmt, C, S, T, fir_lean):
         xv[5, 0] = 0x7F800000; xv[1030, 1] = 0xFFC00001; xv[2100, 2] = 0x7F7FFFFF; xv[2101, 2] = 0xFF7FFFFF
         xv[3000:3004, 1] = 0x00012345; xv[3500, 0] = 0x80000000; xv[4000, C - 1] = 0x7F812345
     run_vs_oracle(fmt, prog, x, C, blocks, rows, 1, fir_lean)
+
+
+@pytest.mark.parametrize("fir_lean", [0, 1])
+@pytest.mark.parametrize("rows", ROWS)
+@pytest.mark.parametrize("fmt,C,S,T", [(6, 8, 0, 300), (6, 9, 2, 700), (4, 12, 3, 130), (6, 5, 0, 2048)])
+def test_short_blocks_take_as_many_tiles_as_they_have(rows, fmt, C, S, T, fir_lean):
+    """Round 5: a chain's waves in a launch are the tiles its block HAS -- 1, 2 or 4 of a one-row-tile wave's four, 1 or 2 of a
+    two-row-tile wave's two -- not the four quarters of a 1024-frame block (three of which left at once on a 256-frame block while
+    their workgroup kept its LDS: two live waves per CU).  Block lengths on both sides of every tile count, including the case that
+    regroups a two-row-tile workgroup as FOUR chains with one 512-frame tile each (their tiles leave together as 16-byte pieces when
+    the columns allow: 8 and 12 chains do, 9 and 5 leave some chains to the plain way)."""
+    prog = pb.synth_program(fmt, C, S, T)
+    blocks = [64, 256, 257, 512, 511, 384, 128, 513, 1024, 768, 769, 300, 1, 255]
+    x = pb.lcg_input(sum(blocks), C, fmt == 6, seed=T + C + rows)
+    run_vs_oracle(fmt, prog, x, C, blocks, rows, 1, fir_lean)

@@ -494,3 +494,12 @@ def test_bench_block_sizes_push_the_same_pins_through():
         assert p.returncode == 0, p.stderr[-2000:]
         line = _bench_line(p)
         assert line["config"]["block"] == blk and f"calls of {blk} frames" in line["verified"] and "SHA-256" in line["verified"]
+    # ... and the north-star program (cascade + 4096-tap FIR) at the short blocks whose FIR launches regroup their waves (one tile of a
+    # one-row-tile wave at 256 frames, four chains per two-row-tile workgroup at 512)
+    for blk in (256, 512):
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "1", "--settle", "0.05",
+                            "--workload", "north", "--block", str(blk), "--no-cpu-baseline"], env=_clean_env(),
+                           capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-2000:]
+        line = _bench_line(p)
+        assert line["config"]["block"] == blk and "north_f6" in line["verified"] and "SHA-256" in line["verified"]

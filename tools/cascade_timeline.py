@@ -17,6 +17,7 @@ ap.add_argument("workload", nargs="?", default="cfg3")
 ap.add_argument("--shard", default=None)
 ap.add_argument("--blocks", type=int, default=300)
 ap.add_argument("--biquad-impl", type=int, default=1)
+ap.add_argument("--block", type=int, default=0, help="frames per block call (0: the workload's own)")
 args = ap.parse_args()
 lib = "/tmp/libavdsp_bqstamps.so"
 src = os.path.join(ROOT, "avdsp_amd", "csrc")
@@ -31,6 +32,8 @@ from avdsp_amd import runtime as rt                                # noqa: E402
 import bench                                                       # noqa: E402
 
 fmt, Cn, S, T, B = bench.WORKLOADS[args.workload]
+if args.block > 0:
+    B = args.block
 r = rt.Runtime(fmt, pb.synth_program(fmt, Cn, S, T))
 r.set_option("biquad_impl", args.biquad_impl)
 if args.shard:
@@ -53,7 +56,8 @@ st = st[st[:, 29] != 0].astype(np.int64)
 print(f"{args.workload} shard {args.shard}: {Cl} chains x {S} sections, {len(st)} waves")
 med = lambda v: float(np.median(v))
 print(f"  start -> batch loop (coefficients, state, first samples): {med(st[:, 1] - st[:, 0]):.0f} cycles")
-per = np.diff(st[:, 2:26], axis=1)
+nbat = (B + 2 * (S - 1) + 1 + 15) // 16
+per = np.diff(st[:, 2:2 + max(2, min(24, nbat - 12 - 6))], axis=1) if nbat > 20 else np.zeros((1, 1))
 print(f"  one batch of 16 steps, batches 12..34: median {med(per):.0f} cycles (p10 {np.percentile(per, 10):.0f}, p90 {np.percentile(per, 90):.0f}) = {med(per) / 16:.1f} per step")
 print(f"  batch loop in all: {med(st[:, 28] - st[:, 1]):.0f} cycles;  behind the loop (state write-back, Inf/NaN look): {med(st[:, 29] - st[:, 28]):.0f} cycles")
 if (st[:, 26] != 0).any():          # biquad_row: the fill batches, the loop of steady batches, the rest (steady leftovers + drain)

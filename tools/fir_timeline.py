@@ -21,11 +21,14 @@ ap.add_argument("--fir-split", type=int, default=0)
 ap.add_argument("--blocks", type=int, default=6, help="blocks run before the one that is summarised")
 ap.add_argument("--overlap", type=int, default=-1, help="the library's \"overlap\" option (-1: its default)")
 ap.add_argument("--fir-lean", type=int, default=-1)
+ap.add_argument("--block", type=int, default=0, help="frames per block call (0: the workload's own)")
+ap.add_argument("--no-build", action="store_true", help="reuse /tmp/libavdsp_stamps.so of an earlier call in this session")
 args = ap.parse_args()
 
 lib = "/tmp/libavdsp_stamps.so"
 src = os.path.join(ROOT, "avdsp_amd", "csrc")
-subprocess.check_call(f"cd {src} && /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form=1 -DAVDSP_FIR_STAMPS "
+if not (args.no_build and os.path.exists(lib)):
+  subprocess.check_call(f"cd {src} && /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form=1 -DAVDSP_FIR_STAMPS "
                       f"-I../../include -c -o /tmp/k_stamps.o avdsp_kernels.hip && gcc -O2 -std=gnu99 -fPIC -I../../include -c -o /tmp/h_stamps.o avdsp_host.c && "
                       f"gcc -O2 -std=gnu99 -fPIC -I../../include -c -o /tmp/q_stamps.o avdsp_qformat.c && "
                       f"/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -Wl,-rpath,/opt/rocm/lib -o {lib} /tmp/h_stamps.o /tmp/q_stamps.o /tmp/k_stamps.o", shell=True)
@@ -36,6 +39,8 @@ from avdsp_amd import runtime as rt                                # noqa: E402
 import bench                                                       # noqa: E402
 
 fmt, Cn, S, T, B = bench.WORKLOADS[args.workload]
+if args.block > 0:
+    B = args.block
 r = rt.Runtime(fmt, pb.synth_program(fmt, Cn, S, T))
 r.set_option("fir_rows", args.fir_rows)
 r.set_option("fir_impl", args.fir_impl)
