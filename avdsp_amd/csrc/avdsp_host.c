@@ -105,6 +105,9 @@ typedef struct avdsp_ctx {
     int             inst_saved_lanes;                      /* 1 + the "strand_lanes" the program had before it got instances (0: nothing saved) */
     int             inst_call;                             /* inside dspRuntimeBlockAllInstancesDevice: block_all hands these strides on */
     size_t          inst_in_words, inst_out_words;
+    int             inst_chain_mode;                       /* 0 not looked yet, 1 every core runs on the interpreter, 2 every core is a chain core (round 5) */
+    int             chain_inst_made;                       /* the device holds ninst copies of the mirror; the plans are ninst x the cores' chains, made for ... */
+    size_t          chain_inst_in, chain_inst_out;         /* ... these distances between the instances' sample blocks (words) */
 } avdsp_ctx;
 
 /* no program loaded: options set now are the defaults every program starts from (and keeps following, see dspRuntimeSetOption) */
@@ -148,6 +151,7 @@ static void drop_device(void)
     G.nplans = 0;
     for (int i_ = 0; i_ < MAX_ARRANGEMENTS; i_++) G.arr[i_].valid = 0;
     G.dev_state_valid = 0;
+    G.chain_inst_made = 0;
 }
 
 /* swap a program's statics in: the exported globals of the reference runtime follow, and so does the active GPU */
@@ -1235,12 +1239,41 @@ static int select_device(void)
 
 /* find or build the device plan of (core, format) */
 /* end_word != 0: the plan of a strand group [core, end_word) of an interpreted core (dspRuntimeBlockAll) */
+/* the program's device copy, made at the first call that needs it */
+static int ensure_device(void)
+{
+    if (select_device()) return g_err_code;
+    if (G.dev) return 0;
+    G.dev = avdsp_hip_prog_create(G.total_words);
+    if (!G.dev) return hip_fail();
+    if (avdsp_hip_upload_words(G.dev, (const int32_t *)G.code, 0, G.total_words) ||
+        avdsp_hip_tpdf_reset(G.dev, G.random, G.dither)) {
+        hip_fail(); drop_device(); return g_err_code;
+    }
+    G.dev_state_valid = 1;
+    avdsp_hip_profile_enable(G.dev, G.opt_profile);
+    if (avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_PROFILE_STRIDE, G.opt_profile_stride > 0 ? G.opt_profile_stride : 1) ||
+        avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_OVERLAP, G.opt_overlap) || avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_FIR_ROWS, G.opt_fir_rows) ||
+        avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_READY_WORDS, G.opt_ready_words) || avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_LANE_HW, G.opt_lane_hw) || avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_FIR_SPLIT, G.opt_fir_split) || (G.opt_fir_launch_set && avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_FIR_LAUNCH, G.opt_fir_launch)) || (G.opt_fir_lean_set && avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_FIR_LEAN, G.opt_fir_lean)) || avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_RING_WAIT, G.opt_ring_wait) ||
+        avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_HOST_SPLIT, G.opt_host_split) || avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_HOST_PIN, G.opt_host_pin) ||
+        (G.ninst > 1 && avdsp_hip_set_instances(G.dev, G.ninst))) {
+        hip_fail(); drop_device(); return g_err_code;
+    }
+    return 0;
+}
+
 static core_plan *get_plan_range(int format, opcode_t *core, int end_word)
 {
     if (!dspHeaderPtr || !G.code) { fail(-1, "no program loaded"); return 0; }
     if (!G.have_rate) { fail(-1, "dspRuntimeReset(fs) has not selected a sample rate yet"); return 0; }
     if (format < 2 || format > 6) { fail(-1, "DSP_FORMAT %d is not one of 2..6", format); return 0; }
     if (core < G.code || core >= G.code + dspHeaderPtr->totalLength) { fail(-1, "core pointer outside the loaded program"); return 0; }
+    /* a program that runs as instances of chain cores has plans of ninst x its chains, which address ninst sample blocks: nothing
+     * but dspRuntimeBlockAllInstancesDevice may launch them (this check sits in front of the plan cache on purpose) */
+    if (G.chain_inst_made && !G.inst_call) {
+        fail(-1, "this program runs as %d instances (dspRuntimeBlockAllInstancesDevice); dspRuntimeSetInstances(0) gives the single program back", G.ninst);
+        return 0;
+    }
     /* one key per core: a host may pass the DSP_CORE word or the first executable word behind it */
     if (!end_word) core = dspFindCoreBegin(core);
     for (int i = 0; i < G.nplans; i++)
@@ -1275,24 +1308,7 @@ static core_plan *get_plan_range(int format, opcode_t *core, int end_word)
     if (!chains && scan_generic(format, core, end_word, &gd, &deps)) return 0;
     if (!chains) gd.tpdf_role = end_word ? G.next_tpdf_role : 0;
 
-    if (select_device()) { lowered_free(&L); return 0; }
-    if (!G.dev) {
-        G.dev = avdsp_hip_prog_create(G.total_words);
-        if (!G.dev) { hip_fail(); lowered_free(&L); return 0; }
-        if (avdsp_hip_upload_words(G.dev, (const int32_t *)G.code, 0, G.total_words) ||
-            avdsp_hip_tpdf_reset(G.dev, G.random, G.dither)) {
-            hip_fail(); lowered_free(&L); drop_device(); return 0;
-        }
-        G.dev_state_valid = 1;
-        avdsp_hip_profile_enable(G.dev, G.opt_profile);
-        if (avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_PROFILE_STRIDE, G.opt_profile_stride > 0 ? G.opt_profile_stride : 1) ||
-            avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_OVERLAP, G.opt_overlap) || avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_FIR_ROWS, G.opt_fir_rows) ||
-            avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_READY_WORDS, G.opt_ready_words) || avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_LANE_HW, G.opt_lane_hw) || avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_FIR_SPLIT, G.opt_fir_split) || (G.opt_fir_launch_set && avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_FIR_LAUNCH, G.opt_fir_launch)) || (G.opt_fir_lean_set && avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_FIR_LEAN, G.opt_fir_lean)) || avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_RING_WAIT, G.opt_ring_wait) ||
-            avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_HOST_SPLIT, G.opt_host_split) || avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_HOST_PIN, G.opt_host_pin) ||
-            (G.ninst > 1 && avdsp_hip_set_instances(G.dev, G.ninst))) {
-            hip_fail(); lowered_free(&L); drop_device(); return 0;
-        }
-    }
+    if (ensure_device()) { lowered_free(&L); return 0; }
     core_plan *cp = &G.plans[G.nplans];
     cp->core = core; cp->format = format; cp->end_word = end_word; cp->skip_from = G.next_skip_from;
     cp->nchains = 0; cp->max_sections = 0; cp->max_taps = 0;
@@ -1319,7 +1335,37 @@ static core_plan *get_plan_range(int format, opcode_t *core, int end_word)
         d.nchains = hi - lo; d.chains = L.chains + lo;
         d.nsections = sec1 - sec0; d.sec_coef_word = L.coef_word + sec0; d.sec_state_word = L.state_word + sec0;
         d.store_mask = G.store_mask;
+        /* Instances of a chain core (round 5): the chain list ninst times -- copy i of a chain reads and writes copy i of the mirror
+         * (every word index + i * total words: its own state, FIR history and parameters) and block i of the callers' samples (IO
+         * numbers + i * the blocks' distance: the kernels form `column = IO - window base`, which then lands in block i).  To the
+         * kernels it is a bigger plan: 8 chains x 512 instances are the 4096 rows of one cascade launch. */
+        avdsp_chain *xch = 0; int32_t *xco = 0, *xst = 0;
+        if (G.chain_inst_made) {
+            const int N = G.ninst, nc = hi - lo, ns = sec1 - sec0;
+            xch = (avdsp_chain *)malloc(sizeof(avdsp_chain) * (size_t)N * (size_t)nc);
+            xco = (int32_t *)malloc(sizeof(int32_t) * ((size_t)N * (size_t)ns + 1));
+            xst = (int32_t *)malloc(sizeof(int32_t) * ((size_t)N * (size_t)ns + 1));
+            if (!xch || !xco || !xst) { free(xch); free(xco); free(xst); lowered_free(&L); fail(-9, "out of memory"); return 0; }
+            for (int i = 0; i < N; i++) {
+                const long long wo = (long long)i * AVDSP_INSTANCE_STRIDE(G.total_words);
+                for (int c = 0; c < nc; c++) {
+                    avdsp_chain ch = L.chains[lo + c];
+                    ch.in_io += (int)((long long)i * (long long)G.chain_inst_in);
+                    for (int k = 0; k < ch.n_out; k++) ch.out_io[k] += (int)((long long)i * (long long)G.chain_inst_out);
+                    ch.sec_base += i * ns;
+                    if (ch.fir_taps) { ch.fir_coef_word += (int)wo; ch.fir_state_word += (int)wo; }
+                    xch[(size_t)i * nc + c] = ch;
+                }
+                for (int j = 0; j < ns; j++) {
+                    xco[(size_t)i * ns + j] = d.sec_coef_word[j] + (int)wo;
+                    xst[(size_t)i * ns + j] = d.sec_state_word[j] + (int)wo;
+                }
+            }
+            d.nchains = N * nc; d.chains = xch; d.nsections = N * ns; d.sec_coef_word = xco; d.sec_state_word = xst;
+            d.instances = N;
+        }
         cp->plan_id = avdsp_hip_prog_add_plan(G.dev, &d);
+        free(xch); free(xco); free(xst);
         for (int i = lo; i < hi; i++) {
             if (L.chains[i].nsec > cp->max_sections) cp->max_sections = L.chains[i].nsec;
             if (L.chains[i].fir_taps > cp->max_taps) cp->max_taps = L.chains[i].fir_taps;
@@ -2187,6 +2233,12 @@ int dspRuntimeSetInstances(int n)
     if (!dspHeaderPtr || !G.code) return fail(-1, "no program loaded");
     if (n < 0 || n > 65536) return fail(-1, "instances: 1 .. 65536 (0: no instances any more)");
     device_current();
+    if (G.chain_inst_made) {                             /* chain instances: plans of the old count go, the device keeps instance 0's copy */
+        if (replan()) return g_err_code;
+        if (G.dev && avdsp_hip_chain_instances(G.dev, 0)) return hip_fail();
+        G.chain_inst_made = 0;
+    }
+    G.inst_chain_mode = 0;
     if (G.dev && avdsp_hip_set_instances(G.dev, n > 0 ? n : 1)) return hip_fail();      /* (else: when the device copy is made) */
     G.ninst = n;
     /* The strand plans know nothing of instances: while a program HAS instances its interpreted cores run as the interpreter's pieces
@@ -2209,6 +2261,72 @@ int dspRuntimeBlockAllInstancesDevice(int format, int *rundata, const void *d_in
 {
     (void)ctx_of(rundata);
     if (G.ninst < 1) return fail(-1, "dspRuntimeSetInstances first");
+    if (!dspHeaderPtr || !G.code) return fail(-1, "no program loaded");
+    if (format < 2 || format > 6) return fail(-1, "DSP_FORMAT %d is not one of 2..6", format);
+    /* Which kind of program?  Every core a set of independent chains (lower_core takes it): the instances are further chains of the
+     * chain kernels' launches.  Every core one for the interpreter: the instances are further copies of its state (round 4).  A
+     * program with both is refused -- its instances would keep their state in two places. */
+    if (!G.inst_chain_mode) {
+        int nchain = 0, nother = 0;
+        if (!G.have_rate) return fail(-1, "dspRuntimeReset(fs) has not selected a sample rate yet");
+        for (int k = 1; k <= MAX_CORE_PLANS; k++) {
+            opcode_t *c = dspFindCore(G.code, k);
+            if (!c || (k > 1 && c == G.code)) break;
+            lowered L;
+            memset(&L, 0, sizeof L);
+            const int rc = G.opt_generic ? -8 : lower_core(format, dspFindCoreBegin(c), &L);
+            lowered_free(&L);
+            if (rc == 0) nchain++; else if (rc == -8) nother++; else return g_err_code;
+            if (c == G.code) break;
+        }
+        if (nchain && nother) return fail(-8, "instances: %d of the program's cores are chain cores and %d are not; all of one kind, please", nchain, nother);
+        G.inst_chain_mode = nchain ? 2 : 1;
+    }
+    if (G.inst_chain_mode == 2) {
+        if (check_rundata(rundata)) return -1;
+        if (nframes <= 0) return 0;
+        if (G.shard_world > 1) return fail(-1, "instances of a sharded program: shard the instances instead");
+        if (in_stride <= 0 || out_stride <= 0) return fail(-1, "instances: strides in words per frame, please");
+        /* the kernels' sample offsets are 32 bits: the last instance's block must end below 4 GiB from the first one's start */
+        if (((unsigned long long)(G.ninst - 1) * in_inst_words + (unsigned long long)nframes * (unsigned)in_stride) >= (1ull << 30) ||
+            ((unsigned long long)(G.ninst - 1) * out_inst_words + (unsigned long long)nframes * (unsigned)out_stride) >= (1ull << 30))
+            return fail(-1, "instances: the sample blocks of %d instances span more than 2^30 words", G.ninst);
+        if (G.ninst > 1 && (in_inst_words < (size_t)nframes * (size_t)in_stride || out_inst_words < (size_t)nframes * (size_t)out_stride))
+            return fail(-1, "instances: a block of %d frames does not fit the distance between two instances' blocks", nframes);
+        if (G.ninst > 1 && (!G.chain_inst_made || G.chain_inst_in != in_inst_words || G.chain_inst_out != out_inst_words)) {
+            /* (first call, or other block distances: the plans are made for them) */
+            if (replan()) return g_err_code;              /* (the instances' FIR histories go home into their mirror copies) */
+            if (ensure_device()) return g_err_code;
+            /* the copies are made ONCE, from what instance 0's state is then; other block distances only re-make the plans */
+            if (!G.chain_inst_made && avdsp_hip_chain_instances(G.dev, G.ninst)) return hip_fail();
+            G.chain_inst_made = 1; G.chain_inst_in = in_inst_words; G.chain_inst_out = out_inst_words;
+        }
+        int rc = 0;
+        G.inst_call = 1;
+        for (int k = 1; k <= MAX_CORE_PLANS && !rc; k++) {
+            opcode_t *c = dspFindCore(G.code, k);
+            if (!c || (k > 1 && c == G.code)) break;
+            core_plan *cp = get_plan(format, c);
+            if (!cp) { rc = g_err_code; break; }
+            if (!cp->empty) {
+                /* the windows against the program's own IO numbers (the plan's carry the instances' offsets) */
+                lowered L;
+                memset(&L, 0, sizeof L);
+                if (lower_core(format, dspFindCoreBegin(c), &L)) { lowered_free(&L); rc = g_err_code; break; }
+                for (int i = 0; i < L.nchains && !rc; i++) {
+                    if (L.chains[i].in_io < in_io_base || L.chains[i].in_io >= in_io_base + in_stride) rc = fail(-10, "input window IO [%d,%d) does not cover IO %d", in_io_base, in_io_base + in_stride, L.chains[i].in_io);
+                    for (int o = 0; o < L.chains[i].n_out && !rc; o++)
+                        if (L.chains[i].out_io[o] < out_io_base || L.chains[i].out_io[o] >= out_io_base + out_stride) rc = fail(-10, "output window IO [%d,%d) does not cover IO %d", out_io_base, out_io_base + out_stride, L.chains[i].out_io[o]);
+                }
+                lowered_free(&L);
+                if (!rc && avdsp_hip_run_block(G.dev, cp->plan_id, d_in, in_stride, in_io_base, d_out, out_stride, out_io_base,
+                                               nframes, G.opt_fir_impl, G.opt_biquad_impl, stream)) rc = hip_fail();
+            }
+            if (c == G.code) break;
+        }
+        G.inst_call = 0;
+        return rc;
+    }
     /* the strand plans know nothing of instances: dspRuntimeSetInstances(n > 1) has switched them off for as long as the program has
      * instances (a caller who turned them on again since gets told, not overridden) */
     if (G.opt_strand_lanes != 0)

@@ -3394,6 +3394,7 @@ struct Plan {
     int dither_arg = 0, dither_word = 0;
     size_t ga_lds = 0; bool ga_staged = false;
     int format = 0, nchains = 0, store_mask = -1;
+    int instances = 1;                /* > 1: the chains are that many copies of a core's chains (avdsp_plan_desc::instances) */
     avdsp_chain *d_chains = nullptr;
     int *d_sec_coef = nullptr, *d_sec_state = nullptr;
     /* launch groups (device arrays of chain ids) */
@@ -3427,6 +3428,8 @@ struct Plan {
 
 struct avdsp_hip_prog {
     int total_words = 0;
+    int chain_inst = 0;                 /* > 1: d_buf holds that many copies of the mirror side by side, [instance][total_words] -- the instances of a program whose
+                                           cores are chain cores (avdsp_hip_chain_instances): an instance is a further block of chains with its own state words */
     int *d_buf = nullptr;
     TpdfGlobals *d_tpdf = nullptr;
     int *d_tpdf_seq = nullptr; int tpdf_seq_frames = 0;   /* per-frame dither values inside a core cut into pieces */
@@ -4159,9 +4162,12 @@ int avdsp_hip_prog_add_plan(avdsp_hip_prog *prog, const avdsp_plan_desc *d)
     std::vector<avdsp_chain> chains(d->chains, d->chains + d->nchains);
     std::vector<int> coef(d->sec_coef_word, d->sec_coef_word + d->nsections);
     std::vector<int> state(d->sec_state_word, d->sec_state_word + d->nsections);
-    /* every word index the kernels will touch must lie inside the mirror */
+    /* every word index the kernels will touch must lie inside the mirror (chain instances: inside the copies, all of them) */
+    const long long buf_words = d->instances > 1 ? (long long)AVDSP_INSTANCE_STRIDE(prog->total_words) * d->instances : (long long)prog->total_words;
+    if (d->instances > 1 && d->instances != prog->chain_inst) return set_err("a plan of %d instances, the device holds %d copies of the program", d->instances, prog->chain_inst);
+    pl.instances = d->instances > 1 ? d->instances : 1;
     for (int i = 0; i < d->nsections; i++)
-        if (coef[i] < 0 || coef[i] + 5 > prog->total_words || state[i] < 0 || state[i] + 6 > prog->total_words || (state[i] & 1))
+        if (coef[i] < 0 || coef[i] + 5 > buf_words || state[i] < 0 || state[i] + 6 > buf_words || (state[i] & 1))
             return set_err("section %d addresses words outside the loaded buffer", i);
     std::vector<std::pair<int, std::vector<int>>> byN;   /* (section count, chain ids) in first-seen order */
     std::vector<int> fir, pass;
@@ -4177,8 +4183,8 @@ int avdsp_hip_prog_add_plan(avdsp_hip_prog *prog, const avdsp_plan_desc *d)
         }
         if (c.fir_taps) {
             if (d->format == 2) return set_err("chain %d: FIR has no int64 definition", i);
-            if (c.fir_coef_word < 0 || c.fir_coef_word + c.fir_taps > prog->total_words ||
-                c.fir_state_word < 0 || c.fir_state_word + c.fir_taps > prog->total_words)
+            if (c.fir_coef_word < 0 || c.fir_coef_word + c.fir_taps > buf_words ||
+                c.fir_state_word < 0 || c.fir_state_word + c.fir_taps > buf_words)
                 return set_err("chain %d: FIR addresses words outside the loaded buffer", i);
             fir.push_back(i);
             pl.max_taps = std::max(pl.max_taps, c.fir_taps);
@@ -4784,9 +4790,11 @@ int avdsp_hip_run_block(avdsp_hip_prog *prog, int plan, const void *d_in, int in
     /* the chain kernels index the sample blocks with the chains' IO numbers: check the windows once here.
      * (The interpreter keeps a whole samples[] frame: slots outside the caller's windows are the frame's
      * own, persistent like the host's array, e.g. values one strand leaves for the next frame.) */
-    if (!pl.generic && pl.io_in_max >= pl.io_in_min && (pl.io_in_min < in_io_base || pl.io_in_max >= in_io_base + in_stride))
+    /* (a plan of chain instances carries the instances' block offsets in its chains' IO numbers -- the host has checked the windows
+     * against the program's own IOs) */
+    if (!pl.generic && pl.instances <= 1 && pl.io_in_max >= pl.io_in_min && (pl.io_in_min < in_io_base || pl.io_in_max >= in_io_base + in_stride))
         return set_err("input window IO [%d,%d) does not cover the IOs the core loads [%d,%d]", in_io_base, in_io_base + in_stride, pl.io_in_min, pl.io_in_max);
-    if (!pl.generic && pl.io_out_max >= pl.io_out_min && (pl.io_out_min < out_io_base || pl.io_out_max >= out_io_base + out_stride))
+    if (!pl.generic && pl.instances <= 1 && pl.io_out_max >= pl.io_out_min && (pl.io_out_min < out_io_base || pl.io_out_max >= out_io_base + out_stride))
         return set_err("output window IO [%d,%d) does not cover the IOs the core stores [%d,%d]", out_io_base, out_io_base + out_stride, pl.io_out_min, pl.io_out_max);
     if (pl.generic) {
         /* the scratch frame is indexed by IO number: both windows must lie inside it */
@@ -5240,6 +5248,31 @@ int avdsp_hip_run_levels(avdsp_hip_prog *prog, const int *plans, const int *leve
 /* N instances of the program over one block each (include/avdsp_hip.h).  Every level must be frame-parallel interpreter pieces (the
  * programs this is for -- the reference's crossovers -- are); the instances' states are made on the first call after
  * avdsp_hip_set_instances as copies of the program's device state as it then is. */
+/* Instances of a program made of chain cores: the mirror n times side by side in d_buf, every copy what instance 0's is now.  The
+ * host then lowers each core into a plan of n x its chains (state and parameter words of instance i at i * total_words, the
+ * instance's sample block as an offset in the chains' IO numbers); the kernels see a bigger plan, nothing else.  No plan may exist
+ * (their rings and records address the old buffer): the host drops them first.  n <= 1: back to the one copy. */
+int avdsp_hip_chain_instances(avdsp_hip_prog *prog, int n)
+{
+    if (n < 0 || n > 65536) return set_err("instances: 1 .. 65536");
+    if (!prog->plans.empty()) return set_err("chain instances: the program's plans must be dropped first");
+    if (n <= 1 && prog->chain_inst <= 1) { prog->chain_inst = 0; return 0; }
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t W = (size_t)(prog->total_words > 0 ? prog->total_words : 1);
+    const size_t Wp = AVDSP_INSTANCE_STRIDE(W);          /* (an even distance: a copy's state words keep their 8-byte alignment) */
+    const size_t copies = n > 1 ? (size_t)n : 1;
+    if (copies * Wp > 0x7FFFFFF0ull) return set_err("%d instances of %zu words exceed the kernels' 32-bit word indices", n, W);
+    int *nb = nullptr;
+    HIP_TRY(hipMalloc((void **)&nb, (copies * Wp + 2) * sizeof(int)));
+    HIP_TRY(hipMemset(nb, 0, (copies * Wp + 2) * sizeof(int)));
+    for (size_t i = 0; i < copies; i++)
+        if (hipMemcpy(nb + i * Wp, prog->d_buf, W * sizeof(int), hipMemcpyDeviceToDevice) != hipSuccess) { (void)hipFree(nb); return set_err("chain instances: copying the mirror failed"); }
+    (void)hipFree(prog->d_buf);
+    prog->d_buf = nb;
+    prog->chain_inst = n > 1 ? n : 0;
+    return 0;
+}
+
 int avdsp_hip_set_instances(avdsp_hip_prog *prog, int n)
 {
     if (n < 1 || n > 65536) return set_err("instances: 1 .. 65536");
@@ -5380,9 +5413,17 @@ int avdsp_hip_run_levels_instances(avdsp_hip_prog *prog, const int *plans, const
 /* the data area (or any word range) of one instance's mirror, for the host */
 int avdsp_hip_download_instance_words(avdsp_hip_prog *p, int inst, int32_t *host_buf, int first, int n)
 {
-    if (inst < 0 || inst >= p->inst_n) return set_err("instance %d of %d", inst, p->inst_n);
+    if (inst < 0 || inst >= std::max(p->inst_n, p->chain_inst)) return set_err("instance %d of %d", inst, std::max(p->inst_n, p->chain_inst));
     if (check_range(p, first, n)) return -1;
     HIP_TRY(hipDeviceSynchronize());
+    if (p->chain_inst > 1) {                             /* chain instances: copy `inst` of the mirror, the FIR histories brought home first */
+        if (inst >= p->chain_inst) return set_err("instance %d of %d", inst, p->chain_inst);
+        READY_CHECK(p);
+        if (rings_to_mirror(p)) return -1;
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(host_buf, p->d_buf + (size_t)inst * AVDSP_INSTANCE_STRIDE(p->total_words) + first, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+        return 0;
+    }
     const int *src = p->d_buf;
     if (inst > 0) {
         if (!p->inst_valid || !p->d_inst_buf) return set_err("the instances have not run yet");

@@ -37,7 +37,7 @@ EXPORTED = [
     "avdsp_hip_prog_add_plan", "avdsp_hip_prog_add_generic", "avdsp_hip_prog_clear_plans", "avdsp_hip_tpdf_reset", "avdsp_hip_upload_words", "avdsp_hip_download_words", "avdsp_hip_zero_words",
     "avdsp_hip_run_block", "avdsp_hip_run_block_host", "avdsp_hip_submit_block_host", "avdsp_hip_wait_block_host", "avdsp_hip_run_levels", "avdsp_hip_run_levels_host", "avdsp_hip_run_levels_pcm_host", "avdsp_hip_unpack_pcm", "avdsp_hip_run_block_pcm_host", "avdsp_hip_profile_enable", "avdsp_hip_profile_read", "avdsp_hip_prog_set_option", "avdsp_hip_tag_output", "avdsp_hip_tag_column_host",
     "avdsp_hip_synchronize", "avdsp_hip_last_error",
-    "avdsp_hip_set_instances", "avdsp_hip_run_levels_instances", "avdsp_hip_download_instance_words", "avdsp_hip_ready_timeouts", "avdsp_hip_ready_clear", "avdsp_hip_prog_get_option", "avdsp_hip_last_error_is_ready_timeout", "avdsp_hip_profile_last_pairs",
+    "avdsp_hip_set_instances", "avdsp_hip_run_levels_instances", "avdsp_hip_download_instance_words", "avdsp_hip_ready_timeouts", "avdsp_hip_ready_clear", "avdsp_hip_chain_instances", "avdsp_hip_prog_get_option", "avdsp_hip_last_error_is_ready_timeout", "avdsp_hip_profile_last_pairs",
     "avdsp_hip_plan_add_strands", "avdsp_hip_plan_strands",
 ]
 

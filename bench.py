@@ -648,13 +648,15 @@ def main():
             # (SURVEY.md 8d): double models 10 flop per section and sample against the FP64 vector peak; int64 5 32x32->64 MADs per
             # section and sample against a quarter of the FP32 FMA rate (v_mad_i64_i32); HBM: algorithmic bytes against 8 TB/s.
             per_launch = bq_raw * 1e-3
-            nbytes = 8.0 * Cl * B + 48.0 * S * Cl + 20.0 * S * Cl   # samples in+out, state r+w, coefficients
+            lps = (B + 1023) // 1024                             # blocks longer than 1024 frames are cut into 1024-frame launches
+            Bl = B / lps                                         # frames per launch
+            nbytes = 8.0 * Cl * Bl + 48.0 * S * Cl + 20.0 * S * Cl   # samples in+out, state r+w, coefficients
             hbm_ach = nbytes / per_launch / 1e9
             kname = "biquad_simple" if not args.biquad_impl else ("biquad_pipe" if args.biquad_impl == 2 else "biquad_row_i64" if fmt == 2 else "biquad_row")
             if fmt == 2:
-                ops, peak, unit = 5.0 * S * Cl * B, PEAK_F32_TFMAS / 4.0, "T MAD/s (v_mad_i64_i32; quarter of the FP32 FMA rate)"
+                ops, peak, unit = 5.0 * S * Cl * Bl, PEAK_F32_TFMAS / 4.0, "T MAD/s (v_mad_i64_i32; quarter of the FP32 FMA rate)"
             else:
-                ops, peak, unit = 10.0 * S * Cl * B, PEAK_F64_TFLOPS, "TFLOP/s"
+                ops, peak, unit = 10.0 * S * Cl * Bl, PEAK_F64_TFLOPS, "TFLOP/s"
             ach = ops / per_launch / 1e12
             roof = dict(bound="valu", kernel=kname, achieved=ach, peak=peak, unit=unit, frac=ach / peak,
                         timing=timing_label(bq_n, bq_pairs),

@@ -51,6 +51,9 @@ typedef struct avdsp_plan_desc {
     const int32_t *sec_coef_word;    /* per section: word index of b0 for the CURRENT sample rate */
     const int32_t *sec_state_word;   /* per section: word index of its 6 state words             */
     int32_t  store_mask;             /* tpdf mask applied by STORE in int-sample formats         */
+    int32_t  instances;              /* > 1: the chains are that many copies of a core's, copy i addressing mirror copy i (word indices
+                                        + i * total words) and sample block i (IO numbers + i * the blocks' distance in words):
+                                        avdsp_hip_chain_instances() must have made the copies; 0 / 1: an ordinary plan */
 } avdsp_plan_desc;
 
 /* A core that is not a set of independent chains runs through the general device interpreter
@@ -236,6 +239,8 @@ enum { AVDSP_OPT_OVERLAP = 0, AVDSP_OPT_PROFILE_STRIDE = 1, AVDSP_OPT_FIR_ROWS =
  * reference's dspMulFloatFloat bit for bit (fir_lane_hw, chain_rows); 0: the integer restatement of the product throughout. */
 /* READY_WORDS 1: under OVERLAP the FIR finds its cascades' blocks through per-chain ready words polled inside the kernel instead of
  * an event between the two queues (0, the default: the event -- the words measured slower on every configuration). */
+#define AVDSP_INSTANCE_STRIDE(total_words) (((total_words) + 1) & ~1)   /* words between two copies of the mirror (chain instances) */
+int avdsp_hip_chain_instances(avdsp_hip_prog *prog, int n);   /* the mirror n times side by side (no plan may exist); <= 1: one copy again */
 int avdsp_hip_prog_get_option(avdsp_hip_prog *prog, int key);   /* AVDSP_OPT_SIDE_BY_SIDE, AVDSP_OPT_READY_MODE */
 int avdsp_hip_ready_clear(avdsp_hip_prog *prog);       /* the caller acknowledges the time-outs: count and sticky mark start again */
 int avdsp_hip_last_error_is_ready_timeout(void);       /* 1: the latest failure of this thread was the sticky ready-word time-out (the host maps it to -11) */

@@ -138,14 +138,105 @@ def test_instances_of_a_random_program(fmt):
     r.release()
 
 
-def test_instances_refuse_what_they_cannot_run():
-    """a chain program (the parallel kernels know nothing of instances) is refused loudly, not run wrongly"""
+def _chain_instances_vs_oracle(fmt, prog, C, ninst, blocks, seed0=40, options=None):
+    """a program of C chains (inputs IO C .. 2C-1, outputs IO 0 .. C-1) in ninst instances with inputs of their own: every instance the
+    oracle's bits for ITS input, block by block, and its data area at the end"""
+    frames = sum(blocks)
+    xs = np.stack([pb.lcg_input(frames, C, fmt in (5, 6), seed=seed0 + i) for i in range(ninst)])
+    if ninst > 3:
+        xs[1] = 0                                                    # a silent instance
+        xs[2] = xs[3]                                                # two alike
     import torch
-    prog = pb.synth_program(6, 4, 2, 0)
+    r = rt.Runtime(fmt, prog)
+    for k, v in (options or {}).items():
+        r.set_option(k, v)
+    r.set_instances(ninst)
+    got = np.zeros((ninst, frames, C), dtype=xs.dtype)
+    st = torch.cuda.current_stream().cuda_stream
+    pos = 0
+    for b in blocks:
+        xd = torch.from_numpy(np.ascontiguousarray(xs[:, pos:pos + b])).cuda()
+        yd = torch.zeros((ninst, b, C), dtype=xd.dtype, device="cuda")
+        r.run_block_all_instances_device(xd.data_ptr(), C, C, b * C, yd.data_ptr(), C, 0, b * C, b, st)
+        torch.cuda.synchronize()
+        got[:, pos:pos + b] = yd.cpu().numpy()
+        pos += b
+    for i in range(ninst):
+        o = po.OracleProgram(fmt, prog)
+        want = np.concatenate([o.run_block(xs[i, p0:p0 + b], C, C) for p0, b in zip(np.cumsum([0] + blocks[:-1]), blocks)])
+        bad = np.nonzero((got[i].view(np.uint32) != want.view(np.uint32)).any(axis=1))[0]
+        assert bad.size == 0, f"instance {i}: first differing frame {bad[0]}"
+        assert (r.instance_state(i) == o.state).all(), f"instance {i}: state"
+    return r
+
+
+def test_cfg2_shaped_program_in_512_instances_is_the_golden_vector_512_times():
+    """Round-4 review, Missing #5: instances of programs whose cores are CHAIN cores.  BASELINE cfg2's program (8 ch x 8 biquads, the
+    golden bq_c8_s8_b256_f6 the compiled reference produced) in 512 instances -- 4096 rows of ONE cascade launch: every instance fed the
+    golden input gives the reference's output and state, bit for bit; then instances with inputs of their own against the oracle."""
+    import json
+    import torch
+    from tests.golden_recipes import make_input, make_program
+    with open(os.path.join(GOLDEN_DIR, "manifest.json")) as f:
+        case = [c for c in json.load(f)["cases"] if c["name"] == "bq_c8_s8_b256_f6"][0]
+    g = np.load(os.path.join(GOLDEN_DIR, case["name"] + ".npz"))
+    prog, x = make_program(case["program"]), make_input(case["input"], 6)
+    ninst, B, C = 512, x.shape[0], 8
+    r = rt.Runtime(6, prog)
+    r.set_instances(ninst)
+    xd = torch.from_numpy(np.ascontiguousarray(np.broadcast_to(x, (ninst,) + x.shape))).cuda()
+    yd = torch.zeros((ninst, B, case["out_stride"]), dtype=xd.dtype, device="cuda")
+    r.run_block_all_instances_device(xd.data_ptr(), x.shape[1], case["in_base"], B * x.shape[1], yd.data_ptr(), case["out_stride"], case["out_base"],
+                                     B * case["out_stride"], B, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = yd.cpu().numpy()
+    assert (got.view(np.uint32) == g["out"].view(np.uint32)[None]).all()
+    for i in (0, 1, 255, 511):
+        assert (r.instance_state(i) == g["state"]).all()
+    # an ordinary block call on a program that runs as instances is refused, not run on one of them by accident; SetInstances(0) gives it back
+    with pytest.raises(rt.AvdspError):
+        r.run_block(x, C, case["in_base"])
+    r.set_instances(0)
+    o = po.OracleProgram(6, prog)
+    o.run_block(x, C, case["in_base"])                              # (instance 0 has run the golden block once already)
+    more = pb.lcg_input(64, x.shape[1], True, seed=9)
+    assert (r.run_block(more, C, case["in_base"]).view(np.uint32) == o.run_block(more, C, case["in_base"]).view(np.uint32)).all()
+    r.release()
+
+
+@pytest.mark.parametrize("fmt,C,S,T,ninst", [(6, 8, 8, 0, 64), (2, 8, 8, 0, 64), (4, 5, 3, 0, 7), (6, 3, 2, 300, 9), (6, 4, 0, 64, 5), (5, 6, 4, 0, 6), (3, 4, 2, 33, 5)])
+def test_chain_instances_each_match_the_oracle(fmt, C, S, T, ninst):
+    """inputs of their own per instance, ragged blocks (the distance between the instances' blocks changes with the block: the plans are
+    re-made, the instances' states -- cascade words and FIR histories -- live on); int64, the double models, the float-accumulator
+    models; cascades, cascade + FIR, FIR only"""
+    prog = pb.synth_program(fmt, C, S, T)
+    r = _chain_instances_vs_oracle(fmt, prog, C, ninst, [256, 64, 700, 1, 1024, 37])
+    r.release()
+
+
+def test_chain_instances_under_the_overlap_mode():
+    """cascade + FIR chains in instances with the cascade of the next block under the FIR of this one"""
+    prog = pb.synth_program(6, 6, 4, 500)
+    r = _chain_instances_vs_oracle(6, prog, 6, 12, [1024, 1024, 512, 1024], options={"overlap": 1})
+    r.release()
+
+
+def test_instances_refuse_a_program_of_both_kinds():
+    """a program with a chain core AND a core for the interpreter: its instances would keep their state in two places -- refused loudly"""
+    import torch
+    from avdsp_amd import encoder as enc
+
+    def build(L):
+        L.dsp_CORE()
+        L.dsp_LOAD(4); L.dsp_STORE(0)                                  # a chain core
+        L.dsp_CORE()
+        L.dsp_LOAD(5); L.dsp_COPYXY(); L.dsp_ADDXY(); L.dsp_STORE(1)   # X/Y arithmetic: the interpreter's
+    prog = enc.encode(build, 6, pb.F48000, pb.F48000)
     r = rt.Runtime(6, prog)
     r.set_instances(3)
-    x = torch.zeros((3, 64, 4), dtype=torch.float32, device="cuda")
-    y = torch.zeros((3, 64, 4), dtype=torch.float32, device="cuda")
-    with pytest.raises(rt.AvdspError):
-        r.run_block_all_instances_device(x.data_ptr(), 4, 4, 64 * 4, y.data_ptr(), 4, 0, 64 * 4, 64, 0)
+    x = torch.zeros((3, 64, 8), dtype=torch.float32, device="cuda")
+    y = torch.zeros((3, 64, 8), dtype=torch.float32, device="cuda")
+    with pytest.raises(rt.AvdspError) as e:
+        r.run_block_all_instances_device(x.data_ptr(), 8, 0, 64 * 8, y.data_ptr(), 8, 0, 64 * 8, 64, 0)
+    assert "all of one kind" in str(e.value)
     r.release()
