@@ -50,5 +50,8 @@ def test_bare_gpus_n_starts_n_fresh_rank_processes():
     p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--no-cpu-baseline", "--workload", "cfg2"],
                        env=_env(AVDSP_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=600)
     assert p.returncode != 0
-    assert p.stderr.count("no GPU visible; the product path has no CPU fallback") >= 2
+    # (the launcher ends the other rank as soon as one has failed: at least one of them got to say it, and the launcher's own report
+    # shows that it was rank processes that failed, not this process)
+    assert p.stderr.count("no GPU visible; the product path has no CPU fallback") >= 1
+    assert "ChildFailedError" in p.stderr or "exitcode" in p.stderr
     assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
