@@ -43,6 +43,8 @@ typedef struct avdsp_chain {
     int32_t  out_io[AVDSP_MAX_STORES];
 } avdsp_chain;
 
+/* words between two copies of the mirror (chain instances, avdsp_hip_chain_instances): even, so that state words keep their alignment */
+#define AVDSP_INSTANCE_STRIDE(total_words) (((total_words) + 1) & ~1)
 typedef struct avdsp_plan_desc {
     int32_t  format;                 /* 2, 4 or 6                                                */
     int32_t  nchains;
@@ -239,7 +241,6 @@ enum { AVDSP_OPT_OVERLAP = 0, AVDSP_OPT_PROFILE_STRIDE = 1, AVDSP_OPT_FIR_ROWS =
  * reference's dspMulFloatFloat bit for bit (fir_lane_hw, chain_rows); 0: the integer restatement of the product throughout. */
 /* READY_WORDS 1: under OVERLAP the FIR finds its cascades' blocks through per-chain ready words polled inside the kernel instead of
  * an event between the two queues (0, the default: the event -- the words measured slower on every configuration). */
-#define AVDSP_INSTANCE_STRIDE(total_words) (((total_words) + 1) & ~1)   /* words between two copies of the mirror (chain instances) */
 int avdsp_hip_chain_instances(avdsp_hip_prog *prog, int n);   /* the mirror n times side by side (no plan may exist); <= 1: one copy again */
 int avdsp_hip_prog_get_option(avdsp_hip_prog *prog, int key);   /* AVDSP_OPT_SIDE_BY_SIDE, AVDSP_OPT_READY_MODE */
 int avdsp_hip_ready_clear(avdsp_hip_prog *prog);       /* the caller acknowledges the time-outs: count and sticky mark start again */
