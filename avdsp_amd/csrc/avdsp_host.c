@@ -350,6 +350,7 @@ int dspRuntimeGetOption(const char *key)
         return G.dev ? avdsp_hip_profile_last_pairs(G.dev, key[13] - '0') : 0;
     if (!strcmp(key, "ready_timeouts")) { device_current(); return G.dev ? avdsp_hip_ready_timeouts(G.dev) : 0; }
     if (!strcmp(key, "side_by_side")) { device_current(); return G.dev ? avdsp_hip_prog_get_option(G.dev, AVDSP_OPT_SIDE_BY_SIDE) : -1; }
+    if (!strcmp(key, "streams_remade")) { device_current(); return G.dev ? avdsp_hip_prog_get_option(G.dev, AVDSP_OPT_STREAMS_REMADE) : 0; }
     if (!strcmp(key, "ready_mode"))  { device_current(); return G.dev ? avdsp_hip_prog_get_option(G.dev, AVDSP_OPT_READY_MODE) : 0; }
     if (!strcmp(key, "fir_rows"))    return G.opt_fir_rows;
     if (!strcmp(key, "host_split"))  return G.opt_host_split;

@@ -3494,6 +3494,8 @@ struct avdsp_hip_prog {
     int ready_mode_now = 0;              /* (the mode of the launch being made) */
     int side_by_side = 0;                /* kernels of the FIRs' stream and of the cascades' have been seen to run at once (probe_side_by_side): without that no ready words */
     std::vector<std::pair<hipStream_t, int>> probed;      /* ... per stream the FIRs were launched on */
+    std::vector<hipStream_t> retired;                     /* cascades' streams that shared a hardware queue with a FIRs' stream (probe_side_by_side) */
+    int remade = 0;                                       /* ... how many times the cascades' stream was made anew */
     unsigned *d_ready_timeouts = nullptr;        /* [0] waves whose bounded wait for a ready word ran out (never, see chain_ready_wait); [2..3] the device address of h_ready_flag */
     unsigned *h_ready_flag = nullptr;            /* mapped pinned host word such a wave sets: the host sees it without a copy or a synchronisation (ready_check) */
     int ready_test = 0;                          /* tests only: that many coming launches of "ready_words" 2 skip their ready_set kernel, so that their FIR waves time out */
@@ -3925,15 +3927,9 @@ __global__ void probe_wait(const unsigned *flag, unsigned *seen)
 }
 __global__ void probe_set(unsigned *flag) { if (threadIdx.x == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-static int probe_side_by_side(avdsp_hip_prog *prog, hipStream_t fir_stream)
+static int probe_once(avdsp_hip_prog *prog, hipStream_t fir_stream, bool *ok)
 {
-    /* per stream the FIRs are launched on: whether two streams run side by side depends on the hardware queues the runtime gave them
-     * (it has a handful and deals them out in turn: a caller's stream that shares one with the cascades' stream would have its FIR
-     * wait for a kernel queued BEHIND it) */
-    for (auto &pr : prog->probed) if (pr.first == fir_stream) { prog->side_by_side = pr.second; return 0; }
-    prog->side_by_side = 0;
-    if (prog->probed.size() >= 16) prog->probed.clear();
-    prog->probed.push_back({fir_stream, 0});
+    *ok = false;
     if (!prog->d_ready_timeouts || !prog->h_ready_flag) return 0;
     unsigned *dseen = nullptr;
     HIP_TRY(hipHostGetDevicePointer((void **)&dseen, prog->h_ready_flag, 0));
@@ -3947,8 +3943,40 @@ static int probe_side_by_side(avdsp_hip_prog *prog, hipStream_t fir_stream)
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(fir_stream));
     HIP_TRY(hipStreamSynchronize(prog->s_bq));
-    prog->side_by_side = *(volatile unsigned *)(prog->h_ready_flag + 1) == 1u;
-    prog->probed.back().second = prog->side_by_side;
+    *ok = *(volatile unsigned *)(prog->h_ready_flag + 1) == 1u;
+    return 0;
+}
+
+/* Per stream the FIRs are launched on: do its kernels and the cascades' stream's run side by side?  That depends on the hardware
+ * queues the runtime gave the two streams -- it has a handful per device and deals them out in turn, so a caller's stream may well
+ * share one with the cascades' stream.  Then the whole overlap mode is a fiction: cascade and FIR take turns on one queue and the
+ * step is their SUM (round 5 saw it in the round's own bench lines: a 512-chain shard at 107.7 us instead of 88, a 1024-chain one
+ * at 163.9 instead of 147 -- FIR + cascade to the microsecond -- in one process out of several; round 4's "two states of a shard"
+ * were probably this as well), and a FIR that looks at ready words would wait for a kernel queued BEHIND it.  So the pair is
+ * tried once per stream (a kernel that waits for a word, a kernel on the other stream that sets it), and when they do not run at
+ * once the cascades' stream is made anew -- the next one the runtime hands out sits on another queue -- up to six times.  What is
+ * left after that (dispatches serialised from outside: a counter-collecting profiler) runs on events, correct anywhere. */
+static int probe_side_by_side(avdsp_hip_prog *prog, hipStream_t fir_stream)
+{
+    for (auto &pr : prog->probed) if (pr.first == fir_stream) { prog->side_by_side = pr.second; return 0; }
+    prog->side_by_side = 0;
+    if (prog->probed.size() >= 16) prog->probed.clear();
+    bool ok = false;
+    for (int attempt = 0; attempt < 6; attempt++) {
+        if (probe_once(prog, fir_stream, &ok)) return -1;
+        if (ok || !prog->d_ready_timeouts || prog->remade >= 8) break;
+        /* the pair shares a queue (or nothing runs side by side here at all): another stream for the cascades.  The old one is kept
+         * until the program goes (destroying it would hand its queue slot straight back), and every pair tried so far is void. */
+        hipStream_t ns = nullptr;
+        HIP_TRY(hipStreamCreateWithFlags(&ns, hipStreamNonBlocking));
+        HIP_TRY(hipStreamSynchronize(prog->s_bq));
+        prog->retired.push_back(prog->s_bq);
+        prog->s_bq = ns;
+        prog->probed.clear();
+        prog->remade++;
+    }
+    prog->side_by_side = ok;
+    prog->probed.push_back({fir_stream, ok ? 1 : 0});
     return 0;
 }
 
@@ -3972,8 +4000,7 @@ int launch_all(avdsp_hip_prog *prog, Plan &pl, BlockIO io, int fir_impl, int biq
     pl.seq++;                                             /* this launch's number in the plan's ready words */
     if (under) {
         if (overlap_ready(prog)) return -1;
-        if (prog->ready_words != 0 && (fir_impl == 1 || fir_impl == 4) &&
-            probe_side_by_side(prog, prog->overlap >= 2 ? prog->s_fir[prog->blk & 1] : stream)) return -1;     /* (remembered per stream) */
+        if (probe_side_by_side(prog, prog->overlap >= 2 ? prog->s_fir[prog->blk & 1] : stream)) return -1;     /* (remembered per stream) */
         /* fir_tile finds its cascades' blocks through the ready words; the other FIR kernels wait for the cascades' event */
         const bool can_words = (fir_impl == 1 || fir_impl == 4) && pl.d_ready && prog->d_ready_timeouts && prog->side_by_side;
         /* Mode 2 takes the wait packet off the FIRs' stream (a FIR follows the previous one like any kernel of a queue): 4096 chains
@@ -4142,6 +4169,7 @@ void avdsp_hip_prog_destroy(avdsp_hip_prog *p)
         for (auto e : {sl.h2d, sl.run, sl.d2h}) if (e) (void)hipEventDestroy(e);
     }
     if (p->s_bq) (void)hipStreamDestroy(p->s_bq);
+    for (auto st : p->retired) (void)hipStreamDestroy(st);
     for (auto fs : p->s_fir) if (fs) (void)hipStreamDestroy(fs);
     if (p->ev_unpack) (void)hipEventDestroy(p->ev_unpack);
     for (int i = 0; i < avdsp_hip_prog::kAhead; i++) { if (p->ev_bq[i]) (void)hipEventDestroy(p->ev_bq[i]); if (p->ev_fir[i]) (void)hipEventDestroy(p->ev_fir[i]); }
@@ -5613,6 +5641,7 @@ int avdsp_hip_prog_get_option(avdsp_hip_prog *prog, int key)
     switch (key) {
     case AVDSP_OPT_SIDE_BY_SIDE: return prog->s_bq ? prog->side_by_side : -1;      /* -1: not probed yet (no overlapped launch so far) */
     case AVDSP_OPT_READY_MODE:   return prog->ready_mode_now;
+    case AVDSP_OPT_STREAMS_REMADE: return prog->remade;
     }
     return -1;
 }

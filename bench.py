@@ -677,7 +677,7 @@ def main():
             "config": {"workload": f"{args.workload}: {C} ch x ({S} biquads + {T}-tap FIR), block {B} frames, "
                                    f"DSP_FORMAT {fmt}; {shard_txt}, no data-path collective",
                        "channels": C, "channels_per_gpu": Cl, "sections": S, "taps": T, "block": B, "format": fmt,
-                       "overlap": r.get_option("overlap"), "ready_words": r.get_option("ready_words"), "ready_mode": r.get_option("ready_mode"), "side_by_side": r.get_option("side_by_side"), "fir_split": r.get_option("fir_split"), "fir_launch": r.get_option("fir_launch"), "fir_lean": r.get_option("fir_lean"), "ring_wait": r.get_option("ring_wait"), "settle_s": args.settle, "profile_stride": stride},
+                       "overlap": r.get_option("overlap"), "ready_words": r.get_option("ready_words"), "ready_mode": r.get_option("ready_mode"), "side_by_side": r.get_option("side_by_side"), "streams_remade": r.get_option("streams_remade"), "fir_split": r.get_option("fir_split"), "fir_launch": r.get_option("fir_launch"), "fir_lean": r.get_option("fir_lean"), "ring_wait": r.get_option("ring_wait"), "settle_s": args.settle, "profile_stride": stride},
             "roofline": roof,
             "hbm_frac_step": step_bytes / step_s / 1e9 / PEAK_HBM_GBS,
             "kernels_ms": {"biquad": bq_raw, "fir": fir_raw, "event_pair": pair_ms,

@@ -89,3 +89,33 @@ def test_a_timeout_inside_a_synchronous_host_call_is_that_calls_error():
     assert r.get_option("ready_timeouts") == 0
     r.run_block(x[2 * B:], C, C)
     r.release()
+
+
+def test_the_cascades_stream_never_shares_a_hardware_queue_with_the_callers():
+    """The overlap mode needs the cascades' stream and the FIRs' (the caller's) to RUN side by side; the runtime deals its few hardware
+    queues out to streams in turn, so some caller's stream shares one with the cascades' stream -- and then cascade and FIR take turns
+    (round 5 found the round's own bench lines at FIR + cascade in one process out of several).  The library tries each pair once and
+    makes the cascades' stream anew until they do run at once.  Here: one program driven from five different caller's streams in turn
+    (more than there are queues: one of them collides with whatever the cascades' stream got) -- every one ends up side by side, and
+    the results are the oracle's."""
+    import torch
+    fmt, C, S, T, B = 6, 64, 4, 300, 1024
+    prog = pb.synth_program(fmt, C, S, T)
+    nb = 10
+    x = pb.lcg_input(nb * B, C, True, seed=79)
+    want = po.OracleProgram(fmt, prog).run_block(x, C, C, block=B)
+    r = rt.Runtime(fmt, prog)
+    r.set_option("overlap", 1)
+    xd = torch.from_numpy(x).cuda()
+    yd = torch.zeros_like(xd)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(5)]
+    for k in range(nb):
+        s = streams[(k // 2) % 5]
+        r.run_block_device(xd[k * B:].data_ptr(), C, C, yd[k * B:].data_ptr(), C, 0, B, s.cuda_stream)
+        torch.cuda.synchronize()                                # (blocks of one program are ordered by the caller: here by waiting)
+        assert r.get_option("side_by_side") == 1, f"block {k}: the cascades' stream shares a queue with caller's stream {(k // 2) % 5}"
+    assert (_words(yd.cpu().numpy()) == _words(want)).all()
+    assert 0 <= r.get_option("streams_remade") <= 8
+    assert r.get_option("ready_timeouts") == 0
+    r.release()
