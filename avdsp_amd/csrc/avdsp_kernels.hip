@@ -3496,6 +3496,8 @@ struct avdsp_hip_prog {
     std::vector<std::pair<hipStream_t, int>> probed;      /* ... per stream the FIRs were launched on */
     std::vector<hipStream_t> retired;                     /* cascades' streams that shared a hardware queue with a FIRs' stream (probe_side_by_side) */
     int remade = 0;                                       /* ... how many times the cascades' stream was made anew */
+    int cu_split = 0;                                     /* "cu_split" (experiment, round 5): > 0: the cascades' stream runs on that many CUs (a CU mask: the first cu_split / 8 CUs of
+                                                             every XCD), the FIRs on a stream of the library's own with the complementary mask */
     unsigned *d_ready_timeouts = nullptr;        /* [0] waves whose bounded wait for a ready word ran out (never, see chain_ready_wait); [2..3] the device address of h_ready_flag */
     unsigned *h_ready_flag = nullptr;            /* mapped pinned host word such a wave sets: the host sees it without a copy or a synchronisation (ready_check) */
     int ready_test = 0;                          /* tests only: that many coming launches of "ready_words" 2 skip their ready_set kernel, so that their FIR waves time out */
@@ -3927,6 +3929,22 @@ __global__ void probe_wait(const unsigned *flag, unsigned *seen)
 }
 __global__ void probe_set(unsigned *flag) { if (threadIdx.x == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+/* the cascades' stream and the FIRs' own streams; with "cu_split" k: on k CUs / on the others (tools/cu_mask_probe.hip: mask bit i is
+ * CU i / 8 of XCD i % 8, so the low k bits are the first k / 8 CUs of every XCD) */
+static int make_side_stream(avdsp_hip_prog *prog, hipStream_t *st, bool cascades)
+{
+    const int ncu = prog->cu_split < 0 ? -prog->cu_split : prog->cu_split;      /* (< 0: only the cascades' stream is masked, the FIRs stay where they are) */
+    if (ncu == 0 || (prog->cu_split < 0 && !cascades)) { HIP_TRY(hipStreamCreateWithFlags(st, hipStreamNonBlocking)); return 0; }
+    uint32_t m[8];
+    for (int w = 0; w < 8; w++) {
+        uint32_t low = 0;
+        for (int bit = 0; bit < 32; bit++) if (32 * w + bit < ncu) low |= 1u << bit;
+        m[w] = cascades ? low : ~low;
+    }
+    HIP_TRY(hipExtStreamCreateWithCUMask(st, 8, m));
+    return 0;
+}
+
 static int probe_once(avdsp_hip_prog *prog, hipStream_t fir_stream, bool *ok)
 {
     *ok = false;
@@ -3968,7 +3986,7 @@ static int probe_side_by_side(avdsp_hip_prog *prog, hipStream_t fir_stream)
         /* the pair shares a queue (or nothing runs side by side here at all): another stream for the cascades.  The old one is kept
          * until the program goes (destroying it would hand its queue slot straight back), and every pair tried so far is void. */
         hipStream_t ns = nullptr;
-        HIP_TRY(hipStreamCreateWithFlags(&ns, hipStreamNonBlocking));
+        if (make_side_stream(prog, &ns, true)) return -1;
         HIP_TRY(hipStreamSynchronize(prog->s_bq));
         prog->retired.push_back(prog->s_bq);
         prog->s_bq = ns;
@@ -3983,8 +4001,8 @@ static int probe_side_by_side(avdsp_hip_prog *prog, hipStream_t fir_stream)
 static int overlap_ready(avdsp_hip_prog *prog)
 {
     if (prog->s_bq) return 0;
-    HIP_TRY(hipStreamCreateWithFlags(&prog->s_bq, hipStreamNonBlocking));
-    for (auto &fs : prog->s_fir) HIP_TRY(hipStreamCreateWithFlags(&fs, hipStreamNonBlocking));
+    if (make_side_stream(prog, &prog->s_bq, true)) return -1;
+    for (auto &fs : prog->s_fir) if (make_side_stream(prog, &fs, false)) return -1;
     for (int i = 0; i < avdsp_hip_prog::kAhead; i++) {
         /* they order kernels of this device among themselves: no system-scope fence (tools/stream_handover_bench.hip: 8.1 instead of 10.6 us) */
         HIP_TRY(hipEventCreateWithFlags(&prog->ev_bq[i], hipEventDisableTiming | hipEventDisableSystemFence));
@@ -4000,7 +4018,8 @@ int launch_all(avdsp_hip_prog *prog, Plan &pl, BlockIO io, int fir_impl, int biq
     pl.seq++;                                             /* this launch's number in the plan's ready words */
     if (under) {
         if (overlap_ready(prog)) return -1;
-        if (probe_side_by_side(prog, prog->overlap >= 2 ? prog->s_fir[prog->blk & 1] : stream)) return -1;     /* (remembered per stream) */
+        const bool own_fir = prog->overlap >= 2 || prog->cu_split > 0;      /* the FIRs on a stream of the library's own */
+        if (probe_side_by_side(prog, prog->overlap >= 2 ? prog->s_fir[prog->blk & 1] : prog->cu_split > 0 ? prog->s_fir[0] : stream)) return -1;     /* (remembered per stream) */
         /* fir_tile finds its cascades' blocks through the ready words; the other FIR kernels wait for the cascades' event */
         const bool can_words = (fir_impl == 1 || fir_impl == 4) && pl.d_ready && prog->d_ready_timeouts && prog->side_by_side;
         /* Mode 2 takes the wait packet off the FIRs' stream (a FIR follows the previous one like any kernel of a queue): 4096 chains
@@ -4046,12 +4065,13 @@ int launch_all(avdsp_hip_prog *prog, Plan &pl, BlockIO io, int fir_impl, int biq
             hipLaunchKernelGGL(ready_set, dim3((unsigned)((pl.n_fir + kBlock - 1) / kBlock)), dim3(kBlock), 0, prog->s_bq, pl.d_ready, pl.d_fir_ids, pl.n_fir, pl.seq);
             HIP_TRY(hipGetLastError());
         }
-        if (prog->overlap >= 2) {
-            /* the FIRs of consecutive blocks on two streams of the library's own, in turn: FIR k+1 needs nothing of FIR k, and on one
+        if (own_fir) {
+            /* ("cu_split": ONE stream of the library's own, on the CUs the cascades' stream does not have)
+             * the FIRs of consecutive blocks on two streams of the library's own, in turn: FIR k+1 needs nothing of FIR k, and on one
              * stream it would start a queue hand-over (~10 us) after FIR k's last wave; here its first workgroups fill the chip as FIR
              * k's last ones leave.  The caller's stream only waits for each FIR's end.  (The mode's contract then covers the output
              * too: the block a call writes must not be one an earlier call's FIR may still be writing.) */
-            hipStream_t fs = prog->s_fir[prog->blk & 1];
+            hipStream_t fs = prog->s_fir[prog->overlap >= 2 ? (prog->blk & 1) : 0];
             if (!words) HIP_TRY(hipStreamWaitEvent(fs, prog->ev_bq[slot], 0));
             if (launch_fir<FMT>(prog, pl, pl.d_fir_ids, pl.n_fir, io, fir_impl, fs, words)) return -1;
             HIP_TRY(hipEventRecord(prog->ev_fir[slot], fs));
@@ -5619,6 +5639,20 @@ int avdsp_hip_prog_set_option(avdsp_hip_prog *prog, int key, int value)
     case AVDSP_OPT_FIR_LEAN: if (value < -1 || value > 1) return set_err("fir_lean: -1 (auto), 0 or 1"); prog->fir_lean = value; return 0;
     case AVDSP_OPT_RING_WAIT: prog->ring_wait_host = value != 0; return 0;
     case AVDSP_OPT_READY_TEST: prog->ready_test = value > 0 ? value : 0; return 0;
+    case AVDSP_OPT_CU_SPLIT:
+        if (value < -128 || value > 128 || (value & 7)) return set_err("cu_split: 0 (off) or 8, 16, ... 128 CUs for the cascades' stream (negative: the FIRs stay on the caller's stream, unmasked)");
+        if (value != prog->cu_split) {                   /* the side streams are made anew with their masks at the next overlapped launch */
+            if (prog->s_bq) { (void)hipStreamDestroy(prog->s_bq); prog->s_bq = nullptr; }
+            for (auto &fs : prog->s_fir) if (fs) { (void)hipStreamDestroy(fs); fs = nullptr; }
+            for (int i = 0; i < avdsp_hip_prog::kAhead; i++) {
+                if (prog->ev_bq[i]) { (void)hipEventDestroy(prog->ev_bq[i]); prog->ev_bq[i] = nullptr; }
+                if (prog->ev_fir[i]) { (void)hipEventDestroy(prog->ev_fir[i]); prog->ev_fir[i] = nullptr; }
+                prog->ev_fir_set[i] = false; prog->ev_fir_now[i] = nullptr;
+            }
+            prog->probed.clear();
+            prog->cu_split = value;
+        }
+        return 0;
     case AVDSP_OPT_FIR_LAUNCH: if (value < -1 || value > 2) return set_err("fir_launch: -1 (auto), 0, 1 or 2"); prog->fir_launch_mode = value; return 0;
     case AVDSP_OPT_FIR_ROWS: if (value != 0 && value != 1 && value != 2 && value != 4) return set_err("fir_tile row tiles: 0 (auto), 1, 2 or 4");
                              prog->fir_rows = value; return 0;

@@ -310,6 +310,8 @@ def main():
     ap.add_argument("--settle", type=float, default=0.5, help="seconds of untimed steps in front of the warm-up: the chip raises its clock over the first ~0.1 s of load "
                     "(tools/fir_timeline.py: 2.15 GHz in-kernel after 6 blocks, 2.36 GHz after 200) and a short run would be timed on the ramp")
     ap.add_argument("--profile-stride", type=int, default=0, help="time every n-th launch of the dominant kernel in the timed region with its dispatch stamps (0: the default below)")
+    ap.add_argument("--cu-split", type=int, default=0, help="experiment (DESIGN.md 5c): under --overlap the cascades' stream on that many CUs of its own (8, 16, 32 ...), the FIRs on a library stream on the others")
+    ap.add_argument("--own-stream", action="store_true", help="hand the library a stream of this process's own (non-blocking) instead of the current (null) stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=10.0, help="seconds of CPU work for the all-cores leg of cpu_baseline (the single thread gets 0.35 of it)")
     ap.add_argument("--block", type=int, default=0, help="frames per block call (0: the workload's own, 1024 for the BASELINE configs): the host's period is the block "
@@ -393,6 +395,8 @@ def main():
         if args.fir_lean >= 0:
             rr.set_option("fir_lean", args.fir_lean)
         rr.set_option("ring_wait", args.ring_wait)
+        if args.cu_split:
+            rr.set_option("cu_split", args.cu_split)
         if args.fir_rows >= 0:
             rr.set_option("fir_rows", args.fir_rows)
         if args.host_split >= 0:
@@ -443,6 +447,10 @@ def main():
     x = torch.from_numpy(xs).cuda()
     y = torch.zeros((B, Cl), dtype=x.dtype, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
+    if args.own_stream:
+        torch.cuda.synchronize()
+        own_stream = torch.cuda.Stream()
+        stream = own_stream.cuda_stream
 
     # "overlap" 2 lets the FIRs of consecutive blocks run into each other: a block's output must then not be the buffer an earlier
     # call may still be writing (the mode's contract) -- three output blocks in turn
@@ -677,7 +685,7 @@ def main():
             "config": {"workload": f"{args.workload}: {C} ch x ({S} biquads + {T}-tap FIR), block {B} frames, "
                                    f"DSP_FORMAT {fmt}; {shard_txt}, no data-path collective",
                        "channels": C, "channels_per_gpu": Cl, "sections": S, "taps": T, "block": B, "format": fmt,
-                       "overlap": r.get_option("overlap"), "ready_words": r.get_option("ready_words"), "ready_mode": r.get_option("ready_mode"), "side_by_side": r.get_option("side_by_side"), "streams_remade": r.get_option("streams_remade"), "fir_split": r.get_option("fir_split"), "fir_launch": r.get_option("fir_launch"), "fir_lean": r.get_option("fir_lean"), "ring_wait": r.get_option("ring_wait"), "settle_s": args.settle, "profile_stride": stride},
+                       "overlap": r.get_option("overlap"), "ready_words": r.get_option("ready_words"), "ready_mode": r.get_option("ready_mode"), "side_by_side": r.get_option("side_by_side"), "streams_remade": r.get_option("streams_remade"), "cu_split": r.get_option("cu_split"), "fir_split": r.get_option("fir_split"), "fir_launch": r.get_option("fir_launch"), "fir_lean": r.get_option("fir_lean"), "ring_wait": r.get_option("ring_wait"), "settle_s": args.settle, "profile_stride": stride},
             "roofline": roof,
             "hbm_frac_step": step_bytes / step_s / 1e9 / PEAK_HBM_GBS,
             "kernels_ms": {"biquad": bq_raw, "fir": fir_raw, "event_pair": pair_ms,

@@ -119,3 +119,32 @@ def test_the_cascades_stream_never_shares_a_hardware_queue_with_the_callers():
     assert 0 <= r.get_option("streams_remade") <= 8
     assert r.get_option("ready_timeouts") == 0
     r.release()
+
+
+def test_cu_split_experiment_is_bit_identical():
+    """"cu_split" (experiment): the overlap mode's cascades on a CU-masked stream of 16 CUs, the FIRs on a library stream
+    with the complementary mask -- a launch arrangement, so the bits are the oracle's whatever it does to the step."""
+    import torch
+    fmt, C, S, T, B = 6, 48, 6, 700, 1024
+    prog = pb.synth_program(fmt, C, S, T)
+    nb = 6
+    x = pb.lcg_input(nb * B, C, True, seed=80)
+    o = po.OracleProgram(fmt, prog)
+    want = o.run_block(x, C, C, block=B)
+    for split in (16, -32, 0):
+        r = rt.Runtime(fmt, prog)
+        r.set_option("overlap", 1)
+        r.set_option("cu_split", split)
+        assert r.get_option("cu_split") == split
+        xd = [torch.from_numpy(x[k * B:(k + 1) * B].copy()).cuda() for k in range(nb)]
+        yd = [torch.zeros((B, C), dtype=xd[0].dtype, device="cuda") for _ in range(nb)]
+        torch.cuda.synchronize()
+        own = torch.cuda.Stream()
+        for k in range(nb):
+            r.run_block_device(xd[k].data_ptr(), C, C, yd[k].data_ptr(), C, 0, B, own.cuda_stream)
+        torch.cuda.synchronize()
+        got = np.concatenate([y.cpu().numpy() for y in yd])
+        assert (_words(got) == _words(want)).all(), f"cu_split {split}"
+        assert (r.sync_state() == o.state).all()
+        r.set_option("cu_split", 0)
+        r.release()
