@@ -18,7 +18,12 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True)
 def _release():
+    # (an option set on a program is also the default of programs loaded later: start from the library's own kernels whatever ran before)
+    for key, value in ((b"fir_impl", 1), (b"biquad_impl", 1), (b"generic", 0), (b"overlap", 0), (b"ready_words", -1), (b"cu_split", 0)):
+        rt.lib().dspRuntimeSetOption(key, value)
     yield
+    for key, value in ((b"overlap", 0), (b"ready_words", -1), (b"cu_split", 0)):
+        rt.lib().dspRuntimeSetOption(key, value)
     rt.lib().dspRuntimeRelease()
 
 
