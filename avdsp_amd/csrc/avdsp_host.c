@@ -109,6 +109,7 @@ typedef struct avdsp_ctx {
     int             inst_chain_mode;                       /* 0 not looked yet, 1 every core runs on the interpreter, 2 every core is a chain core (round 5) */
     int             chain_inst_made;                       /* the device holds ninst copies of the mirror; the plans are ninst x the cores' chains, made for ... */
     size_t          chain_inst_in, chain_inst_out;         /* ... these distances between the instances' sample blocks (words) */
+    int             chain_inst_win[5];                     /* the windows the cores' IOs were last checked against (format, in base, in stride, out base, out stride); [0] = 0: none */
 } avdsp_ctx;
 
 /* no program loaded: options set now are the defaults every program starts from (and keeps following, see dspRuntimeSetOption) */
@@ -153,6 +154,7 @@ static void drop_device(void)
     for (int i_ = 0; i_ < MAX_ARRANGEMENTS; i_++) G.arr[i_].valid = 0;
     G.dev_state_valid = 0;
     G.chain_inst_made = 0;
+    G.chain_inst_win[0] = 0;
 }
 
 /* swap a program's statics in: the exported globals of the reference runtime follow, and so does the active GPU */
@@ -245,6 +247,7 @@ static int replan(void)
     if (G.dev && avdsp_hip_prog_clear_plans(G.dev)) return hip_fail();
     G.nplans = 0;
     for (int i_ = 0; i_ < MAX_ARRANGEMENTS; i_++) G.arr[i_].valid = 0;
+    G.chain_inst_win[0] = 0;
     return 0;
 }
 
@@ -2317,7 +2320,12 @@ int dspRuntimeBlockAllInstancesDevice(int format, int *rundata, const void *d_in
             if (!c || (k > 1 && c == G.code)) break;
             core_plan *cp = get_plan(format, c);
             if (!cp) { rc = g_err_code; break; }
-            if (!cp->empty) {
+            const int same_win = G.chain_inst_win[0] == format && G.chain_inst_win[1] == in_io_base && G.chain_inst_win[2] == in_stride &&
+                                 G.chain_inst_win[3] == out_io_base && G.chain_inst_win[4] == out_stride;
+            if (!cp->empty && same_win) {                 /* (checked by an earlier call: the usual case, a host's windows do not move) */
+                if (avdsp_hip_run_block(G.dev, cp->plan_id, d_in, in_stride, in_io_base, d_out, out_stride, out_io_base,
+                                        nframes, G.opt_fir_impl, G.opt_biquad_impl, stream)) rc = hip_fail();
+            } else if (!cp->empty) {
                 /* the windows against the program's own IO numbers (the plan's carry the instances' offsets) */
                 lowered L;
                 memset(&L, 0, sizeof L);
@@ -2334,6 +2342,8 @@ int dspRuntimeBlockAllInstancesDevice(int format, int *rundata, const void *d_in
             if (c == G.code) break;
         }
         G.inst_call = 0;
+        if (!rc) { G.chain_inst_win[0] = format; G.chain_inst_win[1] = in_io_base; G.chain_inst_win[2] = in_stride; G.chain_inst_win[3] = out_io_base; G.chain_inst_win[4] = out_stride; }
+        else G.chain_inst_win[0] = 0;
         return rc;
     }
     /* the strand plans know nothing of instances: dspRuntimeSetInstances(n > 1) has switched them off for as long as the program has
