@@ -155,6 +155,7 @@ static void drop_device(void)
     G.dev_state_valid = 0;
     G.chain_inst_made = 0;
     G.chain_inst_win[0] = 0;
+    G.inst_chain_mode = 0;               /* (which kind of program it is gets looked at again: another program, another option) */
 }
 
 /* swap a program's statics in: the exported globals of the reference runtime follow, and so does the active GPU */
@@ -248,6 +249,7 @@ static int replan(void)
     G.nplans = 0;
     for (int i_ = 0; i_ < MAX_ARRANGEMENTS; i_++) G.arr[i_].valid = 0;
     G.chain_inst_win[0] = 0;
+    if (!G.chain_inst_made) G.inst_chain_mode = 0;
     return 0;
 }
 
