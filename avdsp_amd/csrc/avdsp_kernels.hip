@@ -5472,6 +5472,10 @@ int avdsp_hip_download_instance_words(avdsp_hip_prog *p, int inst, int32_t *host
         HIP_TRY(hipMemcpy(host_buf, p->d_buf + (size_t)inst * AVDSP_INSTANCE_STRIDE(p->total_words) + first, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
         return 0;
     }
+    /* (instance 0 of a program with ONE instance may be a chain program like any other: its FIR histories live in the plans' rings) */
+    READY_CHECK(p);
+    if (rings_to_mirror(p)) return -1;
+    HIP_TRY(hipDeviceSynchronize());
     const int *src = p->d_buf;
     if (inst > 0) {
         if (!p->inst_valid || !p->d_inst_buf) return set_err("the instances have not run yet");

@@ -240,3 +240,11 @@ def test_instances_refuse_a_program_of_both_kinds():
         r.run_block_all_instances_device(x.data_ptr(), 8, 0, 64 * 8, y.data_ptr(), 8, 0, 64 * 8, 64, 0)
     assert "all of one kind" in str(e.value)
     r.release()
+
+
+def test_one_instance_of_a_fir_chain_program_hands_back_its_fir_history():
+    """found by tests/dev/gpu_instance_sweep.py (14 of its first 400 runs): with ONE instance a chain program runs on its ordinary plan, whose
+    FIR histories live in device rings -- dspRuntimeInstanceState(0) has to bring them home like dspRuntimeSyncState does"""
+    prog = pb.synth_program(6, 2, 8, 33)
+    r = _chain_instances_vs_oracle(6, prog, 2, 1, [256, 64])
+    r.release()

@@ -73,3 +73,26 @@ def test_overlap_arrangements_on_random_shapes(lo):
     from tests.dev.gpu_overlap_sweep import run
     n, bad = run(lo, lo + 18)
     assert n == 18 and not bad, bad
+
+
+@pytest.mark.parametrize("lo", range(0, 60, 20))
+def test_random_chain_programs_in_instances_slice(lo):
+    """seeds lo .. lo + 19 of tests/dev/gpu_instance_sweep.py: random chain programs (cascades, FIRs, both; five formats in turn) in 1 .. 37
+    instances, ragged blocks, every instance with its own input against the oracle -- outputs and each instance's state"""
+    from tests.dev.gpu_instance_sweep import run
+    n, bad = run(lo, lo + 20)
+    assert n == 20 and not bad, bad
+
+
+@pytest.mark.parametrize("rows", [2, 4])
+def test_random_chain_shapes_with_forced_row_tiles(rows):
+    """seeds 200 .. 239 of the chain sweep with fir_tile's row tiles forced: short and ragged blocks (1 .. 2500 frames) then regroup a
+    workgroup's waves by the tiles the block has (round 5), including four chains of one 512-frame tile each"""
+    import os
+    from tests.dev.gpu_chain_sweep import run
+    os.environ["AVDSP_SWEEP_OPTIONS"] = f"fir_rows={rows}"
+    try:
+        n, bad = run(200, 240, formats=(4, 6))
+    finally:
+        os.environ.pop("AVDSP_SWEEP_OPTIONS", None)
+    assert n > 0 and not bad, bad
