@@ -12,6 +12,11 @@
  * There is NO CPU execution path in this library: a core that cannot be lowered to the device
  * kernels, a missing GPU, or a HIP error makes the call return a negative code and leaves a message
  * in dspRuntimeLastError().  (A CPU restatement exists under oracle/ -- test infrastructure only.)
+ * Codes: -1 .. -6 the reference's (dsp_runtime.c:119-125,159-194: no header, no cores, checksum, opcode too new, buffer too
+ * small, sample rate), -7 an encoding this library cannot convert, -8 a core refused (no defined result / an offset outside the
+ * buffer / a shape the call cannot take), -9 out of memory or table space, -10 a HIP error, -11 (sticky) a FIR wave of the overlap
+ * mode gave up waiting for its cascade: the block is not valid, acknowledge with dspRuntimeReset() or
+ * dspRuntimeSetOption("ready_timeouts", 0).
  *
  * Ownership is the reference's: the caller owns ONE contiguous int32 buffer holding the program
  * followed by the state ("data") area, dspRuntimeInit returns the program length so that
@@ -213,14 +218,23 @@ int dspRuntimeStrandInfo(int format, opcode_t *core, int *strands, int *ops_per_
  * "overlap" (chain cores with cascades in front of FIRs, blocks resident on the device) 1 = the cascades run up to three blocks ahead of
  * the FIRs on a stream of the library's own -- the caller then guarantees that a block's INPUT is complete in memory when the call is made
  * (stream order no longer covers it); 2 = also the FIRs of consecutive blocks on two streams in turn, so that one starts while the other's
- * last workgroups leave (worth 5 % on a 4096-channel program, a loss below ~2000 channels) -- the caller then also guarantees that the
+ * last workgroups leave (worth 3.5 % on a 4096-channel program, a loss below ~2000 channels) -- the caller then also guarantees that the
  * OUTPUT block of a call is not one an earlier call's FIR may still be writing (the caller's stream still waits for every block's end).
  * Results are identical in every mode.  Under "overlap": "ring_wait" 1 (default) = the HOST waits (at most 1 ms, then it leaves it to the
  * stream after all) until the FIR three blocks back has ended before it enqueues a block's cascade -- the call then returns no more than
  * three blocks ahead of the device, and the cascades' stream carries no wait packet (worth 10 % on a 512-channel shard); 0 = that stream
  * waits.  "ready_words" = how a block's FIR finds its cascades' block: 0 an event between the two queues, 1 words published by the
  * cascade's waves and polled by the FIR's (slower), 2 words set by a kernel behind the cascade (no wait packet on the FIRs' stream),
- * -1 (default) = 2 where the FIR is the bound, else 0.                                              */
+ * -1 (default) = 2 where the FIR is the bound, else 0.  Round 5: ready words are only taken once kernels of the FIRs' stream and of the
+ * cascades' stream have been SEEN to run side by side (a one-time probe per stream; dspRuntimeGetOption("side_by_side") 1 / 0 / -1 not
+ * tried yet), and the cascades' stream is made anew while it shares a hardware queue with the FIRs' ("streams_remade" says how often) --
+ * without that the mode does not overlap anything.  A FIR wave whose bounded wait for a ready word runs out all the same (a GPU that stops
+ * running two queues at once) makes EVERY later call fail with -11 until dspRuntimeReset() or dspRuntimeSetOption("ready_timeouts", 0)
+ * acknowledges; dspRuntimeGetOption("ready_timeouts") counts such waves, ("ready_mode") tells what the latest launch used.
+ * "cu_split" k (experiment; 0 = off): under "overlap" the cascades' stream on k CUs of its own (8, 16, 32 ...; a CU mask),
+ * the FIRs on a stream of the library's with the complementary mask (negative k: only the cascades masked); hand over a non-blocking
+ * stream of your own with it -- CU-masked streams are blocking streams, beside the null stream every launch on them synchronises.
+ * A program's options are also the defaults of programs loaded later.                                */
 int dspRuntimeSetOption(const char *key, int value);
 int dspRuntimeGetOption(const char *key);
 
