@@ -13,7 +13,7 @@
  * kernels, a missing GPU, or a HIP error makes the call return a negative code and leaves a message
  * in dspRuntimeLastError().  (A CPU restatement exists under oracle/ -- test infrastructure only.)
  * Codes: -1 .. -6 the reference's (dsp_runtime.c:119-125,159-194: no header, no cores, checksum, opcode too new, buffer too
- * small, sample rate), -7 an encoding this library cannot convert, -8 a core refused (no defined result / an offset outside the
+ * small; -1 / -2 from dspRuntimeReset: sample rate), -8 a core refused (no defined result / an offset outside the
  * buffer / a shape the call cannot take), -9 out of memory or table space, -10 a HIP error, -11 (sticky) a FIR wave of the overlap
  * mode gave up waiting for its cascade: the block is not valid, acknowledge with dspRuntimeReset() or
  * dspRuntimeSetOption("ready_timeouts", 0).
