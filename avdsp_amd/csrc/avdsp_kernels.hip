@@ -3738,7 +3738,11 @@ int launch_fir_tile(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, Block
     /* (BIG -- at most a wave per SIMD -- keeps the four-quarters arrangement: there a wave that leaves at once frees nothing anybody waits
      * for, and its workgroup's other waves sit on CUs of their own: 256 chains x 4096 taps at 64 .. 512 frames 36.3-37.6 us against
      * 38.1-38.8 regrouped) */
-    const int wpc = (SPLIT || BIG) ? kWpc : tiles <= 1 ? 1 : tiles <= 2 ? std::min(2, kWpc) : kWpc;
+    /* ... as long as its workgroups -- one per chain, one per CU: 140 KB of LDS -- fit the chip at once.  512 or 1024 chains at 256 frames
+     * are 512 / 1024 workgroups of ONE live wave each, two or four rounds of 36 us (a 512-chain shard's 256-frame block took 91 us,
+     * longer than its 1024-frame block): those regroup like everybody else. */
+    const bool quarters = SPLIT || (BIG && n <= (prog->num_cus > 0 ? prog->num_cus : 256));
+    const int wpc = quarters ? kWpc : tiles <= 1 ? 1 : tiles <= 2 ? std::min(2, kWpc) : kWpc;
     a.wpc_shift = wpc == 4 ? 2 : wpc == 2 ? 1 : 0;
     const int nwg = (n * wpc * (SPLIT ? 2 : 1) + 3) / 4;
     a.per_xcd = (nwg + 7) / 8;
@@ -4082,8 +4086,11 @@ int launch_all(avdsp_hip_prog *prog, Plan &pl, BlockIO io, int fir_impl, int biq
              * packet on another queue's signal -- holds the next dispatch back by ~9 us even when the signal is long down
              * (tools/step_gaps.py: 10.7 us between two FIRs of the 4096-chain program, 1.5-2 us between two kernels of one queue). */
             if (!words) HIP_TRY(hipStreamWaitEvent(stream, prog->ev_bq[slot], 0));
+            /* (round 5, tools/shard_blocks_ab.sh: mode 2's empty microseconds only pay where the cascades are the clock, and that takes
+             * a block long enough for them to be -- shards of 512 / 1024 chains, mode 2 against mode 1: 86.9 / 90.8 and 146.5 / 148.6 us at
+             * 1024 frames, but 150.4 / 138.0 at 768, 91.2 / 78.1 and 57.6 / 51.6 at 512, 58.1 / 47.9 and 56.6 / 45.4 at 256) */
             const int mode = fir_impl != 1 && fir_impl != 4 ? 0 : prog->fir_launch_mode >= 0 ? prog->fir_launch_mode
-                           : (long long)pl.n_fir * pl.max_taps <= 6000000ll ? 2 : 1;
+                           : ((long long)pl.n_fir * pl.max_taps <= 6000000ll && io.nframes > 768) ? 2 : 1;
             /* (a launch whose kernel timer is sampled carries the timer's events instead; its event is then recorded behind it) */
             const bool rides = mode == 1 && !((prog->profile >> AVDSP_KERNEL_FIR & 1u) && prog->profile_seen[AVDSP_KERNEL_FIR & 7] % (unsigned)prog->profile_stride == 0);
             prog->fir_mode_now = mode;

@@ -13,7 +13,7 @@ def run(lo, hi):
     bad, n = [], 0
     for seed in range(lo, hi):
         rng = np.random.default_rng(seed + 55000)
-        C = int(rng.choice([1024, 1027, 2048, 2052, 3000])); S = int(rng.choice([0, 1, 2])); T = int(rng.choice([17, 64, 130]))
+        C = int(rng.choice([300, 512, 700, 1024, 1027, 2048, 2052, 3000])); S = int(rng.choice([0, 1, 2])); T = int(rng.choice([17, 64, 130]))
         fmt = int(rng.choice([4, 6]))
         blocks = [int(b) for b in rng.choice([1, 64, 128, 255, 256, 257, 384, 512, 513, 768, 769, 1024], size=int(rng.integers(2, 5)))]
         prog = pb.synth_program(fmt, C, S, T)

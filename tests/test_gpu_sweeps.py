@@ -99,7 +99,7 @@ def test_random_chain_shapes_with_forced_row_tiles(rows):
 
 
 def test_many_chains_in_short_and_ragged_blocks_slice():
-    """seeds 0 .. 9 of tests/dev/gpu_wide_blocks_sweep.py: 1024 .. 3000 chains (two and four row tiles per FIR wave by the automatic choice)
+    """seeds 0 .. 9 of tests/dev/gpu_wide_blocks_sweep.py: 300 .. 3000 chains (two and four row tiles per FIR wave by the automatic choice)
     in blocks of 1 .. 1024 frames -- the regrouping of a workgroup's waves by the tiles a block has, where the chain count makes it matter"""
     from tests.dev.gpu_wide_blocks_sweep import run
     n, bad = run(0, 10)
