@@ -3856,7 +3856,20 @@ int launch_fir(avdsp_hip_prog *prog, Plan &pl, const int *ids, int n, BlockIO io
         if (fir_impl == 1) {
             /* row tiles per wave: as many as leave the chip two waves per SIMD (2048) -- a bigger tile reads fewer operands per MFMA */
             int rows = prog->fir_rows;
-            if (rows != 1 && rows != 2 && rows != 4) rows = n >= 2048 ? 4 : n >= 1024 ? 2 : 1;
+            if (rows != 1 && rows != 2 && rows != 4) {
+                /* Round 5 (tools/regime_scan.sh): the chip holds 2048 of these waves at a time, a wave of R row tiles lasts R units, and a launch
+                 * is over when its LAST round of waves is -- 3000 chains at four row tiles were 1.46 rounds, i.e. two: 480 us, as long as 4096
+                 * chains.  So: the R with the fewest units, rounds(R) x R / efficiency(R) (0.90 / 0.84 / 0.79 of the matrix pipe at 4 / 2 / 1 row
+                 * tiles).  For 512 / 1024 / 2048 / 4096 / 16384 chains that is what the thresholds chose (1 / 2 / 4 / 4 / 4). */
+                double best = 1e30;
+                rows = 1;
+                for (int r : {4, 2, 1}) {
+                    if (r > 1 && 128 * r >= io.nframes) continue;           /* a tile twice the block would multiply zeros */
+                    const long long waves = (long long)n * ((io.nframes + 256 * r - 1) / (256 * r));
+                    const double cost = (double)((waves + 2047) / 2048) * r / (r == 4 ? 0.90 : r == 2 ? 0.84 : 0.79);
+                    if (cost < best - 1e-9) { best = cost; rows = r; }
+                }
+            }
             while (rows > 1 && 128 * rows >= io.nframes) rows >>= 1;       /* a tile twice the block would multiply zeros */
             /* one row tile and at most a wave per SIMD (1024): chunks twice as long -- nothing hides a boundary there */
             const long long waves1 = (long long)n * ((io.nframes + 255) / 256);

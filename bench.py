@@ -294,6 +294,8 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="north", choices=sorted(WORKLOADS))
+    ap.add_argument("--custom", default=None, help="FMT,CHANNELS,SECTIONS,TAPS,FRAMES: a synthetic chain program of any shape instead of a named workload (no reference pins: "
+                    "nothing is verified, nothing is a BASELINE config -- tools/regime_scan.sh looks for launch arrangements that do not fit a shape)")
     ap.add_argument("--fir-impl", type=int, default=1, help="0 the reference's tap loop, 1 fir_tile (default), 2 fir_mfma (round 1), 3 fir_stream, 4 fir_flow (DESIGN.md 4.2)")
     ap.add_argument("--biquad-impl", type=int, default=1)
     ap.add_argument("--overlap", type=int, default=1, help="cascade of the next block under the FIR of this one (the blocks are resident in HBM, which is that mode's contract): 0 off, 1 on, 2 also the FIRs of consecutive blocks on two streams in turn")
@@ -324,6 +326,9 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the block-boundary collectives leg")
     args = ap.parse_args()
 
+    if args.custom:
+        WORKLOADS["custom"] = tuple(int(v) for v in args.custom.split(","))
+        args.workload = "custom"
     fmt, C, S, T, B = WORKLOADS[args.workload]
     if args.block > 0:
         B = args.block
