@@ -106,6 +106,7 @@ typedef struct avdsp_ctx {
     int             inst_call;                             /* inside dspRuntimeBlockAllInstancesDevice: block_all hands these strides on */
     size_t          inst_in_words, inst_out_words;
     int             opt_cu_split;                          /* experiment: "cu_split" */
+    int             opt_group_serial;                      /* "group_fanout" 0 (stored inverted: the default, 0, is fan-out on) */
     int             inst_chain_mode;                       /* 0 not looked yet, 1 every core runs on the interpreter, 2 every core is a chain core (round 5) */
     int             chain_inst_made;                       /* the device holds ninst copies of the mirror; the plans are ninst x the cores' chains, made for ... */
     size_t          chain_inst_in, chain_inst_out;         /* ... these distances between the instances' sample blocks (words) */
@@ -305,6 +306,11 @@ static int set_option_here(const char *key, int value)
         if (G.dev && avdsp_hip_ready_clear(G.dev)) return hip_fail();
         return 0;
     }
+    if (!strcmp(key, "group_fanout")) {                  /* 0: a plan's cascade launches (one per section count) one after the other, as through round 4 */
+        if (G.dev && avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_GROUP_FANOUT, value)) return hip_fail();
+        G.opt_group_serial = !value;
+        return 0;
+    }
     if (!strcmp(key, "cu_split")) {                      /* experiment: the cascades' stream on `value` CUs of its own (applies to the program's device copy as it is) */
         if (G.dev && avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_CU_SPLIT, value)) return hip_fail();
         G.opt_cu_split = value;
@@ -361,6 +367,7 @@ int dspRuntimeGetOption(const char *key)
         return G.dev ? avdsp_hip_profile_last_pairs(G.dev, key[13] - '0') : 0;
     if (!strcmp(key, "ready_timeouts")) { device_current(); return G.dev ? avdsp_hip_ready_timeouts(G.dev) : 0; }
     if (!strcmp(key, "cu_split"))    return G.opt_cu_split;
+    if (!strcmp(key, "group_fanout")) return !G.opt_group_serial;
     if (!strcmp(key, "side_by_side")) { device_current(); return G.dev ? avdsp_hip_prog_get_option(G.dev, AVDSP_OPT_SIDE_BY_SIDE) : -1; }
     if (!strcmp(key, "streams_remade")) { device_current(); return G.dev ? avdsp_hip_prog_get_option(G.dev, AVDSP_OPT_STREAMS_REMADE) : 0; }
     if (!strcmp(key, "ready_mode"))  { device_current(); return G.dev ? avdsp_hip_prog_get_option(G.dev, AVDSP_OPT_READY_MODE) : 0; }
@@ -486,7 +493,7 @@ int dspRuntimeInit(opcode_t *codePtr, int maxSize, const int fs, int random, int
         const avdsp_ctx *o = &g_template;
         c->opt_fir_impl = o->opt_fir_impl; c->opt_biquad_impl = o->opt_biquad_impl; c->opt_device = o->opt_device; c->opt_profile = o->opt_profile;
         c->opt_generic = o->opt_generic; c->opt_interp_impl = o->opt_interp_impl; c->opt_strand_split = o->opt_strand_split; c->opt_strand_lanes = o->opt_strand_lanes;
-        c->opt_profile_stride = o->opt_profile_stride; c->opt_overlap = o->opt_overlap; c->opt_fir_rows = o->opt_fir_rows; c->opt_host_split = o->opt_host_split; c->opt_host_pin = o->opt_host_pin; c->opt_ready_words = o->opt_ready_words; c->opt_lane_hw = o->opt_lane_hw; c->opt_fir_split = o->opt_fir_split; c->opt_fir_launch = o->opt_fir_launch; c->opt_fir_launch_set = o->opt_fir_launch_set; c->opt_fir_lean = o->opt_fir_lean; c->opt_fir_lean_set = o->opt_fir_lean_set; c->opt_ring_wait = o->opt_ring_wait; c->opt_cu_split = o->opt_cu_split;
+        c->opt_profile_stride = o->opt_profile_stride; c->opt_overlap = o->opt_overlap; c->opt_fir_rows = o->opt_fir_rows; c->opt_host_split = o->opt_host_split; c->opt_host_pin = o->opt_host_pin; c->opt_ready_words = o->opt_ready_words; c->opt_lane_hw = o->opt_lane_hw; c->opt_fir_split = o->opt_fir_split; c->opt_fir_launch = o->opt_fir_launch; c->opt_fir_launch_set = o->opt_fir_launch_set; c->opt_fir_lean = o->opt_fir_lean; c->opt_fir_lean_set = o->opt_fir_lean_set; c->opt_ring_wait = o->opt_ring_wait; c->opt_cu_split = o->opt_cu_split; c->opt_group_serial = o->opt_group_serial;
         c->shard_rank = o->shard_rank; c->shard_world = o->shard_world;
         c->mantissa = DSP_MANT; c->device_ordinal = -1;
         c->code = codePtr;
@@ -1270,6 +1277,7 @@ static int ensure_device(void)
         avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_READY_WORDS, G.opt_ready_words) || avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_LANE_HW, G.opt_lane_hw) || avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_FIR_SPLIT, G.opt_fir_split) || (G.opt_fir_launch_set && avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_FIR_LAUNCH, G.opt_fir_launch)) || (G.opt_fir_lean_set && avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_FIR_LEAN, G.opt_fir_lean)) || avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_RING_WAIT, G.opt_ring_wait) ||
         avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_HOST_SPLIT, G.opt_host_split) || avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_HOST_PIN, G.opt_host_pin) ||
         (G.opt_cu_split && avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_CU_SPLIT, G.opt_cu_split)) ||
+        (G.opt_group_serial && avdsp_hip_prog_set_option(G.dev, AVDSP_OPT_GROUP_FANOUT, 0)) ||
         (G.ninst > 1 && avdsp_hip_set_instances(G.dev, G.ninst))) {
         hip_fail(); drop_device(); return g_err_code;
     }

@@ -341,7 +341,9 @@ __device__ __forceinline__ void emit_out(const BlockIO &io, const avdsp_chain &c
  *           (SAT0DB/STORE) and store them together.
  * ---------------------------------------------------------------------------------------- */
 /* what biquad_row needs of a chain and of a section, one record per row slot / per lane of a launch group; made with the plan */
-struct RowRec { int cid, in_io, out_io, flags; unsigned gain_bits; int pad[3]; };      /* flags: load_mode | sat << 8 | to_ring << 9 | n_out << 16 */
+struct RowRec { int cid, in_io, out_io, flags; unsigned gain_bits; int pad[3]; };      /* flags: load_mode | sat << 8 | to_ring << 9 | n_out << 16; pad[0]: the row's section count
+                                                                                            (a launch with BiquadArgs::nsec 0 holds rows of several counts, four-row waves of one
+                                                                                            count each; cid -1: a row that only fills its wave) */
 struct LaneRec { int coef_word, state_word; };                                          /* -1: the lane holds no section */
 
 struct BiquadArgs {
@@ -839,10 +841,13 @@ __global__ __launch_bounds__(kBlock) void biquad_row(const BiquadArgs a)
     const int slot = blk * 16 + wv * 4 + row;
     const Ring ring_l = a.ring;
     const BlockIO io_l = a.io;
-    const int B = io_l.nframes, L = a.nsec - 1;
-    const bool have_chain = slot < a.ngroup;
+    const int B = io_l.nframes;
     /* one load level to the records, a second to coefficients, state and the first samples (biquad_pipe: four) */
-    const RowRec rr = a.rows[have_chain ? slot : 0];
+    const RowRec rr = a.rows[slot < a.ngroup ? slot : 0];
+    /* the cascade's length: the launch's, or (round 5, a launch of rows of SEVERAL lengths: one launch for all cascades of a plan up to 16
+     * sections instead of one per length) the wave's -- its four rows have one length, the table is filled up with empty rows */
+    const int L = (a.nsec ? a.nsec : __builtin_amdgcn_readfirstlane(rr.pad[0])) - 1;
+    const bool have_chain = slot < a.ngroup && rr.cid >= 0;
     const LaneRec lr = a.lanes[(size_t)(have_chain ? slot : 0) * 16 + rp];
     const int sec = rp - (15 - L);                      /* this lane's section (negative: none) */
     const bool lane_on = have_chain && sec >= 0;
@@ -1182,9 +1187,10 @@ __global__ __launch_bounds__(kBlock) void biquad_row_i64(const BiquadArgs a)
     const int blk = xcd_remap(blockIdx.x, a.per_xcd);
     const int slot = blk * 16 + wv * 4 + row;
     const BlockIO io_l = a.io;
-    const int B = io_l.nframes, L = a.nsec - 1;
-    const bool have_chain = slot < a.ngroup;
-    const RowRec rr = a.rows[have_chain ? slot : 0];
+    const int B = io_l.nframes;
+    const RowRec rr = a.rows[slot < a.ngroup ? slot : 0];
+    const int L = (a.nsec ? a.nsec : __builtin_amdgcn_readfirstlane(rr.pad[0])) - 1;      /* (biquad_row: rows of several lengths in one launch) */
+    const bool have_chain = slot < a.ngroup && rr.cid >= 0;
     const LaneRec lr = a.lanes[(size_t)(have_chain ? slot : 0) * 16 + rp];
     const int sec = rp - (15 - L);
     const bool lane_on = have_chain && sec >= 0;
@@ -3400,6 +3406,10 @@ struct Plan {
     /* launch groups (device arrays of chain ids) */
     struct Group { int P; int nsec; int n; int *d_ids; bool all_fir;        /* all_fir: every chain of the group feeds a FIR (its cascade writes the ring) */
                    RowRec *d_rows; LaneRec *d_lanes; };                     /* biquad_row's records (P == 16) */
+    /* round 5: the rows of ALL the plan's 16-lane groups in one table -- runs of one section count, each filled up to whole waves (four
+     * rows) with empty rows, the table to whole workgroups -- for ONE biquad_row launch instead of one per section count (nsec 0 in its
+     * arguments: every wave takes its rows' count from their records).  Only made when there are two such groups or more. */
+    RowRec *d_rows_all = nullptr; LaneRec *d_lanes_all = nullptr; int n_rows_all = 0; bool rows_all_fir = true; int n_row_groups = 0;
     std::vector<Group> bq;            /* biquad chains grouped by section count (P = lanes per chain) */
     int *d_fir_ids = nullptr;  int n_fir = 0, max_taps = 0;
     int *d_pass_ids = nullptr; int n_pass = 0;
@@ -3496,6 +3506,10 @@ struct avdsp_hip_prog {
     std::vector<std::pair<hipStream_t, int>> probed;      /* ... per stream the FIRs were launched on */
     std::vector<hipStream_t> retired;                     /* cascades' streams that shared a hardware queue with a FIRs' stream (probe_side_by_side) */
     int remade = 0;                                       /* ... how many times the cascades' stream was made anew */
+    /* cascade launch groups of one plan side by side (round 5: launch_cascades) */
+    hipStream_t bq_side[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t bq_fork = nullptr, bq_join[3] = {nullptr, nullptr, nullptr};
+    int group_fanout = 1;               /* "group_fanout" 0: the groups one after the other on one stream, as through round 4 */
     int cu_split = 0;                                     /* "cu_split" (experiment, round 5): > 0: the cascades' stream runs on that many CUs (a CU mask: the first cu_split / 8 CUs of
                                                              every XCD), the FIRs on a stream of the library's own with the complementary mask */
     unsigned *d_ready_timeouts = nullptr;        /* [0] waves whose bounded wait for a ready word ran out (never, see chain_ready_wait); [2..3] the device address of h_ready_flag */
@@ -3557,6 +3571,7 @@ void free_plan(Plan &p)
 {
     (void)hipFree(p.d_chains); (void)hipFree(p.d_sec_coef); (void)hipFree(p.d_sec_state);
     for (auto &g : p.bq) { (void)hipFree(g.d_ids); (void)hipFree(g.d_rows); (void)hipFree(g.d_lanes); }
+    (void)hipFree(p.d_rows_all); (void)hipFree(p.d_lanes_all);
     (void)hipFree(p.d_sops); (void)hipFree(p.d_sargs); (void)hipFree(p.d_lseq); (void)hipFree(p.d_lane_rows);
     (void)hipFree(p.d_fir_ids); (void)hipFree(p.d_pass_ids); (void)hipFree(p.d_ring); (void)hipFree(p.d_ring64); (void)hipFree(p.d_own); (void)hipFree(p.d_taps64);
     (void)hipFree(p.d_ready);
@@ -4028,6 +4043,58 @@ static int overlap_ready(avdsp_hip_prog *prog)
     return 0;
 }
 
+/* The cascades of a plan: one launch per section count (a row of biquad_row, a lane group of biquad_pipe, has ONE length).  A program of
+ * equal chains -- every BASELINE config -- is one launch; a real crossover, two biquads on one way and six on another, is several, each a
+ * latency-bound recurrence of ~32 us whatever it holds: 1024 chains with 1 .. 8 sections took 248 us on one stream, eight launches in a row
+ * (tools/mixed_groups_bench.py).  The groups are independent chains: they go out over up to four streams (`st` and three of the library's
+ * own, as many as the runtime has hardware queues), forked from `st` by an event and joined back into it, so that whatever follows on
+ * `st` -- the block's FIR, the caller's next kernel -- is ordered behind all of them.  `last_stop`: an event the caller wants on the
+ * cascades' completion (the overlap mode's ev_bq): recorded behind the join. */
+template <int FMT>
+int launch_cascades(avdsp_hip_prog *prog, Plan &pl, BlockIO io, int biquad_impl, hipStream_t st, hipEvent_t last_stop, bool with_ready)
+{
+    /* (i) every cascade of up to 16 sections in ONE biquad_row launch, whatever their lengths (the table of all rows, Plan::d_rows_all):
+     * 1024 chains with 1 .. 8 sections 248 -> 33 us.  (ii) what that does not cover -- 17 sections and more, or the options that take
+     * biquad_row out -- as before, one launch per length, side by side over the streams. */
+    const bool merged = prog->group_fanout && biquad_impl == 1 && pl.d_rows_all && (FMT == 2 || FMT == 6 || (FMT == 4 && pl.rows_all_fir));
+    std::vector<const Plan::Group *> todo;
+    for (auto &g : pl.bq) if (!(merged && g.P == 16 && g.d_rows)) todo.push_back(&g);
+    if (merged) {
+        const Plan::Group m{16, 0, pl.n_rows_all, nullptr, pl.rows_all_fir, pl.d_rows_all, pl.d_lanes_all};
+        if (launch_biquad<FMT>(prog, pl, m, nullptr, m.n, io, biquad_impl, st, todo.empty() ? last_stop : nullptr, with_ready)) return -1;
+        if (todo.empty()) return 0;
+    }
+    const size_t ng = todo.size();
+    if (ng < 2 || !prog->group_fanout) {
+        for (size_t gi = 0; gi < ng; gi++) {                  /* (the last group's kernel carries the event: the stream is in order) */
+            auto &g = *todo[gi];
+            if (launch_biquad<FMT>(prog, pl, g, g.d_ids, g.n, io, biquad_impl, st, gi + 1 == ng ? last_stop : nullptr, with_ready)) return -1;
+        }
+        return 0;
+    }
+    if (!prog->bq_fork) {
+        HIP_TRY(hipEventCreateWithFlags(&prog->bq_fork, hipEventDisableTiming | hipEventDisableSystemFence));
+        for (int i = 0; i < 3; i++) {
+            HIP_TRY(hipStreamCreateWithFlags(&prog->bq_side[i], hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&prog->bq_join[i], hipEventDisableTiming | hipEventDisableSystemFence));
+        }
+    }
+    const int lanes = (int)std::min<size_t>(ng, 4);          /* streams in use: st + lanes - 1 sides */
+    HIP_TRY(hipEventRecord(prog->bq_fork, st));
+    for (int k = 1; k < lanes; k++) HIP_TRY(hipStreamWaitEvent(prog->bq_side[k - 1], prog->bq_fork, 0));
+    for (size_t gi = 0; gi < ng; gi++) {
+        auto &g = *todo[gi];
+        const int k = (int)(gi % (size_t)lanes);
+        if (launch_biquad<FMT>(prog, pl, g, g.d_ids, g.n, io, biquad_impl, k ? prog->bq_side[k - 1] : st, nullptr, with_ready)) return -1;
+    }
+    for (int k = 1; k < lanes; k++) {
+        HIP_TRY(hipEventRecord(prog->bq_join[k - 1], prog->bq_side[k - 1]));
+        HIP_TRY(hipStreamWaitEvent(st, prog->bq_join[k - 1], 0));
+    }
+    if (last_stop) HIP_TRY(hipEventRecord(last_stop, st));
+    return 0;
+}
+
 template <int FMT>
 int launch_all(avdsp_hip_prog *prog, Plan &pl, BlockIO io, int fir_impl, int biquad_impl, hipStream_t stream)
 {
@@ -4073,10 +4140,7 @@ int launch_all(avdsp_hip_prog *prog, Plan &pl, BlockIO io, int fir_impl, int biq
             if (!done) HIP_TRY(hipStreamWaitEvent(prog->s_bq, prog->ev_fir_now[slot], 0));
         }
         if (prog->input_ready) HIP_TRY(hipStreamWaitEvent(prog->s_bq, prog->input_ready, 0));           /* (queued host blocks: the copy of this block) */
-        for (size_t gi = 0; gi < pl.bq.size(); gi++) {        /* (the last group's kernel carries the event: the stream is in order) */
-            auto &g = pl.bq[gi];
-            if (launch_biquad<FMT>(prog, pl, g, g.d_ids, g.n, io, biquad_impl, prog->s_bq, !words && gi + 1 == pl.bq.size() ? prog->ev_bq[slot] : nullptr, wt)) return -1;
-        }
+        if (launch_cascades<FMT>(prog, pl, io, biquad_impl, prog->s_bq, !words ? prog->ev_bq[slot] : nullptr, wt)) return -1;
         if (behind && prog->ready_test > 0) prog->ready_test--;       /* (tests: this launch's words are never set) */
         else if (behind) {
             hipLaunchKernelGGL(ready_set, dim3((unsigned)((pl.n_fir + kBlock - 1) / kBlock)), dim3(kBlock), 0, prog->s_bq, pl.d_ready, pl.d_fir_ids, pl.n_fir, pl.seq);
@@ -4122,8 +4186,7 @@ int launch_all(avdsp_hip_prog *prog, Plan &pl, BlockIO io, int fir_impl, int biq
         prog->ev_fir_set[slot] = true;
         prog->blk++;
     } else {
-        for (auto &g : pl.bq)
-            if (launch_biquad<FMT>(prog, pl, g, g.d_ids, g.n, io, biquad_impl, stream)) return -1;
+        if (launch_cascades<FMT>(prog, pl, io, biquad_impl, stream, nullptr, false)) return -1;
         if (pl.n_fir && launch_fir<FMT>(prog, pl, pl.d_fir_ids, pl.n_fir, io, fir_impl, stream)) return -1;
     }
     if (pl.n_pass) {
@@ -4210,6 +4273,9 @@ void avdsp_hip_prog_destroy(avdsp_hip_prog *p)
     }
     if (p->s_bq) (void)hipStreamDestroy(p->s_bq);
     for (auto st : p->retired) (void)hipStreamDestroy(st);
+    for (auto st : p->bq_side) if (st) (void)hipStreamDestroy(st);
+    for (auto e : p->bq_join) if (e) (void)hipEventDestroy(e);
+    if (p->bq_fork) (void)hipEventDestroy(p->bq_fork);
     for (auto fs : p->s_fir) if (fs) (void)hipStreamDestroy(fs);
     if (p->ev_unpack) (void)hipEventDestroy(p->ev_unpack);
     for (int i = 0; i < avdsp_hip_prog::kAhead; i++) { if (p->ev_bq[i]) (void)hipEventDestroy(p->ev_bq[i]); if (p->ev_fir[i]) (void)hipEventDestroy(p->ev_fir[i]); }
@@ -4274,6 +4340,7 @@ int avdsp_hip_prog_add_plan(avdsp_hip_prog *prog, const avdsp_plan_desc *d)
         prog->plans.push_back(pl);
         return (int)prog->plans.size() - 1;
     }
+    std::vector<RowRec> all_rows; std::vector<LaneRec> all_lanes;
     for (auto &e : byN) {                                /* > 64 sections (P = 128): biquad_simple */
         /* lanes per chain: the next power of two -- but a 16-lane row per chain while the chip has SIMDs to spare
          * (<= 1024 waves): its step is shorter (one input batch per 16 steps, no mid-row section-0 lanes: cfg5's
@@ -4290,12 +4357,27 @@ int avdsp_hip_prog_add_plan(avdsp_hip_prog *prog, const avdsp_plan_desc *d)
             for (size_t i = 0; i < e.second.size(); i++) {
                 const avdsp_chain &c = chains[e.second[i]];
                 rows[i] = RowRec{e.second[i], c.in_io, c.out_io[0], (c.load_mode & 0xFF) | (c.sat ? 1 << 8 : 0) | (c.fir_taps ? 1 << 9 : 0) | (c.n_out << 16),
-                                 c.gain_bits, {0, 0, 0}};
+                                 c.gain_bits, {c.nsec, 0, 0}};
                 for (int k = 0; k < c.nsec; k++) lanes[i * 16 + (16 - c.nsec) + k] = LaneRec{coef[c.sec_base + k], state[c.sec_base + k]};
             }
             if (upload_vec(&g.d_rows, rows) || upload_vec(&g.d_lanes, lanes)) { (void)hipFree(g.d_ids); (void)hipFree(g.d_rows); free_plan(pl); return -1; }
+            /* ... and the same rows in the table of all lengths: this run, filled up to whole waves */
+            all_rows.insert(all_rows.end(), rows.begin(), rows.end());
+            all_lanes.insert(all_lanes.end(), lanes.begin(), lanes.end());
+            /* (an empty row is a copy of a real one with no chain behind it: every lane of a wave FETCHES, section or not -- its input
+             * column must be one the block has; nothing of it is stored) */
+            RowRec empty = rows[0]; empty.cid = -1;
+            while (all_rows.size() % 4) { all_rows.push_back(empty); all_lanes.insert(all_lanes.end(), 16, LaneRec{-1, -1}); }
+            pl.n_row_groups++;
+            pl.rows_all_fir = pl.rows_all_fir && all_fir;
         }
         pl.bq.push_back(g);
+    }
+    if (pl.n_row_groups >= 2) {
+        RowRec empty = all_rows.back(); empty.cid = -1;
+        while (all_rows.size() % 16) { all_rows.push_back(empty); all_lanes.insert(all_lanes.end(), 16, LaneRec{-1, -1}); }
+        pl.n_rows_all = (int)all_rows.size();
+        if (upload_vec(&pl.d_rows_all, all_rows) || upload_vec(&pl.d_lanes_all, all_lanes)) { free_plan(pl); return -1; }
     }
     pl.n_fir = (int)fir.size(); pl.n_pass = (int)pass.size();
     if (upload_vec(&pl.d_fir_ids, fir) || upload_vec(&pl.d_pass_ids, pass)) { free_plan(pl); return -1; }
@@ -5663,6 +5745,7 @@ int avdsp_hip_prog_set_option(avdsp_hip_prog *prog, int key, int value)
     case AVDSP_OPT_FIR_LEAN: if (value < -1 || value > 1) return set_err("fir_lean: -1 (auto), 0 or 1"); prog->fir_lean = value; return 0;
     case AVDSP_OPT_RING_WAIT: prog->ring_wait_host = value != 0; return 0;
     case AVDSP_OPT_READY_TEST: prog->ready_test = value > 0 ? value : 0; return 0;
+    case AVDSP_OPT_GROUP_FANOUT: prog->group_fanout = value != 0; return 0;
     case AVDSP_OPT_CU_SPLIT:
         if (value < -128 || value > 128 || (value & 7)) return set_err("cu_split: 0 (off) or 8, 16, ... 128 CUs for the cascades' stream (negative: the FIRs stay on the caller's stream, unmasked)");
         if (value != prog->cu_split) {                   /* the side streams are made anew with their masks at the next overlapped launch */

@@ -225,6 +225,7 @@ int avdsp_hip_plan_strands(const avdsp_hip_prog *prog, int plan);      /* strand
 enum { AVDSP_OPT_OVERLAP = 0, AVDSP_OPT_PROFILE_STRIDE = 1, AVDSP_OPT_FIR_ROWS = 3, AVDSP_OPT_HOST_SPLIT = 4, AVDSP_OPT_HOST_PIN = 5,
        AVDSP_OPT_READY_WORDS = 6, AVDSP_OPT_LANE_HW = 7, AVDSP_OPT_FIR_SPLIT = 8, AVDSP_OPT_FIR_LAUNCH = 9, AVDSP_OPT_FIR_LEAN = 10, AVDSP_OPT_RING_WAIT = 11,
        AVDSP_OPT_SIDE_BY_SIDE = 13, /* read-only: 1 kernels of two queues were seen to run at once (the precondition of ready words), 0 not (dispatches are serialised: a PMC profiler, a debugger), -1 not probed yet */
+       AVDSP_OPT_GROUP_FANOUT = 17, /* 1 (default): a plan's cascade launches -- one per section count -- go out over up to four streams side by side; 0: one after the other */
        AVDSP_OPT_CU_SPLIT = 16,     /* experiment: the overlap mode's cascades on that many CUs of their own (CU-masked stream), the FIRs on the others */
        AVDSP_OPT_STREAMS_REMADE = 15, /* read-only: how many times the cascades' stream was made anew because it shared a hardware queue with the FIRs' */
        AVDSP_OPT_READY_MODE = 14,   /* read-only: how the latest overlapped launch's FIR found its cascades' block: 0 event, 1 / 2 ready words */

@@ -234,6 +234,8 @@ int dspRuntimeStrandInfo(int format, opcode_t *core, int *strands, int *ops_per_
  * "cu_split" k (experiment; 0 = off): under "overlap" the cascades' stream on k CUs of its own (8, 16, 32 ...; a CU mask),
  * the FIRs on a stream of the library's with the complementary mask (negative k: only the cascades masked); hand over a non-blocking
  * stream of your own with it -- CU-masked streams are blocking streams, beside the null stream every launch on them synchronises.
+ * "group_fanout" 1 (default) = a chain core's cascades of up to 16 sections run as ONE launch whatever their lengths, longer ones side by
+ * side over up to four streams; 0 = one launch per section count, one after the other (as through round 4; results identical).
  * A program's options are also the defaults of programs loaded later.                                */
 int dspRuntimeSetOption(const char *key, int value);
 int dspRuntimeGetOption(const char *key);

@@ -606,3 +606,45 @@ def test_signed_zeros_in_the_state_across_one_frame_blocks(fmt, sections):
         assert (r.sync_state() == o.state).all(), f"state after the block at frame {pos} ({b} frames)"
         pos += b
     r.release()
+
+
+@pytest.mark.parametrize("fmt", [2, 4, 6])
+@pytest.mark.parametrize("fanout", [1, 0])
+def test_cascades_of_many_lengths_in_one_launch(fmt, fanout):
+    """A core whose chains have DIFFERENT section counts -- a real crossover -- used to be one cascade launch per count, one after the
+    other (1024 chains with 1 .. 8 sections: 248 us per block).  Round 5: all cascades of up to 16 sections are ONE biquad_row launch
+    (a table of rows of every length, four-row waves of one length each), longer ones go out side by side over streams.  Here: 37 chains
+    with 1 .. 16, 17, 20 and 40 sections (the last three: biquad_pipe groups beside the merged launch), ragged blocks, against the oracle --
+    and the same with "group_fanout" 0 (one launch per length, as before)."""
+    from avdsp_amd import encoder as enc
+    import ctypes as C
+    counts = [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 20, 40, 3, 3, 8, 8, 8, 16, 16, 1, 2, 12, 12, 12, 12, 12, 5, 6, 7, 9]
+    n = len(counts)
+
+    def build(L):
+        banks = []
+        for c in range(n):
+            L.dsp_PARAM()
+            banks.append(L.dspBiquad_Sections(counts[c]))
+            for b in range(counts[c]):
+                L.dsp_Filter2ndOrder(9, C.c_double(100.0 + 37 * b + 3 * c), C.c_double(0.7 + 0.05 * (b % 5)), C.c_float(1.2 if b & 1 else 0.8))
+        L.dsp_CORE()
+        for c in range(n):
+            L.dsp_LOAD_GAIN_Fixed(n + c, C.c_float(0.5)); L.dsp_BIQUADS(banks[c]); L.dsp_SAT0DB(); L.dsp_STORE(c)
+    prog = enc.encode(build, 2 if fmt == 2 else 6, pb.F48000, pb.F48000, max_io=2 * n + 8, capacity=1 << 20)
+    x = pb.lcg_input(2300, n, fmt == 6, seed=fmt)
+    o = po.OracleProgram(fmt, prog)
+    r = rt.Runtime(fmt, prog)
+    r.set_option("group_fanout", fanout)
+    assert r.core_info(0)["chains"] == n
+    try:
+        pos = 0
+        for b in (1024, 37, 700, 1, 538):
+            want, got = o.run_block(x[pos:pos + b], n, n), r.run_block(x[pos:pos + b], n, n)
+            bad = np.nonzero((got.view(np.uint32) != want.view(np.uint32)).any(axis=0))[0]
+            assert bad.size == 0, f"block at {pos}: chains {bad.tolist()} (sections {[counts[i] for i in bad]}) differ"
+            pos += b
+        assert (r.sync_state() == o.state).all()
+    finally:
+        r.set_option("group_fanout", 1)
+        r.release()
