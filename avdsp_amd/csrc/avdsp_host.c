@@ -103,6 +103,7 @@ typedef struct avdsp_ctx {
     int             device_ordinal;                        /* the GPU its device copy lives on (-1: none yet) */
     int             ninst;                                 /* dspRuntimeSetInstances */
     int             inst_saved_lanes;                      /* 1 + the "strand_lanes" the program had before it got instances (0: nothing saved) */
+    int             inst_saved_generic;                    /* 1 + the "generic" a program of BOTH kinds of cores had before its instances put every core on the interpreter */
     int             inst_call;                             /* inside dspRuntimeBlockAllInstancesDevice: block_all hands these strides on */
     size_t          inst_in_words, inst_out_words;
     int             opt_cu_split;                          /* experiment: "cu_split" */
@@ -2249,7 +2250,8 @@ int dspRuntimeBlockAllDevice(int format, int *rundata, const void *d_in, int in_
  * from a copy of the program's device state (parameters, data area, dither generator, samples[] frame) as it is at the first
  * dspRuntimeBlockAllInstancesDevice call after dspRuntimeSetInstances, and keeps its own from then on; dspRuntimeReset /
  * dspRuntimeUploadState / ...UploadParams afterwards reach instance 0 only -- set the instances again to hand them on.
- * Every core must run on the frame-parallel interpreter (the reference's programs do); a block is 2 .. 65536 frames. */
+ * Cores for the frame-parallel interpreter (the reference's programs): the instances are copies of its state; chain cores only: the
+ * instances are further chains of the chain kernels' launches; both in one program: every core on the interpreter. */
 int dspRuntimeSetInstances(int n)
 {
     if (!dspHeaderPtr || !G.code) return fail(-1, "no program loaded");
@@ -2266,6 +2268,11 @@ int dspRuntimeSetInstances(int n)
     /* The strand plans know nothing of instances: while a program HAS instances its interpreted cores run as the interpreter's pieces
      * ("strand_lanes" 0, the plans rebuilt once, here -- not silently inside a block call), and dspRuntimeSetInstances(0) gives the
      * program back the arrangement it had. */
+    if (n == 0 && G.inst_saved_generic) {                /* (a program of both kinds gets its chain plans back) */
+        const int back = G.inst_saved_generic - 1;
+        G.inst_saved_generic = 0;
+        if (set_option_here("generic", back)) return g_err_code;
+    }
     if (n >= 1 && G.opt_strand_lanes != 0) {
         G.inst_saved_lanes = 1 + G.opt_strand_lanes;
         return set_option_here("strand_lanes", 0);
@@ -2301,8 +2308,14 @@ int dspRuntimeBlockAllInstancesDevice(int format, int *rundata, const void *d_in
             if (rc == 0) nchain++; else if (rc == -8) nother++; else return g_err_code;
             if (c == G.code) break;
         }
-        if (nchain && nother) return fail(-8, "instances: %d of the program's cores are chain cores and %d are not; all of one kind, please", nchain, nother);
-        G.inst_chain_mode = nchain ? 2 : 1;
+        if (nchain && nother) {
+            /* both kinds: the instances' state must live in ONE place, and the interpreter runs chain cores too -- every core on it for as
+             * long as the program has instances ("generic" 1: the chain plans go, their FIR histories home into the mirror first;
+             * dspRuntimeSetInstances(0) gives the program its arrangement back) */
+            G.inst_saved_generic = 1 + G.opt_generic;
+            if (set_option_here("generic", 1)) return g_err_code;
+        }
+        G.inst_chain_mode = nchain && !nother ? 2 : 1;
     }
     if (G.inst_chain_mode == 2) {
         if (check_rundata(rundata)) return -1;

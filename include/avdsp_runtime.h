@@ -140,12 +140,13 @@ int dspRuntimeBlockDevice(int format, opcode_t *core, int *rundata,
  * core per process -- a host with many independent streams of the same program (a thousand stereo crossovers) loads it once.
  * Instance i: sample blocks at d_in + i * in_inst_words and d_out + i * out_inst_words (32-bit words), state of its own, copied
  * from the program's at the first block call after dspRuntimeSetInstances.  dspRuntimeInstanceState(i, dst) brings back instance
- * i's data area (dataSize words).  The program's cores must be of one kind: all for the frame-parallel interpreter (the reference's own
- * programs: an instance is a further copy of the device state, round 4), or all CHAIN cores (round 5: an instance is a further block of
+ * i's data area (dataSize words).  Cores for the frame-parallel interpreter (the reference's own
+ * programs): an instance is a further copy of the device state (round 4); a program of CHAIN cores only (round 5): an instance is a further block of
  * chains in the chain kernels' launches -- 8 channels x 8 biquads in 512 instances are the 4096 rows of one cascade launch, 78 Gsamples/s
  * at 256-frame blocks -- with state, FIR history and parameters of its own in a copy of the mirror).  While a chain program runs as
  * instances the ordinary block calls on it are refused; dspRuntimeSetInstances(0) ends it (the single program continues from instance
- * 0's state, "strand_lanes" is what it was).  A program with cores of both kinds is refused (-8). */
+ * 0's state, "strand_lanes" is what it was).  A program with cores of both kinds runs every core on the interpreter while it has
+ * instances ("generic" reads 1 meanwhile; dspRuntimeSetInstances(0) gives it its chain plans back). */
 int dspRuntimeSetInstances(int n);
 int dspRuntimeBlockAllInstancesDevice(int format, int *rundata, const void *d_in, int in_stride, int in_io_base, size_t in_inst_words,
                                       void *d_out, int out_stride, int out_io_base, size_t out_inst_words, int nframes, void *stream);

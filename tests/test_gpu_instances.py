@@ -221,24 +221,51 @@ def test_chain_instances_under_the_overlap_mode():
     r.release()
 
 
-def test_instances_refuse_a_program_of_both_kinds():
-    """a program with a chain core AND a core for the interpreter: its instances would keep their state in two places -- refused loudly"""
+@pytest.mark.parametrize("fmt", [2, 4, 6])
+def test_instances_of_a_program_of_both_kinds(fmt):
+    """a program with a CHAIN core (gain -> 5 biquads [-> 40-tap FIR] -> SAT0DB -> store, two channels) and a core for the interpreter (X/Y
+    moves): until round 5 refused -- its instances would keep their state in two places.  Now every core runs on the interpreter while
+    the program has instances; each instance the oracle's bits and data area; dspRuntimeSetInstances(0) gives the single program its
+    chain plans back and it continues from instance 0's state."""
     import torch
-    from avdsp_amd import encoder as enc
-
-    def build(L):
-        L.dsp_CORE()
-        L.dsp_LOAD(4); L.dsp_STORE(0)                                  # a chain core
-        L.dsp_CORE()
-        L.dsp_LOAD(5); L.dsp_COPYXY(); L.dsp_ADDXY(); L.dsp_STORE(1)   # X/Y arithmetic: the interpreter's
-    prog = enc.encode(build, 6, pb.F48000, pb.F48000)
-    r = rt.Runtime(6, prog)
-    r.set_instances(3)
-    x = torch.zeros((3, 64, 8), dtype=torch.float32, device="cuda")
-    y = torch.zeros((3, 64, 8), dtype=torch.float32, device="cuda")
-    with pytest.raises(rt.AvdspError) as e:
-        r.run_block_all_instances_device(x.data_ptr(), 8, 0, 64 * 8, y.data_ptr(), 8, 0, 64 * 8, 64, 0)
-    assert "all of one kind" in str(e.value)
+    C, S, T = 2, 5, 40 if fmt != 2 else 0
+    w = pb.ProgramWriter(fmt, pb.F48000, pb.F48000)
+    w.core()
+    for c in range(C):
+        w.param()
+        bank = w.biquad_bank(pb.synth_sections(c, S, pb.F48000, pb.F48000))
+        imp = w.fir_impulses([pb.lcg_taps(c, T)]) if T else None
+        w.load_gain_fixed(4 + c, 0.5); w.biquads(bank, S)
+        if T:
+            w.fir(imp, T)
+        w.sat0db(); w.store(c)
+    w.core()
+    w.load(6); w.copyxy(); w.load(7); w.swapxy(); w.store(2); w.swapxy(); w.store(3)
+    prog = w.end_of_code()
+    ninst, blocks = 9, [64, 300, 2, 129]
+    frames = sum(blocks)
+    xs = np.stack([pb.lcg_input(frames, 4, fmt == 6, seed=70 + i) for i in range(ninst)])
+    xs[4] = xs[5]
+    got, r = _run_instances(fmt, prog, xs, 4, 4, 4, blocks)
+    for i in range(ninst):
+        o = po.OracleProgram(fmt, prog, fs=48000, random=3, dither=24)
+        frame = np.zeros(4096, dtype=np.uint32)
+        pos = 0
+        for b in blocks:
+            want = o.run_block(xs[i, pos:pos + b], 4, 4, 0, block=b, frame=frame)
+            assert (got[i, pos:pos + b].view(np.uint32) == want.view(np.uint32)).all(), f"instance {i}, block at {pos}"
+            pos += b
+        assert (r.instance_state(i) == o.state).all(), f"instance {i}: data area"
+        if i == 0:
+            o0, frame0 = o, frame
+    assert (got[4] == got[5]).all() and got.any()
+    assert r.get_option("generic") == 1
+    r.set_instances(0)                                               # the single program again, on its chain plan + the interpreter
+    assert r.get_option("generic") == 0
+    more = pb.lcg_input(200, 4, fmt == 6, seed=5)
+    want = o0.run_block(more, 4, 4, 0, block=200, frame=frame0)
+    assert (r.run_block_all(more, 4, 4).view(np.uint32) == want.view(np.uint32)).all()
+    assert (r.sync_state() == o0.state).all()
     r.release()
 
 
