@@ -397,6 +397,18 @@ __device__ __forceinline__ Hand<FMT> hand_from_sample(unsigned raw, int load_mod
     h.y = narrow_stage<FMT>(load_stage<FMT>(raw, load_mode, gain_bits));
     return h;
 }
+/* Pieces of a long cascade (round 5; more than 64 sections: add_plan cuts the chain into pieces of up to 64 that run one launch after the
+ * other).  What travels between two sections is a 32-bit word -- (int)(acc >> 28), or the bits of (float)acc -- and between two PIECES the
+ * same word goes through a scratch column: kLoadRaw takes a sample word as the first section's input as it is, kStoreRaw (in the chain
+ * record's `sat`) stores the last section's result word as it is.  Device-side only; the host's descriptors never hold them. */
+constexpr int kLoadRaw = 2, kStoreRaw = 2;
+template <int FMT>
+__device__ __forceinline__ Hand<FMT> hand_from_sample_or_raw(unsigned raw, int load_mode, unsigned gain_bits)
+{
+    Hand<FMT> h = hand_from_sample<FMT>(raw, load_mode, gain_bits);
+    if (load_mode == kLoadRaw) h.y = raw;
+    return h;
+}
 
 template <int FMT, int CTRL>
 __device__ __forceinline__ Hand<FMT> hand_rotate(Hand<FMT> h)
@@ -407,7 +419,7 @@ __device__ __forceinline__ Hand<FMT> hand_rotate(Hand<FMT> h)
 
 /* One chain's cascade over the block in the reference's own order -- frames outer, sections inner, state in memory
  * (dsp_biquadSTD.h:37-74, 87-117), every product through mulop(), i.e. with the bit-field reading of exponent 255.
- * Slow and obviously sequential: biquad_simple runs it for every chain (cross-check path, cascades longer than 64
+ * Slow and obviously sequential: biquad_simple runs it for every chain (cross-check path; until round 5 cascades longer than 64
  * sections), biquad_pipe for a chain whose block turned up an Inf or NaN.                                        */
 template <int FMT>
 __device__ void cascade_in_reference_order(const BiquadArgs &a, int cid, const avdsp_chain &c)
@@ -415,8 +427,9 @@ __device__ void cascade_in_reference_order(const BiquadArgs &a, int cid, const a
     using alu_t = typename Alu<FMT>::type;
     const unsigned *inp = a.io.in + (c.in_io - a.io.in_base);
     for (int n = 0; n < a.io.nframes; n++) {
-        alu_t X = load_stage<FMT>(inp[(size_t)n * a.io.in_stride], c.load_mode, c.gain_bits);
-        unsigned xin = narrow_stage<FMT>(X);
+        const unsigned raw_in = inp[(size_t)n * a.io.in_stride];
+        alu_t X = load_stage<FMT>(raw_in, c.load_mode, c.gain_bits);
+        unsigned xin = c.load_mode == kLoadRaw ? raw_in : narrow_stage<FMT>(X);
         for (int s = 0; s < c.nsec; s++) {
             const int *co = a.buf + a.sec_coef[c.sec_base + s];
             int *st = a.buf + a.sec_state[c.sec_base + s];
@@ -452,6 +465,7 @@ __device__ void cascade_in_reference_order(const BiquadArgs &a, int cid, const a
             xin = yn;
         }
         if (c.fir_taps) ring_put(a.ring, cid, n, narrow_stage<FMT>(X), a.ready != nullptr);
+        else if (c.sat == kStoreRaw) emit_out(a.io, c, n, xin);      /* (a piece of a long cascade: the last section's result word) */
         else emit_out(a.io, c, n, store_stage<FMT>(X, c.sat, a.io.store_mask));
     }
 }
@@ -474,7 +488,9 @@ __global__ __launch_bounds__(kBlock) void biquad_pipe(const BiquadArgs a)
     const BlockIO io_l = a.io;
     const int nsec = a.nsec, B = io_l.nframes;
     const bool have_chain = slot < a.ngroup;
-    const int cid = have_chain ? a.group[slot] : 0;
+    /* (lanes without a chain fetch like the others -- see below -- so they take the launch's FIRST chain, whose input column the launch's
+     * block has: chain 0 of the plan may be a piece of a long cascade with a column in another launch's scratch block) */
+    const int cid = a.group[have_chain ? slot : 0];
     const avdsp_chain c = a.chains[cid];
     const bool lane_on = have_chain && s < nsec;
     const bool first = s == 0;
@@ -494,7 +510,7 @@ __global__ __launch_bounds__(kBlock) void biquad_pipe(const BiquadArgs a)
         oslot = blk * CPB + (tid >> 4) * (16 / P) + (((src - (nsec - 1)) & 15) / P);
     }
     owner = owner && oslot < a.ngroup;
-    const int ocid = owner ? a.group[oslot] : 0;
+    const int ocid = a.group[owner ? oslot : 0];
     const avdsp_chain oc = a.chains[ocid];
     const int ostep = NB - 1 - d;                       /* step of the batch whose result this lane stores */
     [[maybe_unused]] const unsigned long long lastmask = __ballot(last);   /* lanes whose results leave the cascade */
@@ -620,7 +636,7 @@ __global__ __launch_bounds__(kBlock) void biquad_pipe(const BiquadArgs a)
      * load at every batch -- the prefetch distance was one batch, not three, and a third of the kernel's time was
      * s_waitcnt (profiles/r01_cfg3: SQ_WAIT_ANY 33 %). */
     const int c_load_mode = c.load_mode; const unsigned c_gain_bits = c.gain_bits;      /* (scalars: the chain record itself stays out of the lambdas) */
-    Hand<FMT> ib = hand_from_sample<FMT>(rawq[0], c_load_mode, c_gain_bits);
+    Hand<FMT> ib = hand_from_sample_or_raw<FMT>(rawq[0], c_load_mode, c_gain_bits);
     rawq[0] = fetch(DEPTH);
     BQ_STAMP(1);
     /* the NB steps of a batch in which every lane is busy */
@@ -674,11 +690,11 @@ __global__ __launch_bounds__(kBlock) void biquad_pipe(const BiquadArgs a)
     auto flush_word = [&](bool to_ring) __attribute__((always_inline)) -> unsigned {
         if constexpr (FMT == 4) {
             const double X = __longlong_as_double((long long)(((unsigned long long)ob_hi << 32) | ob_lo));
-            return to_ring ? narrow_stage<FMT>(X) : store_stage<FMT>(X, oc.sat, io_l.store_mask);
+            return to_ring || oc.sat == kStoreRaw ? narrow_stage<FMT>(X) : store_stage<FMT>(X, oc.sat, io_l.store_mask);
         } else if constexpr (FMT == 6) {
-            return to_ring ? ob_lo : (oc.sat ? __float_as_uint(saturate_f32_0db(__uint_as_float(ob_lo))) : ob_lo);
+            return to_ring ? ob_lo : (oc.sat == 1 ? __float_as_uint(saturate_f32_0db(__uint_as_float(ob_lo))) : ob_lo);
         } else
-            return ob_lo & (unsigned)io_l.store_mask;
+            return oc.sat == kStoreRaw ? ob_lo : ob_lo & (unsigned)io_l.store_mask;      /* (kStoreRaw: ob_lo is y1, like behind SAT0DB) */
     };
     constexpr int kNext[3] = {1 % DEPTH, 2 % DEPTH, 0};
     /* a batch anywhere in the block: steps masked where the pipeline fills or drains, fetch clamped into the block, flush checked */
@@ -691,7 +707,7 @@ __global__ __launch_bounds__(kBlock) void biquad_pipe(const BiquadArgs a)
             for (int i = 0; i < NB; i++) step(ib, tb + i, std::true_type{});
         }
         /* batch b+1's samples were requested DEPTH batches ago; its slot is then refilled for batch b+1+DEPTH */
-        ib = hand_from_sample<FMT>(rawq[kNext[j]], c_load_mode, c_gain_bits);
+        ib = hand_from_sample_or_raw<FMT>(rawq[kNext[j]], c_load_mode, c_gain_bits);
         rawq[kNext[j]] = fetch(b + 1 + DEPTH);
         /* flush the output batch: this lane holds the result of step tb + ostep of chain `ocid` */
         const int n = tb + ostep - 1 - 2 * (nsec - 1);
@@ -726,7 +742,7 @@ __global__ __launch_bounds__(kBlock) void biquad_pipe(const BiquadArgs a)
         auto batch_steady = [&](auto jc) __attribute__((always_inline)) {
             constexpr int j = decltype(jc)::value;
             fast_steps(0);
-            ib = hand_from_sample<FMT>(rawq[kNext[j]], c_load_mode, c_gain_bits);
+            ib = hand_from_sample_or_raw<FMT>(rawq[kNext[j]], c_load_mode, c_gain_bits);
             rawq[kNext[j]] = *in_run;
             in_run += in_step;
             if (owner) {
@@ -1472,7 +1488,7 @@ __global__ __launch_bounds__(kBlock) void biquad_row_i64(const BiquadArgs a)
     BQ_STAMP(29);
 }
 
-/* lane per chain, the reference's loop order: cross-check path, and cascades longer than 64 sections */
+/* lane per chain, the reference's loop order: the cross-check path ("biquad_impl" 0) */
 template <int FMT>
 __global__ __launch_bounds__(64) void biquad_simple(const BiquadArgs a)
 {
@@ -3405,7 +3421,11 @@ struct Plan {
     int *d_sec_coef = nullptr, *d_sec_state = nullptr;
     /* launch groups (device arrays of chain ids) */
     struct Group { int P; int nsec; int n; int *d_ids; bool all_fir;        /* all_fir: every chain of the group feeds a FIR (its cascade writes the ring) */
-                   RowRec *d_rows; LaneRec *d_lanes; };                     /* biquad_row's records (P == 16) */
+                   RowRec *d_rows; LaneRec *d_lanes;                        /* biquad_row's records (P == 16) */
+                   /* more than 64 sections (round 5): the group as pieces of up to 64, launched one after the other; piece k hands the
+                    * word between its last section and piece k + 1's first through column j (the chain's place in the group) of
+                    * d_scratch[k & 1], [1024 frames][n] words (kLoadRaw / kStoreRaw) */
+                   std::vector<Group> pieces = {}; unsigned *d_scratch[2] = {nullptr, nullptr}; };
     /* round 5: the rows of ALL the plan's 16-lane groups in one table -- runs of one section count, each filled up to whole waves (four
      * rows) with empty rows, the table to whole workgroups -- for ONE biquad_row launch instead of one per section count (nsec 0 in its
      * arguments: every wave takes its rows' count from their records).  Only made when there are two such groups or more. */
@@ -3570,7 +3590,10 @@ int upload_vec(T **dst, const std::vector<T> &v)
 void free_plan(Plan &p)
 {
     (void)hipFree(p.d_chains); (void)hipFree(p.d_sec_coef); (void)hipFree(p.d_sec_state);
-    for (auto &g : p.bq) { (void)hipFree(g.d_ids); (void)hipFree(g.d_rows); (void)hipFree(g.d_lanes); }
+    for (auto &g : p.bq) {
+        (void)hipFree(g.d_ids); (void)hipFree(g.d_rows); (void)hipFree(g.d_lanes); (void)hipFree(g.d_scratch[0]); (void)hipFree(g.d_scratch[1]);
+        for (auto &pc : g.pieces) (void)hipFree(pc.d_ids);
+    }
     (void)hipFree(p.d_rows_all); (void)hipFree(p.d_lanes_all);
     (void)hipFree(p.d_sops); (void)hipFree(p.d_sargs); (void)hipFree(p.d_lseq); (void)hipFree(p.d_lane_rows);
     (void)hipFree(p.d_fir_ids); (void)hipFree(p.d_pass_ids); (void)hipFree(p.d_ring); (void)hipFree(p.d_ring64); (void)hipFree(p.d_own); (void)hipFree(p.d_taps64);
@@ -4057,6 +4080,20 @@ int launch_cascades(avdsp_hip_prog *prog, Plan &pl, BlockIO io, int biquad_impl,
      * 1024 chains with 1 .. 8 sections 248 -> 33 us.  (ii) what that does not cover -- 17 sections and more, or the options that take
      * biquad_row out -- as before, one launch per length, side by side over the streams. */
     const bool merged = prog->group_fanout && biquad_impl == 1 && pl.d_rows_all && (FMT == 2 || FMT == 6 || (FMT == 4 && pl.rows_all_fir));
+    /* one group on one stream: a launch -- or, for cascades of more than 64 sections, the group's pieces one after the other, the words
+     * between them through the group's scratch columns */
+    auto launch_group = [&](const Plan::Group &g, hipStream_t s, hipEvent_t stop) -> int {
+        if (g.pieces.empty()) return launch_biquad<FMT>(prog, pl, g, g.d_ids, g.n, io, biquad_impl, s, stop, with_ready);
+        const size_t np = g.pieces.size();
+        for (size_t k = 0; k < np; k++) {
+            BlockIO pio = io;
+            if (k > 0)      { pio.in = g.d_scratch[(k - 1) & 1]; pio.in_stride = g.n; pio.in_base = 0; }
+            if (k + 1 < np) { pio.out = g.d_scratch[k & 1];      pio.out_stride = g.n; pio.out_base = 0; }
+            const auto &pc = g.pieces[k];
+            if (launch_biquad<FMT>(prog, pl, pc, pc.d_ids, pc.n, pio, biquad_impl, s, k + 1 == np ? stop : nullptr, k + 1 == np && with_ready)) return -1;
+        }
+        return 0;
+    };
     std::vector<const Plan::Group *> todo;
     for (auto &g : pl.bq) if (!(merged && g.P == 16 && g.d_rows)) todo.push_back(&g);
     if (merged) {
@@ -4068,7 +4105,7 @@ int launch_cascades(avdsp_hip_prog *prog, Plan &pl, BlockIO io, int biquad_impl,
     if (ng < 2 || !prog->group_fanout) {
         for (size_t gi = 0; gi < ng; gi++) {                  /* (the last group's kernel carries the event: the stream is in order) */
             auto &g = *todo[gi];
-            if (launch_biquad<FMT>(prog, pl, g, g.d_ids, g.n, io, biquad_impl, st, gi + 1 == ng ? last_stop : nullptr, with_ready)) return -1;
+            if (launch_group(g, st, gi + 1 == ng ? last_stop : nullptr)) return -1;
         }
         return 0;
     }
@@ -4085,7 +4122,7 @@ int launch_cascades(avdsp_hip_prog *prog, Plan &pl, BlockIO io, int biquad_impl,
     for (size_t gi = 0; gi < ng; gi++) {
         auto &g = *todo[gi];
         const int k = (int)(gi % (size_t)lanes);
-        if (launch_biquad<FMT>(prog, pl, g, g.d_ids, g.n, io, biquad_impl, k ? prog->bq_side[k - 1] : st, nullptr, with_ready)) return -1;
+        if (launch_group(g, k ? prog->bq_side[k - 1] : st, nullptr)) return -1;
     }
     for (int k = 1; k < lanes; k++) {
         HIP_TRY(hipEventRecord(prog->bq_join[k - 1], prog->bq_side[k - 1]));
@@ -4329,7 +4366,9 @@ int avdsp_hip_prog_add_plan(avdsp_hip_prog *prog, const avdsp_plan_desc *d)
             it->second.push_back(i);
         } else if (!c.fir_taps) pass.push_back(i);
     }
-    if (upload_vec(&pl.d_chains, chains) || upload_vec(&pl.d_sec_coef, coef) || upload_vec(&pl.d_sec_state, state)) { free_plan(pl); return -1; }
+    if (upload_vec(&pl.d_sec_coef, coef) || upload_vec(&pl.d_sec_state, state)) { free_plan(pl); return -1; }
+    if (pl.lane_mode && upload_vec(&pl.d_chains, chains)) { free_plan(pl); return -1; }
+    std::vector<avdsp_chain> dev_chains = chains;        /* what the kernels see: the host's records + the pieces of long cascades (below) */
     if (pl.lane_mode) {                                  /* no launch groups, no rings: chain_lane walks the chain list itself */
         pl.n_lane_fir = (int)fir.size();             /* (n_fir stays 0: that one counts chains with a ring) */
         std::vector<int> rows;
@@ -4341,7 +4380,7 @@ int avdsp_hip_prog_add_plan(avdsp_hip_prog *prog, const avdsp_plan_desc *d)
         return (int)prog->plans.size() - 1;
     }
     std::vector<RowRec> all_rows; std::vector<LaneRec> all_lanes;
-    for (auto &e : byN) {                                /* > 64 sections (P = 128): biquad_simple */
+    for (auto &e : byN) {                                /* > 64 sections (P = 128): pieces of up to 64, below */
         /* lanes per chain: the next power of two -- but a 16-lane row per chain while the chip has SIMDs to spare
          * (<= 1024 waves): its step is shorter (one input batch per 16 steps, no mid-row section-0 lanes: cfg5's
          * 8-section cascades 85 -> 62 us) and idle lanes cost nothing there */
@@ -4351,6 +4390,38 @@ int avdsp_hip_prog_add_plan(avdsp_hip_prog *prog, const avdsp_plan_desc *d)
         for (int id : e.second) all_fir = all_fir && chains[id].fir_taps != 0;
         Plan::Group g{P, e.first, (int)e.second.size(), nullptr, all_fir, nullptr, nullptr};
         if (upload_vec(&g.d_ids, e.second)) { free_plan(pl); return -1; }
+        if (e.first > 64) {
+            /* A cascade of more than 64 sections does not fit a wave's lanes.  biquad_simple (a lane per chain, state in memory) took 81 ms
+             * for 4096 chains x 65 sections against 136 us for 64: the chain is CUT instead, into pieces of equal length (+- 1) that run as
+             * launches of biquad_pipe one after the other.  The pieces but the last are chain records of their own behind the host's
+             * (no FIR, no SAT0DB, one raw store into the scratch column); the last piece is the chain's own record with its input moved
+             * to the scratch column (its ring, stores and ready word are the chain's). */
+            const int np = (e.first + 63) / 64, base = e.first / np, extra = e.first % np, n = (int)e.second.size();
+            int at = 0;
+            for (int k = 0; k < np; k++) {
+                const int len = base + (k < extra ? 1 : 0);
+                std::vector<int> ids(n);
+                for (int j = 0; j < n; j++) {
+                    const avdsp_chain &c = chains[e.second[j]];
+                    avdsp_chain pc = c;
+                    pc.sec_base = c.sec_base + at; pc.nsec = len;
+                    if (k > 0) { pc.in_io = j; pc.load_mode = kLoadRaw; }
+                    if (k + 1 < np) {
+                        pc.fir_taps = 0; pc.sat = kStoreRaw; pc.n_out = 1; pc.out_io[0] = j;
+                        ids[j] = (int)dev_chains.size(); dev_chains.push_back(pc);
+                    } else { ids[j] = e.second[j]; dev_chains[e.second[j]] = pc; }
+                }
+                Plan::Group pg{pow2ceil(len), len, n, nullptr, k + 1 == np && all_fir, nullptr, nullptr};
+                if (upload_vec(&pg.d_ids, ids)) { (void)hipFree(g.d_ids); for (auto &x : g.pieces) (void)hipFree(x.d_ids); free_plan(pl); return -1; }
+                g.pieces.push_back(pg);
+                at += len;
+            }
+            for (int k = 0; k < 2; k++)
+                if (hipMalloc((void **)&g.d_scratch[k], (size_t)kFirChunk * n * sizeof(unsigned)) != hipSuccess) {
+                    (void)hipFree(g.d_ids); (void)hipFree(g.d_scratch[0]); for (auto &x : g.pieces) (void)hipFree(x.d_ids); free_plan(pl);
+                    return set_err("hipMalloc(scratch of %d long cascades)", n);
+                }
+        }
         if (P == 16) {                                   /* what biquad_row loads instead of walking group -> chain -> section tables */
             std::vector<RowRec> rows(e.second.size());
             std::vector<LaneRec> lanes(e.second.size() * 16, LaneRec{-1, -1});
@@ -4373,6 +4444,7 @@ int avdsp_hip_prog_add_plan(avdsp_hip_prog *prog, const avdsp_plan_desc *d)
         }
         pl.bq.push_back(g);
     }
+    if (upload_vec(&pl.d_chains, dev_chains)) { free_plan(pl); return -1; }
     if (pl.n_row_groups >= 2) {
         RowRec empty = all_rows.back(); empty.cid = -1;
         while (all_rows.size() % 16) { all_rows.push_back(empty); all_lanes.insert(all_lanes.end(), 16, LaneRec{-1, -1}); }

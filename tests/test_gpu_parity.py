@@ -648,3 +648,52 @@ def test_cascades_of_many_lengths_in_one_launch(fmt, fanout):
     finally:
         r.set_option("group_fanout", 1)
         r.release()
+
+
+@pytest.mark.parametrize("fmt", [2, 4, 6])
+@pytest.mark.parametrize("biquad_impl", [1, 0])
+def test_cascades_longer_than_a_wave_run_as_pieces(fmt, biquad_impl):
+    """More than 64 sections in one chain do not fit a wave's lanes: until round 5 such a chain fell to biquad_simple (a lane per chain,
+    state in memory -- 4096 chains x 65 sections 81 ms against 136 us for 64).  Now add_plan cuts it into pieces of up to 64 sections that
+    run as launches one after the other, the 32-bit word between two sections going through a scratch column.  Chains of 65, 100, 128, 129
+    and 200 sections beside short ones, plain and gain loads, with and without SAT0DB, two of them in front of a FIR, ragged blocks (one
+    of more than 1024 frames) against the oracle, outputs and state; in format 6 then an Inf and a NaN sample (the pieces' replay in the
+    reference's own order).  biquad_impl 0: the same pieces through biquad_simple."""
+    counts = [65, 100, 128, 129, 200, 16, 3, 64, 65, 65]
+    n = len(counts)
+    w = pb.ProgramWriter(fmt, pb.F48000, pb.F48000, capacity=1 << 16)
+    w.core()
+    for c, S in enumerate(counts):
+        w.param()
+        bank = w.biquad_bank(pb.synth_sections(c, S, pb.F48000, pb.F48000))
+        T = 40 if (fmt != 2 and c in (1, 3)) else 0
+        imp = w.fir_impulses([pb.lcg_taps(c, T)]) if T else None
+        if c & 1:
+            w.load_gain_fixed(n + c, 0.5)
+        else:
+            w.load(n + c)
+        w.biquads(bank, S)
+        if T:
+            w.fir(imp, T)
+        if c % 3:
+            w.sat0db()
+        w.store(c)
+    prog = w.end_of_code()
+    x = pb.lcg_input(3200, n, fmt == 6, seed=10 + fmt)
+    if fmt == 6:
+        x[2900, 0] = np.inf; x[2950, 4] = np.nan; x[3000, 8] = -np.inf
+    o = po.OracleProgram(fmt, prog)
+    r = rt.Runtime(fmt, prog)
+    r.set_option("biquad_impl", biquad_impl)
+    assert r.core_info(0)["chains"] == n
+    try:
+        pos = 0
+        for b in (1024, 37, 1500, 1, 638):
+            want, got = o.run_block(x[pos:pos + b], n, n), r.run_block(x[pos:pos + b], n, n)
+            bad = np.nonzero((got.view(np.uint32) != want.view(np.uint32)).any(axis=0))[0]
+            assert bad.size == 0, f"block at {pos}: chains {bad.tolist()} (sections {[counts[i] for i in bad]}) differ"
+            pos += b
+        assert (r.sync_state() == o.state).all()
+    finally:
+        r.set_option("biquad_impl", 1)
+        r.release()
