@@ -33,6 +33,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <chrono>
+#include <mutex>
 #include <thread>
 
 #include <cstdarg>
@@ -3577,14 +3578,94 @@ int ready_check(avdsp_hip_prog *prog)
 }
 #define READY_CHECK(prog) do { if (ready_check(prog)) return -1; } while (0)
 
+/* ---- copies between the CALLER's memory and the device: the GPU never touches pageable memory it does not own (round 5) ----
+ * hipMemcpy[Async] of pageable memory: up to ~1 MB this runtime copies through a pinned buffer of its own; from 4 MB on it PINS THE CALLER'S
+ * PAGES and lets the copy engine read / write them (tools/pageable_copy_probe.hip: the engine's addresses are the caller's), and such a pin
+ * outlives the call -- it stays with the stream until that stream's next wait.  This library's input stream was never waited for.  A buffer
+ * that is freed, whose heap pages are trimmed away and come back, and that is handed over again at the same address and size then meets the
+ * old pin: "Memory access fault by GPU node-2 ... on address 0x5c87... (a heap address)", no wave active in the core dump (rocgdb: a copy
+ * engine, not a kernel) -- three full test runs of five died that way this round, one of them inside PyTorch's own .cuda() of a 4 MB numpy array.
+ * So: every copy of 1 MB or more between memory the caller owns and the device goes through two pinned chunks of the library's own (the CPU
+ * copies a chunk while the engine moves the previous one), whatever the runtime would have done.  Memory the CALLER has pinned -- "host_pin",
+ * the queued calls, hipHostRegister / hipHostMalloc of his own -- is told apart by hipPointerGetAttributes and copied directly. */
+constexpr size_t kBounceFrom = 1u << 20, kBounceChunk = 4u << 20;
+struct Bounce { char *h[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {nullptr, nullptr}; hipStream_t s = nullptr; };
+Bounce g_bounce[16];
+std::mutex g_bounce_mutex;
+
+bool caller_memory_is_pinned(const void *p)
+{
+    hipPointerAttribute_t at;
+    const hipError_t e = hipPointerGetAttributes(&at, p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return false; }      /* (an address the runtime has never heard of: pageable) */
+    return at.type == hipMemoryTypeHost || at.type == hipMemoryTypeManaged || at.type == hipMemoryTypeDevice;
+}
+
+int bounce_ready(Bounce **out)
+{
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    Bounce &b = g_bounce[dev & 15];
+    if (!b.s) {
+        HIP_TRY(hipStreamCreateWithFlags(&b.s, hipStreamNonBlocking));
+        for (int k = 0; k < 2; k++) {
+            HIP_TRY(hipHostMalloc((void **)&b.h[k], kBounceChunk, hipHostMallocDefault));
+            HIP_TRY(hipEventCreateWithFlags(&b.ev[k], hipEventDisableTiming));
+        }
+    }
+    *out = &b;
+    return 0;
+}
+
+/* both like hipMemcpy: the device side is idle or ordered by the caller of these (they run on a stream of their own and wait for it) */
+int copy_from_caller(void *d_dst, const void *h_src, size_t bytes)
+{
+    if (!bytes) return 0;
+    if (bytes < kBounceFrom || caller_memory_is_pinned(h_src)) { HIP_TRY(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice)); return 0; }
+    std::lock_guard<std::mutex> lock(g_bounce_mutex);
+    Bounce *b;
+    if (bounce_ready(&b)) return -1;
+    size_t off = 0;
+    for (int c = 0; off < bytes; c++, off += kBounceChunk) {
+        const size_t n = std::min(kBounceChunk, bytes - off);
+        if (c >= 2) HIP_TRY(hipEventSynchronize(b->ev[c & 1]));          /* the chunk this buffer held two turns ago has left it */
+        memcpy(b->h[c & 1], (const char *)h_src + off, n);
+        HIP_TRY(hipMemcpyAsync((char *)d_dst + off, b->h[c & 1], n, hipMemcpyHostToDevice, b->s));
+        HIP_TRY(hipEventRecord(b->ev[c & 1], b->s));
+    }
+    HIP_TRY(hipStreamSynchronize(b->s));
+    return 0;
+}
+
+int copy_to_caller(void *h_dst, const void *d_src, size_t bytes)
+{
+    if (!bytes) return 0;
+    if (bytes < kBounceFrom || caller_memory_is_pinned(h_dst)) { HIP_TRY(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost)); return 0; }
+    std::lock_guard<std::mutex> lock(g_bounce_mutex);
+    Bounce *b;
+    if (bounce_ready(&b)) return -1;
+    const int nc = (int)((bytes + kBounceChunk - 1) / kBounceChunk);
+    auto chunk_bytes = [&](int c) { return std::min(kBounceChunk, bytes - (size_t)c * kBounceChunk); };
+    for (int c = 0; c <= nc; c++) {                       /* chunk c is on its way while the CPU takes chunk c - 1 home */
+        if (c < nc) {                                     /* (its buffer was emptied by the CPU a turn ago) */
+            HIP_TRY(hipMemcpyAsync(b->h[c & 1], (const char *)d_src + (size_t)c * kBounceChunk, chunk_bytes(c), hipMemcpyDeviceToHost, b->s));
+            HIP_TRY(hipEventRecord(b->ev[c & 1], b->s));
+        }
+        if (c >= 1) {
+            HIP_TRY(hipEventSynchronize(b->ev[(c - 1) & 1]));
+            memcpy((char *)h_dst + (size_t)(c - 1) * kBounceChunk, b->h[(c - 1) & 1], chunk_bytes(c - 1));
+        }
+    }
+    return 0;
+}
+
 template <typename T>
 int upload_vec(T **dst, const std::vector<T> &v)
 {
     *dst = nullptr;
     if (v.empty()) return 0;
     HIP_TRY(hipMalloc((void **)dst, v.size() * sizeof(T)));
-    HIP_TRY(hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
-    return 0;
+    return copy_from_caller(*dst, v.data(), v.size() * sizeof(T));
 }
 
 void free_plan(Plan &p)
@@ -4978,7 +5059,7 @@ int avdsp_hip_upload_words(avdsp_hip_prog *p, const int32_t *host_buf, int first
 {
     if (check_range(p, first, n)) return -1;
     HIP_TRY(hipDeviceSynchronize());
-    if (n) HIP_TRY(hipMemcpy(p->d_buf + first, host_buf + first, (size_t)n * 4, hipMemcpyHostToDevice));
+    if (n && copy_from_caller(p->d_buf + first, host_buf + first, (size_t)n * 4)) return -1;
     return mirror_to_rings(p);
 }
 
@@ -4989,7 +5070,7 @@ int avdsp_hip_download_words(avdsp_hip_prog *p, int32_t *host_buf, int first, in
     READY_CHECK(p);                                      /* the state the caller asks for would not be the reference's */
     if (rings_to_mirror(p)) return -1;
     HIP_TRY(hipDeviceSynchronize());
-    if (n) HIP_TRY(hipMemcpy(host_buf + first, p->d_buf + first, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (n && copy_to_caller(host_buf + first, p->d_buf + first, (size_t)n * 4)) return -1;
     return 0;
 }
 
@@ -5206,8 +5287,11 @@ int avdsp_hip_run_block_host(avdsp_hip_prog *prog, int plan, const void *h_in, i
     }
     /* The chain kernels over a block of some size: the host loop of linux/avdsp_plugin.c:98-141 as a three-stage pipeline --
      * piece k+1 crosses PCIe while piece k is computed and piece k-1 goes back.  The output block is uploaded first only if
-     * the core leaves slots of the window untouched (they must keep the caller's content). */
-    if (!pl.generic && nframes >= 256) {
+     * the core leaves slots of the window untouched (they must keep the caller's content).
+     * Only over PINNED memory ("host_pin", or buffers the caller has pinned himself): asynchronous copies of pageable memory make
+     * the runtime pin the caller's pages behind his back (copy_from_caller); pageable buffers take the synchronous way below. */
+    const bool whole_window = !pl.generic && pl.stores_whole_window && out_io_base == pl.io_out_min && out_stride == pl.io_out_max - pl.io_out_min + 1;
+    if (!pl.generic && nframes >= 256 && (prog->host_pin || (caller_memory_is_pinned(h_in) && caller_memory_is_pinned(h_out)))) {
         if (!prog->s_h2d) {
             HIP_TRY(hipStreamCreateWithFlags(&prog->s_h2d, hipStreamNonBlocking));
             HIP_TRY(hipStreamCreateWithFlags(&prog->s_run, hipStreamNonBlocking));
@@ -5220,8 +5304,7 @@ int avdsp_hip_run_block_host(avdsp_hip_prog *prog, int plan, const void *h_in, i
             pin_in_place(prog, h_in, in_words * 4, true);   pin_hold.a = h_in;
             pin_in_place(prog, h_out, out_words * 4, true); pin_hold.b = h_out;
         }
-        const bool whole = pl.stores_whole_window && out_io_base == pl.io_out_min && out_stride == pl.io_out_max - pl.io_out_min + 1;
-        if (!whole) HIP_TRY(hipMemcpyAsync(prog->d_out, h_out, out_words * 4, hipMemcpyHostToDevice, prog->s_h2d));
+        if (!whole_window) HIP_TRY(hipMemcpyAsync(prog->d_out, h_out, out_words * 4, hipMemcpyHostToDevice, prog->s_h2d));
         const int split = prog->host_split > 0 ? std::max(prog->host_split, 64) : nframes;
         const int npieces = (nframes + split - 1) / split;
         while ((int)prog->ev_host.size() < 2 * npieces) {
@@ -5245,6 +5328,7 @@ int avdsp_hip_run_block_host(avdsp_hip_prog *prog, int plan, const void *h_in, i
         }
         HIP_TRY(hipStreamSynchronize(prog->s_d2h));
         HIP_TRY(hipStreamSynchronize(prog->s_run));
+        HIP_TRY(hipStreamSynchronize(prog->s_h2d));      /* (nothing of this call stays behind on any stream) */
         READY_CHECK(prog);                               /* (synchronous: a time-out inside THIS block is this call's error) */
         return 0;
     }
@@ -5265,13 +5349,13 @@ int avdsp_hip_run_block_host(avdsp_hip_prog *prog, int plan, const void *h_in, i
         memcpy(h_out, ho, out_words * 4);
         return 0;
     }
-    HIP_TRY(hipMemcpy(prog->d_in, h_in, in_words * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(prog->d_out, h_out, out_words * 4, hipMemcpyHostToDevice));   /* unstored slots keep their content */
+    if (copy_from_caller(prog->d_in, h_in, in_words * 4)) return -1;
+    if (!whole_window && copy_from_caller(prog->d_out, h_out, out_words * 4)) return -1;   /* unstored slots keep their content */
     if (avdsp_hip_run_block(prog, plan, prog->d_in, in_stride, in_io_base, prog->d_out, out_stride, out_io_base,
                             nframes, fir_impl, biquad_impl, nullptr)) return -1;
     HIP_TRY(hipDeviceSynchronize());
     READY_CHECK(prog);                                   /* (synchronous: a time-out inside THIS block is this call's error) */
-    HIP_TRY(hipMemcpy(h_out, prog->d_out, out_words * 4, hipMemcpyDeviceToHost));
+    if (copy_to_caller(h_out, prog->d_out, out_words * 4)) return -1;
     return 0;
 }
 
@@ -5324,6 +5408,14 @@ int avdsp_hip_submit_block_host(avdsp_hip_prog *prog, int plan, const void *h_in
     }
     pin_in_place(prog, h_in, in_words * 4, true);   sl.h_in = h_in;
     pin_in_place(prog, h_out, out_words * 4, true); sl.h_out = h_out;
+    if (!caller_memory_is_pinned(h_in) || !caller_memory_is_pinned(h_out)) {
+        /* the registration did not take (the runtime refuses some ranges): no asynchronous copy over pageable memory (copy_from_caller) --
+         * the block is done on the spot, behind the queue */
+        unpin_block(prog, sl.h_in); unpin_block(prog, sl.h_out); sl.h_in = sl.h_out = nullptr;
+        if (avdsp_hip_wait_block_host(prog, 0) < 0) return -1;
+        if (avdsp_hip_run_block_host(prog, plan, h_in, in_stride, in_io_base, h_out, out_stride, out_io_base, nframes, fir_impl, biquad_impl)) return -1;
+        return 0;
+    }
     const bool whole = pl.stores_whole_window && out_io_base == pl.io_out_min && out_stride == pl.io_out_max - pl.io_out_min + 1;
     if (!whole) HIP_TRY(hipMemcpyAsync(sl.d_out, h_out, out_words * 4, hipMemcpyHostToDevice, prog->q_h2d));   /* unstored slots keep their content */
     HIP_TRY(hipMemcpyAsync(sl.d_in, h_in, in_words * 4, hipMemcpyHostToDevice, prog->q_h2d));
@@ -5643,7 +5735,7 @@ int avdsp_hip_download_instance_words(avdsp_hip_prog *p, int inst, int32_t *host
         READY_CHECK(p);
         if (rings_to_mirror(p)) return -1;
         HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipMemcpy(host_buf, p->d_buf + (size_t)inst * AVDSP_INSTANCE_STRIDE(p->total_words) + first, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+        if (copy_to_caller(host_buf, p->d_buf + (size_t)inst * AVDSP_INSTANCE_STRIDE(p->total_words) + first, (size_t)n * sizeof(int))) return -1;
         return 0;
     }
     /* (instance 0 of a program with ONE instance may be a chain program like any other: its FIR histories live in the plans' rings) */
@@ -5655,7 +5747,7 @@ int avdsp_hip_download_instance_words(avdsp_hip_prog *p, int inst, int32_t *host
         if (!p->inst_valid || !p->d_inst_buf) return set_err("the instances have not run yet");
         src = p->d_inst_buf + (size_t)(inst - 1) * ((size_t)p->total_words + 2);
     }
-    HIP_TRY(hipMemcpy(host_buf, src + first, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    if (copy_to_caller(host_buf, src + first, (size_t)n * sizeof(int))) return -1;
     return 0;
 }
 
@@ -5672,12 +5764,12 @@ int avdsp_hip_run_levels_host(avdsp_hip_prog *prog, const int *plans, const int 
         (void)hipFree(prog->d_out); prog->d_out = nullptr; prog->out_cap = 0;
         HIP_TRY(hipMalloc((void **)&prog->d_out, out_words * 4)); prog->out_cap = out_words;
     }
-    HIP_TRY(hipMemcpy(prog->d_in, h_in, in_words * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(prog->d_out, h_out, out_words * 4, hipMemcpyHostToDevice));   /* unstored slots keep their content */
+    if (copy_from_caller(prog->d_in, h_in, in_words * 4)) return -1;
+    if (copy_from_caller(prog->d_out, h_out, out_words * 4)) return -1;   /* unstored slots keep their content */
     if (avdsp_hip_run_levels(prog, plans, level_size, nlevels, prog->d_in, in_stride, in_io_base, prog->d_out, out_stride,
                              out_io_base, nframes, fir_impl, biquad_impl, nullptr)) return -1;
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(h_out, prog->d_out, out_words * 4, hipMemcpyDeviceToHost));
+    if (copy_to_caller(h_out, prog->d_out, out_words * 4)) return -1;
     return 0;
 }
 
@@ -5728,15 +5820,15 @@ int avdsp_hip_run_block_pcm_host(avdsp_hip_prog *prog, int plan, int pcm, const 
         HIP_TRY(hipMalloc((void **)&prog->d_out, out_words * 4)); prog->out_cap = out_words;
     }
     unsigned *d_raw = prog->d_in + unpacked;
-    HIP_TRY(hipMemcpy(d_raw, h_src, raw_bytes, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(prog->d_out, h_out, out_words * 4, hipMemcpyHostToDevice));
+    if (copy_from_caller(d_raw, h_src, raw_bytes)) return -1;
+    if (copy_from_caller(prog->d_out, h_out, out_words * 4)) return -1;
     if (avdsp_hip_unpack_pcm(prog, pcm, d_raw, prog->d_in, nsamples, nullptr) || unpack_done(prog)) return -1;
     const int rc = avdsp_hip_run_block(prog, plan, prog->d_in, in_stride, in_io_base, prog->d_out, out_stride, out_io_base,
                                        nframes, fir_impl, biquad_impl, nullptr);
     prog->input_ready = nullptr;
     if (rc) return -1;
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(h_out, prog->d_out, out_words * 4, hipMemcpyDeviceToHost));
+    if (copy_to_caller(h_out, prog->d_out, out_words * 4)) return -1;
     return 0;
 }
 
@@ -5768,15 +5860,15 @@ int avdsp_hip_run_levels_pcm_host(avdsp_hip_prog *prog, const int *plans, const 
         HIP_TRY(hipMalloc((void **)&prog->d_out, out_words * 4)); prog->out_cap = out_words;
     }
     unsigned *d_raw = prog->d_in + unpacked;
-    HIP_TRY(hipMemcpy(d_raw, h_src, raw_bytes, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(prog->d_out, h_out, out_words * 4, hipMemcpyHostToDevice));
+    if (copy_from_caller(d_raw, h_src, raw_bytes)) return -1;
+    if (copy_from_caller(prog->d_out, h_out, out_words * 4)) return -1;
     if (avdsp_hip_unpack_pcm(prog, pcm, d_raw, prog->d_in, nsamples, nullptr) || unpack_done(prog)) return -1;
     const int rc = avdsp_hip_run_levels(prog, plans, level_size, nlevels, prog->d_in, in_stride, in_io_base, prog->d_out, out_stride,
                                         out_io_base, nframes, fir_impl, biquad_impl, nullptr);
     prog->input_ready = nullptr;
     if (rc) return -1;
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(h_out, prog->d_out, out_words * 4, hipMemcpyDeviceToHost));
+    if (copy_to_caller(h_out, prog->d_out, out_words * 4)) return -1;
     return 0;
 }
 

@@ -205,6 +205,7 @@ def verify_against_reference_pins(args, make_runtime, workload, shard_rank, shar
     SHA-256 of every block and of the final state.  Returns a description for the JSON line; raises VerificationError on a
     mismatch (main() lets every rank know before any of them leaves, so that an N > 1 job ends as one)."""
     import hashlib
+    from avdsp_amd import devmem as dm
     from avdsp_amd import progbuilder as pb
     name = HEADLINE_CASE.get(workload)
     gdir = os.path.join(ROOT, "tests", "golden")
@@ -222,7 +223,7 @@ def verify_against_reference_pins(args, make_runtime, workload, shard_rank, shar
     if Cl < 1:
         r.release()
         return f"{name}: shard {shard_rank}/{shard_world} holds no chains"
-    xs = torch.from_numpy(np.ascontiguousarray(x[:, in_base - C:in_base - C + Cl])).cuda()
+    xs = dm.to_device(x[:, in_base - C:in_base - C + Cl])
     ys = torch.zeros((frames, Cl), dtype=xs.dtype, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
     # the pins are per 1024-frame block of the case; --block pushes the same frames through in calls of that many frames (the last
@@ -232,7 +233,7 @@ def verify_against_reference_pins(args, make_runtime, workload, shard_rank, shar
         n = min(Bcall, frames - f0)
         r.run_block_device(xs[f0:].data_ptr(), Cl, in_base, ys[f0:].data_ptr(), Cl, out_base, n, stream)
     torch.cuda.synchronize()
-    out = ys.cpu().numpy()
+    out = dm.to_host(ys)
     w = np.ascontiguousarray(out).view(np.uint32)
     col = w.sum(axis=0, dtype=np.uint64).astype(np.uint32)
     want = g["col_sum"][out_base:out_base + Cl]
@@ -344,6 +345,7 @@ def main():
 
     import torch                      # first: its bundled HIP runtime must be the process's only one
     import torch.distributed as dist
+    from avdsp_amd import devmem as dm
     from avdsp_amd import progbuilder as pb
     from avdsp_amd import runtime as rt
 
@@ -449,7 +451,7 @@ def main():
 
     xfull = pb.lcg_input(B, C, fmt == 6, seed=12345)
     xs = np.ascontiguousarray(xfull[:, in_base - C:in_base - C + Cl])      # the rank's column slice of the [B][C] block
-    x = torch.from_numpy(xs).cuda()
+    x = dm.to_device(xs)         # (through pinned memory: avdsp_amd/devmem.py)
     y = torch.zeros((B, Cl), dtype=x.dtype, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
     if args.own_stream:
@@ -534,7 +536,7 @@ def main():
         # (shards differ by at most one chain: every rank hands over max(C/N) columns, the last one of a smaller shard unused)
         cmax = -(-C // world)
         ypad = y if Cl == cmax else torch.nn.functional.pad(y, (0, cmax - Cl))
-        dev_y = ypad.contiguous() if backend == "nccl" else ypad.cpu().contiguous()
+        dev_y = ypad.contiguous() if backend == "nccl" else torch.from_numpy(dm.to_host(ypad))
         parts = [torch.empty_like(dev_y) for _ in range(world)]
         csum = dev_y.view(torch.int32).to(torch.int64).sum().reshape(1)
         for _ in range(3):

@@ -7,6 +7,7 @@ import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from avdsp_amd import progbuilder as pb, runtime as rt
+from avdsp_amd import devmem as dm
 from oracle import pyoracle as po
 from tests.fuzz_programs import stress_input
 
@@ -36,12 +37,12 @@ def run(lo, hi, formats=(2, 3, 4, 5, 6)):
         st = torch.cuda.current_stream().cuda_stream
         pos = 0
         for b in blocks:
-            xd = torch.from_numpy(np.ascontiguousarray(xs[:, pos:pos + b])).cuda()
+            xd = dm.to_device(np.ascontiguousarray(xs[:, pos:pos + b]))
             yd = torch.zeros((ninst, b, C), dtype=xd.dtype, device="cuda")
             torch.cuda.synchronize()
             r.run_block_all_instances_device(xd.data_ptr(), C, C, b * C, yd.data_ptr(), C, 0, b * C, b, st)
             torch.cuda.synchronize()
-            got[:, pos:pos + b] = yd.cpu().numpy()
+            got[:, pos:pos + b] = dm.to_host(yd)
             pos += b
         ok = True
         for i in range(ninst):

@@ -8,6 +8,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from avdsp_amd import progbuilder as pb, runtime as rt
+from avdsp_amd import devmem as dm
 from oracle import pyoracle as po
 from tests.fuzz_programs import stress_input
 
@@ -30,14 +31,14 @@ def run(lo, hi):
         arr = ARR[seed % len(ARR)]
         r = rt.Runtime(fmt, prog)
         for k, v in arr.items(): r.set_option(k, v)
-        xd = [torch.from_numpy(np.ascontiguousarray(x[k * B:(k + 1) * B])).cuda() for k in range(nb)]
+        xd = [dm.to_device(np.ascontiguousarray(x[k * B:(k + 1) * B])) for k in range(nb)]
         yd = [torch.zeros((B, C), dtype=xd[0].dtype, device="cuda") for _ in range(nb)]
         torch.cuda.synchronize()
         st = torch.cuda.current_stream().cuda_stream
         for k in range(nb):
             r.run_block_device(xd[k].data_ptr(), C, C, yd[k].data_ptr(), C, 0, B, st)
         torch.cuda.synchronize()
-        got = np.concatenate([y.cpu().numpy() for y in yd])
+        got = np.concatenate([dm.to_host(y) for y in yd])
         ok = bool((got.view(np.uint32) == want.view(np.uint32)).all()) and bool((r.sync_state() == o.state).all()) and r.get_option("ready_timeouts") == 0
         n += 1
         if not ok:

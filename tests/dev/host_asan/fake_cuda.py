@@ -12,6 +12,7 @@ def _cpu_device(fn):
     def wrapped(*a, **kw):
         if str(kw.get("device", "")).startswith("cuda"):
             kw["device"] = "cpu"
+        kw.pop("pin_memory", None)
         return fn(*a, **kw)
     return wrapped
 

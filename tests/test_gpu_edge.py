@@ -9,6 +9,7 @@ import pytest
 
 from avdsp_amd import progbuilder as pb
 from avdsp_amd import runtime as rt
+from avdsp_amd import devmem as dm
 from oracle import pyoracle as po
 from tests.test_gpu_parity import assert_close
 
@@ -143,13 +144,13 @@ def test_device_entry_point_on_a_side_stream():
         xd.copy_(torch.from_numpy(x[:B]))
         r.run_block_device(xd.data_ptr(), C, C, yd.data_ptr(), C, 0, B, side.cuda_stream)     # plan creation outside capture
     side.synchronize()
-    got = [yd.cpu().numpy().copy()]
+    got = [dm.to_host(yd)]
     for k in (1, 2):
         with torch.cuda.stream(side):
             xd.copy_(torch.from_numpy(x[k * B:(k + 1) * B]))
             r.run_block_device(xd.data_ptr(), C, C, yd.data_ptr(), C, 0, B, side.cuda_stream)
         side.synchronize()
-        got.append(yd.cpu().numpy().copy())
+        got.append(dm.to_host(yd))
     assert_close(np.concatenate(got), want, 6)
 
 
@@ -244,7 +245,7 @@ def test_unpack_on_device_misaligned_source():
             rc = r.L.dspRuntimeUnpackPcmDevice(pcm, buf.data_ptr() + shift, dst.data_ptr(), x.size, None)
             assert rc == 0, r.last_error()
             torch.cuda.synchronize()
-            got = dst.cpu().numpy()
+            got = dm.to_host(dst)
             assert (got[:x.size] == _unpack_like_the_plugin(raw, pcm)).all()
             assert (got[x.size:] == 0).all()
 
@@ -362,10 +363,10 @@ def test_in_place_blocks_with_inf_and_nan(fmt, sections):
     pos = 0
     for b in blocks:
         want = o.run_block(x[pos:pos + b], C, C)
-        buf = torch.from_numpy(x[pos:pos + b].copy()).cuda()
+        buf = dm.to_device(x[pos:pos + b].copy())
         r.run_block_device(buf.data_ptr(), C, C, buf.data_ptr(), C, 0, b, st)
         torch.cuda.synchronize()
-        got = buf.cpu().numpy()
+        got = dm.to_host(buf)
         bad = np.nonzero((got.view(np.uint32) != want.view(np.uint32)).any(axis=0))[0]
         assert bad.size == 0, f"block at {pos}: channels {bad.tolist()} differ"
         pos += b

@@ -19,6 +19,7 @@ import pytest
 
 from avdsp_amd import progbuilder as pb
 from avdsp_amd import runtime as rt
+from avdsp_amd import devmem as dm
 from avdsp_amd import sharding as sh
 from oracle import pyoracle as po
 from tests.golden_recipes import GOLDEN_DIR
@@ -314,14 +315,14 @@ def test_overlap_mode_is_bit_identical(fmt, C, S, T, fir_impl):
         r.set_option("ready_words", ready_words)
         r.set_option("ring_wait", ring_wait)
         assert r.get_option("overlap") == overlap and r.get_option("ready_words") == ready_words and r.get_option("ring_wait") == ring_wait
-        xd = [torch.from_numpy(x[k * B:(k + 1) * B].copy()).cuda() for k in range(nb)]
+        xd = [dm.to_device(x[k * B:(k + 1) * B].copy()) for k in range(nb)]
         yd = [torch.zeros((B, C), dtype=xd[0].dtype, device="cuda") for _ in range(nb)]
         torch.cuda.synchronize()                             # the mode's contract: inputs complete when the call is made
         st = torch.cuda.current_stream().cuda_stream
         for k in range(nb):
             r.run_block_device(xd[k].data_ptr(), C, C, yd[k].data_ptr(), C, 0, B, st)
         torch.cuda.synchronize()
-        got = np.concatenate([y.cpu().numpy() for y in yd])
+        got = np.concatenate([dm.to_host(y) for y in yd])
         assert (words(got) == words(want)).all(), f"overlap={overlap} ready_words={ready_words} ring_wait={ring_wait}"
         assert (r.sync_state() == o.state).all()
         assert r.get_option("ready_timeouts") == 0            # no wave ever gave up waiting for a ready word
@@ -340,7 +341,7 @@ def test_overlap_mode_is_bit_identical(fmt, C, S, T, fir_impl):
             r.run_block_device(xd[k].data_ptr(), C, C, y1.data_ptr(), C, 0, B, st)
             outs.append(y1.clone())                           # (on the current stream: ordered behind the block)
         torch.cuda.synchronize()
-        got = np.concatenate([y.cpu().numpy() for y in outs])
+        got = np.concatenate([dm.to_host(y) for y in outs])
         assert (words(got) == words(want)).all(), f"overlap={overlap} ready_words={ready_words}, one output buffer"
         r.set_option("overlap", 0)
         r.set_option("ready_words", -1)

@@ -8,6 +8,7 @@ import pytest
 
 from avdsp_amd import progbuilder as pb
 from avdsp_amd import runtime as rt
+from avdsp_amd import devmem as dm
 from oracle import pyoracle as po
 from tests.golden_recipes import GOLDEN_DIR
 
@@ -32,11 +33,11 @@ def _run_instances(fmt, prog, xs, in_stride, in_base, out_stride, blocks, fs=480
     st = torch.cuda.current_stream().cuda_stream
     pos = 0
     for b in blocks:
-        xd = torch.from_numpy(np.ascontiguousarray(xs[:, pos:pos + b])).cuda()          # [ninst][b][in_stride]
+        xd = dm.to_device(np.ascontiguousarray(xs[:, pos:pos + b]))          # [ninst][b][in_stride]
         yd = torch.zeros((ninst, b, out_stride), dtype=xd.dtype, device="cuda")
         r.run_block_all_instances_device(xd.data_ptr(), in_stride, in_base, b * in_stride, yd.data_ptr(), out_stride, 0, b * out_stride, b, st)
         torch.cuda.synchronize()
-        out[:, pos:pos + b] = yd.cpu().numpy()
+        out[:, pos:pos + b] = dm.to_host(yd)
         pos += b
     return out, r
 
@@ -58,11 +59,11 @@ def test_instances_of_the_reference_crossover_each_match_the_oracle():
     st = torch.cuda.current_stream().cuda_stream
     pos = 0
     for b in blocks:
-        xd = torch.from_numpy(np.ascontiguousarray(xs[:, pos:pos + b])).cuda()
+        xd = dm.to_device(np.ascontiguousarray(xs[:, pos:pos + b]))
         yd = torch.zeros((ninst, b, OUT_S), dtype=xd.dtype, device="cuda")
         r.run_block_all_instances_device(xd.data_ptr(), IN_S, IN_B, b * IN_S, yd.data_ptr(), OUT_S, OUT_B, b * OUT_S, b, st)
         torch.cuda.synchronize()
-        got[:, pos:pos + b] = yd.cpu().numpy()
+        got[:, pos:pos + b] = dm.to_host(yd)
         pos += b
     for i in range(ninst):
         o = po.OracleProgram(2, prog, fs=48000, random=3, dither=24)
@@ -97,11 +98,11 @@ def test_instances_with_windows_that_share_io_numbers(name):
     st = torch.cuda.current_stream().cuda_stream
     pos = 0
     for b in blocks:
-        xd = torch.from_numpy(np.ascontiguousarray(xs[:, pos:pos + b])).cuda()
+        xd = dm.to_device(np.ascontiguousarray(xs[:, pos:pos + b]))
         yd = torch.zeros((ninst, b, OUT_S), dtype=xd.dtype, device="cuda")
         r.run_block_all_instances_device(xd.data_ptr(), IN_S, IN_B, b * IN_S, yd.data_ptr(), OUT_S, OUT_B, b * OUT_S, b, st)
         torch.cuda.synchronize()
-        got[:, pos:pos + b] = yd.cpu().numpy()
+        got[:, pos:pos + b] = dm.to_host(yd)
         pos += b
     for i in range(ninst):
         o = po.OracleProgram(2, prog, fs=48000, random=3, dither=24)
@@ -155,11 +156,11 @@ def _chain_instances_vs_oracle(fmt, prog, C, ninst, blocks, seed0=40, options=No
     st = torch.cuda.current_stream().cuda_stream
     pos = 0
     for b in blocks:
-        xd = torch.from_numpy(np.ascontiguousarray(xs[:, pos:pos + b])).cuda()
+        xd = dm.to_device(np.ascontiguousarray(xs[:, pos:pos + b]))
         yd = torch.zeros((ninst, b, C), dtype=xd.dtype, device="cuda")
         r.run_block_all_instances_device(xd.data_ptr(), C, C, b * C, yd.data_ptr(), C, 0, b * C, b, st)
         torch.cuda.synchronize()
-        got[:, pos:pos + b] = yd.cpu().numpy()
+        got[:, pos:pos + b] = dm.to_host(yd)
         pos += b
     for i in range(ninst):
         o = po.OracleProgram(fmt, prog)
@@ -184,12 +185,12 @@ def test_cfg2_shaped_program_in_512_instances_is_the_golden_vector_512_times():
     ninst, B, C = 512, x.shape[0], 8
     r = rt.Runtime(6, prog)
     r.set_instances(ninst)
-    xd = torch.from_numpy(np.ascontiguousarray(np.broadcast_to(x, (ninst,) + x.shape))).cuda()
+    xd = dm.to_device(np.ascontiguousarray(np.broadcast_to(x, (ninst,) + x.shape)))
     yd = torch.zeros((ninst, B, case["out_stride"]), dtype=xd.dtype, device="cuda")
     r.run_block_all_instances_device(xd.data_ptr(), x.shape[1], case["in_base"], B * x.shape[1], yd.data_ptr(), case["out_stride"], case["out_base"],
                                      B * case["out_stride"], B, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
-    got = yd.cpu().numpy()
+    got = dm.to_host(yd)
     assert (got.view(np.uint32) == g["out"].view(np.uint32)[None]).all()
     for i in (0, 1, 255, 511):
         assert (r.instance_state(i) == g["state"]).all()

@@ -11,6 +11,7 @@ import pytest
 
 from avdsp_amd import progbuilder as pb
 from avdsp_amd import runtime as rt
+from avdsp_amd import devmem as dm
 from oracle import pyoracle as po
 
 pytestmark = pytest.mark.gpu
@@ -41,7 +42,7 @@ def test_a_ready_word_timeout_turns_every_later_call_into_an_error():
     r = rt.Runtime(fmt, prog)
     r.set_option("overlap", 1)
     r.set_option("ready_words", 2)
-    xd = torch.from_numpy(x).cuda()
+    xd = dm.to_device(x)
     yd = torch.zeros_like(xd)
     torch.cuda.synchronize()
     st = torch.cuda.current_stream().cuda_stream
@@ -49,7 +50,7 @@ def test_a_ready_word_timeout_turns_every_later_call_into_an_error():
         assert r.run_block_device(xd[k * B:].data_ptr(), C, C, yd[k * B:].data_ptr(), C, 0, B, st) == 0
     torch.cuda.synchronize()
     assert r.get_option("ready_timeouts") == 0
-    assert (_words(yd[:2 * B].cpu().numpy()) == _words(want[:2 * B])).all()
+    assert (_words(dm.to_host(yd[:2 * B])) == _words(want[:2 * B])).all()
 
     r.set_option("ready_test", 1)                           # the next launch's ready words are never set
     assert r.run_block_device(xd[2 * B:].data_ptr(), C, C, yd[2 * B:].data_ptr(), C, 0, B, st) == 0     # (enqueued: nothing known yet)
@@ -111,7 +112,7 @@ def test_the_cascades_stream_never_shares_a_hardware_queue_with_the_callers():
     want = po.OracleProgram(fmt, prog).run_block(x, C, C, block=B)
     r = rt.Runtime(fmt, prog)
     r.set_option("overlap", 1)
-    xd = torch.from_numpy(x).cuda()
+    xd = dm.to_device(x)
     yd = torch.zeros_like(xd)
     torch.cuda.synchronize()
     streams = [torch.cuda.Stream() for _ in range(5)]
@@ -120,7 +121,7 @@ def test_the_cascades_stream_never_shares_a_hardware_queue_with_the_callers():
         r.run_block_device(xd[k * B:].data_ptr(), C, C, yd[k * B:].data_ptr(), C, 0, B, s.cuda_stream)
         torch.cuda.synchronize()                                # (blocks of one program are ordered by the caller: here by waiting)
         assert r.get_option("side_by_side") == 1, f"block {k}: the cascades' stream shares a queue with caller's stream {(k // 2) % 5}"
-    assert (_words(yd.cpu().numpy()) == _words(want)).all()
+    assert (_words(dm.to_host(yd)) == _words(want)).all()
     assert 0 <= r.get_option("streams_remade") <= 8
     assert r.get_option("ready_timeouts") == 0
     r.release()
@@ -141,14 +142,14 @@ def test_cu_split_experiment_is_bit_identical():
         r.set_option("overlap", 1)
         r.set_option("cu_split", split)
         assert r.get_option("cu_split") == split
-        xd = [torch.from_numpy(x[k * B:(k + 1) * B].copy()).cuda() for k in range(nb)]
+        xd = [dm.to_device(x[k * B:(k + 1) * B].copy()) for k in range(nb)]
         yd = [torch.zeros((B, C), dtype=xd[0].dtype, device="cuda") for _ in range(nb)]
         torch.cuda.synchronize()
         own = torch.cuda.Stream()
         for k in range(nb):
             r.run_block_device(xd[k].data_ptr(), C, C, yd[k].data_ptr(), C, 0, B, own.cuda_stream)
         torch.cuda.synchronize()
-        got = np.concatenate([y.cpu().numpy() for y in yd])
+        got = np.concatenate([dm.to_host(y) for y in yd])
         assert (_words(got) == _words(want)).all(), f"cu_split {split}"
         assert (r.sync_state() == o.state).all()
         r.set_option("cu_split", 0)

@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 from avdsp_amd import encoder as enc, progbuilder as pb, runtime as rt
+from avdsp_amd import devmem as dm
 from oracle import pyoracle as po
 from tests.fuzz_programs import _prototypes
 
@@ -349,14 +350,14 @@ def test_block_all_device_entry_point_on_a_side_stream():
     try:
         r.set_option("profile", 1)
         side = torch.cuda.Stream()
-        x = torch.from_numpy(xh).cuda()
+        x = dm.to_device(xh)
         y = torch.zeros((512, 8), dtype=torch.int32, device="cuda")
         torch.cuda.synchronize()
         with torch.cuda.stream(side):
             for b0 in (0, 256):
                 r._check(r.L.dspRuntimeBlockAllDevice(2, r.rundata, x[b0:].data_ptr(), 16, 8, y[b0:].data_ptr(), 8, 0, 256, side.cuda_stream))
         side.synchronize()
-        assert (y.cpu().numpy() == want).all()
+        assert (dm.to_host(y) == want).all()
         assert (r.sync_state() == o.state).all()
         assert r.get_option("levels") == 2 and r.get_option("cores") == 4
         assert r.kernel_time(KIND_WAVE)[1] >= 4                # two blocks x two levels, the cores of a level in one launch

@@ -10,6 +10,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from avdsp_amd import progbuilder as pb
+from avdsp_amd import devmem as dm
 from avdsp_amd import runtime as rt
 
 fmt = int(sys.argv[1]) if len(sys.argv) > 1 else 6
@@ -17,7 +18,7 @@ S = 16
 for C in (512, 4096, 8192):
     r = rt.Runtime(fmt, pb.synth_program(fmt, C, S))
     r.set_option("profile", 1)
-    x = torch.from_numpy(pb.lcg_input(1024, C, fmt == 6)).cuda()
+    x = dm.to_device(pb.lcg_input(1024, C, fmt == 6))
     y = torch.zeros_like(x)
     st = torch.cuda.current_stream().cuda_stream
     rows = []

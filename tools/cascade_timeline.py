@@ -28,6 +28,7 @@ subprocess.check_call(f"cd {src} && /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --o
 os.environ["AVDSP_LIB"] = lib
 import torch                                                       # noqa: E402
 from avdsp_amd import progbuilder as pb                            # noqa: E402
+from avdsp_amd import devmem as dm
 from avdsp_amd import runtime as rt                                # noqa: E402
 import bench                                                       # noqa: E402
 
@@ -41,7 +42,7 @@ if args.shard:
     r.set_shard(a, b)
 info = r.shard_info()
 Cl = info["nchains"]
-x = torch.from_numpy(np.ascontiguousarray(pb.lcg_input(B, Cn, fmt == 6)[:, info["in_io_min"] - Cn:info["in_io_min"] - Cn + Cl])).cuda()
+x = dm.to_device(np.ascontiguousarray(pb.lcg_input(B, Cn, fmt == 6)[:, info["in_io_min"] - Cn:info["in_io_min"] - Cn + Cl]))
 y = torch.zeros((B, Cl), dtype=x.dtype, device="cuda")
 for _ in range(args.blocks):
     r.run_block_device(x.data_ptr(), Cl, info["in_io_min"], y.data_ptr(), Cl, info["out_io_min"], B, 0)

@@ -12,6 +12,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from avdsp_amd import progbuilder as pb      # noqa: E402
+from avdsp_amd import devmem as dm
 from avdsp_amd import runtime as rt          # noqa: E402
 
 HBM_GBS = 8000.0
@@ -82,7 +83,7 @@ def program_level():
             r = rt.Runtime(fmt, prog, fs=48000, random=1, dither=24)
             if os.environ.get("STRAND_LANES") is not None:                   # 0: strand runs stay with the interpreter's strand groups
                 r.set_option("strand_lanes", int(os.environ["STRAND_LANES"]))
-            x = torch.from_numpy(pb.lcg_input(frames, in_stride, fmt in (5, 6), seed=5)).cuda()
+            x = dm.to_device(pb.lcg_input(frames, in_stride, fmt in (5, 6), seed=5))
             y = torch.zeros((frames, out_stride), dtype=x.dtype, device="cuda")
             stream = torch.cuda.current_stream().cuda_stream
             res = {}

@@ -6,6 +6,7 @@ import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from avdsp_amd import progbuilder as pb, runtime as rt
+from avdsp_amd import devmem as dm
 
 T, B = int(os.environ.get("TAPS", 4096)), 1024
 taps = pb.lcg_taps_all(1, T)
@@ -13,7 +14,7 @@ for C in (256, 512, 1024, 1536, 2048, 3072, 4096, 6144, 8192):
     prog = pb.synth_program(6, C, 0, T, shared_taps=True, taps=taps)
     r = rt.Runtime(6, prog)
     r.set_option("profile", 1)
-    x = torch.from_numpy(pb.lcg_input(B, C, True)).cuda()
+    x = dm.to_device(pb.lcg_input(B, C, True))
     y = torch.zeros((B, C), dtype=torch.float32, device="cuda")
     for _ in range(3):
         r.run_block_device(x.data_ptr(), C, C, y.data_ptr(), C, 0, B)

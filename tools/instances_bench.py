@@ -13,6 +13,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from avdsp_amd import progbuilder as pb      # noqa: E402
+from avdsp_amd import devmem as dm
 from avdsp_amd import runtime as rt          # noqa: E402
 
 ap = argparse.ArgumentParser()
@@ -37,12 +38,12 @@ if args.synth:
     for n in args.instances:
         r = rt.Runtime(fmt, prog)
         r.set_instances(n)
-        x = torch.from_numpy(x1).cuda().unsqueeze(0).repeat(n, 1, 1).contiguous()
+        x = dm.to_device(x1).unsqueeze(0).repeat(n, 1, 1).contiguous()
         y = torch.zeros((n, B, Cc), dtype=x.dtype, device="cuda")
         st = torch.cuda.current_stream().cuda_stream
         run = lambda: r.run_block_all_instances_device(x.data_ptr(), Cc, Cc, B * Cc, y.data_ptr(), Cc, 0, B * Cc, B, st)
         run(); torch.cuda.synchronize()
-        got = y.cpu().numpy()
+        got = dm.to_host(y)
         ok = all((got[i].view(np.uint32) == want.view(np.uint32)).all() for i in sorted({0, n // 2, n - 1}))
         for _ in range(5):
             run()
@@ -68,12 +69,12 @@ r0.release()
 for n in args.instances:
     r = rt.Runtime(2, prog, fs=48000, random=3, dither=24)
     r.set_instances(n)
-    x = torch.from_numpy(x1).cuda().unsqueeze(0).repeat(n, 1, 1).contiguous()
+    x = dm.to_device(x1).unsqueeze(0).repeat(n, 1, 1).contiguous()
     y = torch.zeros((n, B, OUT_STRIDE), dtype=x.dtype, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
     run = lambda: r.run_block_all_instances_device(x.data_ptr(), IN_STRIDE, IN_BASE, B * IN_STRIDE, y.data_ptr(), OUT_STRIDE, OUT_BASE, B * OUT_STRIDE, B, st)
     run(); torch.cuda.synchronize()
-    got = y.cpu().numpy()
+    got = dm.to_host(y)
     ok = all((got[i].view(np.uint32) == want.view(np.uint32)).all() for i in sorted({0, n // 2, n - 1}))
     for _ in range(2):
         run()

@@ -12,6 +12,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from avdsp_amd import progbuilder as pb      # noqa: E402
+from avdsp_amd import devmem as dm
 from avdsp_amd import runtime as rt          # noqa: E402
 
 ap = argparse.ArgumentParser()
@@ -28,7 +29,7 @@ for fmt in (3, 5):
         r = rt.Runtime(fmt, pb.synth_program(fmt, C, S, T))
         r.set_option("lane_hw", args.lane_hw)
         info = r.shard_info()
-        x = torch.from_numpy(np.ascontiguousarray(pb.lcg_input(B, C, fmt == 5))).cuda()
+        x = dm.to_device(np.ascontiguousarray(pb.lcg_input(B, C, fmt == 5)))
         y = torch.zeros((B, C), dtype=x.dtype, device="cuda")
         run = lambda: r.run_block_device(x.data_ptr(), C, info["in_io_min"], y.data_ptr(), C, info["out_io_min"], B, 0)
         run(); torch.cuda.synchronize()

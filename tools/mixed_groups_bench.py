@@ -6,6 +6,7 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from avdsp_amd import runtime as rt, encoder as enc, progbuilder as pb
+from avdsp_amd import devmem as dm
 
 def program(counts, per):
     """len(counts) * per chains: chain c has counts[c % len(counts)] peaking filters; inputs IO n .. 2n-1, outputs 0 .. n-1"""
@@ -27,7 +28,7 @@ for counts, per in (([8], 1024), ([2, 4, 6, 8], 256), ([1, 2, 3, 4, 5, 6, 7, 8],
     prog, n = program(counts, per)
     r = rt.Runtime(6, prog)
     B = 1024
-    x = torch.from_numpy(pb.lcg_input(B, n, True, seed=1)).cuda(); y = torch.zeros((B, n), dtype=x.dtype, device="cuda")
+    x = dm.to_device(pb.lcg_input(B, n, True, seed=1)); y = torch.zeros((B, n), dtype=x.dtype, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
     for _ in range(5): r.run_block_device(x.data_ptr(), n, n, y.data_ptr(), n, 0, B, st)
     torch.cuda.synchronize(); t0 = time.perf_counter()

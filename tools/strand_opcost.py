@@ -17,6 +17,7 @@ import ctypes as C
 import numpy as np
 import torch
 from avdsp_amd import encoder as enc, progbuilder as pb, runtime as rt
+from avdsp_amd import devmem as dm
 from tests.fuzz_programs import _prototypes
 
 FPEAK, F48000 = 74, 5
@@ -49,7 +50,7 @@ def program(nch, fmt, upto):
 
 nch, frames = 128, 4096
 for fmt in (2, 6):
-    x = torch.from_numpy(pb.lcg_input(frames, nch, fmt == 6, seed=1)).cuda()
+    x = dm.to_device(pb.lcg_input(frames, nch, fmt == 6, seed=1))
     y = torch.zeros((frames, nch), dtype=x.dtype, device="cuda")
     prev = 0.0
     for upto, name in enumerate(STEPS):

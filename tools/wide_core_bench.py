@@ -7,6 +7,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 from avdsp_amd import encoder as enc, progbuilder as pb, runtime as rt
+from avdsp_amd import devmem as dm
 from tests.fuzz_programs import _prototypes
 
 FPEAK, F48000 = 74, 5
@@ -43,7 +44,7 @@ for fmt in args.fmt:
         in_base = max(128, nch)
         prog = program(nch, fmt, in_base)
         frames = 4096 if nch <= 100 else 1024
-        x = torch.from_numpy(pb.lcg_input(frames, nch, fmt == 6, seed=1)).cuda()
+        x = dm.to_device(pb.lcg_input(frames, nch, fmt == 6, seed=1))
         y = torch.zeros((frames, nch), dtype=x.dtype, device="cuda")
         res = {}
         for split in (2, 1, 0):                                   # 2: strand runs on lanes (the default); 1: strand groups through the interpreter; 0: the core whole
