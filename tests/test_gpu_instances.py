@@ -205,7 +205,7 @@ def test_cfg2_shaped_program_in_512_instances_is_the_golden_vector_512_times():
     r.release()
 
 
-@pytest.mark.parametrize("fmt,C,S,T,ninst", [(6, 8, 8, 0, 64), (2, 8, 8, 0, 64), (4, 5, 3, 0, 7), (6, 3, 2, 300, 9), (6, 4, 0, 64, 5), (5, 6, 4, 0, 6), (3, 4, 2, 33, 5)])
+@pytest.mark.parametrize("fmt,C,S,T,ninst", [(6, 8, 8, 0, 64), (2, 8, 8, 0, 64), (4, 5, 3, 0, 7), (6, 3, 2, 300, 9), (6, 4, 0, 64, 5), (5, 6, 4, 0, 6), (3, 4, 2, 33, 5), (6, 2, 70, 0, 3), (2, 3, 130, 0, 2)])
 def test_chain_instances_each_match_the_oracle(fmt, C, S, T, ninst):
     """inputs of their own per instance, ragged blocks (the distance between the instances' blocks changes with the block: the plans are
     re-made, the instances' states -- cascade words and FIR histories -- live on); int64, the double models, the float-accumulator
@@ -219,6 +219,16 @@ def test_chain_instances_under_the_overlap_mode():
     """cascade + FIR chains in instances with the cascade of the next block under the FIR of this one"""
     prog = pb.synth_program(6, 6, 4, 500)
     r = _chain_instances_vs_oracle(6, prog, 6, 12, [1024, 1024, 512, 1024], options={"overlap": 1})
+    r.release()
+
+
+@pytest.mark.parametrize("ready_words", [-1, 0, 1, 2])
+def test_long_cascades_in_pieces_under_the_overlap_mode(ready_words):
+    """70 sections in front of a 300-tap FIR: the cascade runs as two pieces (more than 64 sections do not fit a wave), on the cascades'
+    stream, under the previous block's FIR; only the LAST piece's launch appends to the rings and publishes the chains' ready words"""
+    prog = pb.synth_program(6, 3, 70, 300)
+    r = _chain_instances_vs_oracle(6, prog, 3, 1, [1024, 1024, 1024, 333, 1024], options={"overlap": 1, "ready_words": ready_words})
+    r.set_option("ready_words", -1); r.set_option("overlap", 0)
     r.release()
 
 
