@@ -32,6 +32,7 @@
  */
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <atomic>
 #include <chrono>
 #include <mutex>
 #include <thread>
@@ -3406,6 +3407,15 @@ __global__ __launch_bounds__(256) void fir_lane_hw(const LaneArgs a)
     }
 }
 
+/* dspRuntime_N, one frame per call: the host's wait for the frame.  hipDeviceSynchronize() costs a trip through the runtime's completion signal
+ * (an interrupt and a wake-up) per call; this one-thread kernel behind the frame's kernels writes the call's number into pinned host memory
+ * instead -- the kernels in front of it have completed, their stores into the same pinned area are visible -- and the host looks at that
+ * word in its own memory (avdsp_hip_run_block_host). */
+__global__ void frame_done(unsigned *flag, unsigned seq)
+{
+    __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 /* ------------------------------------------------------------------------------------------
  * host side of the thin ABI
  * ---------------------------------------------------------------------------------------- */
@@ -3477,6 +3487,8 @@ struct avdsp_hip_prog {
     int inst_frame_words = 0, inst_seq_frames = 0;
     static constexpr int kSmallWords = 4096;             /* host calls of up to that many sample words (dspRuntime_N) ... */
     unsigned *h_small = nullptr, *d_small = nullptr;     /* ... go through a pinned area the kernels access in place */
+    unsigned *done_offer = nullptr; bool done_taken = false;      /* ... offered to the frame's own kernel where that is ONE wave (interp_core) */
+    unsigned small_seq = 0;                               /* ... whose last 16 words hold the "frame done" word a kernel behind the frame's kernels sets (frame_done) */
     /* optional per-kernel timing with HIP events on the launch stream (avdsp_hip_profile_*) */
     int num_cus = 0;                    /* compute units of the device (fir_stream's grid) */
     unsigned profile = 0;               /* bit k: time the launches of kind k (AVDSP_KERNEL_*) */
@@ -5000,6 +5012,7 @@ static int launch_generic(avdsp_hip_prog *prog, Plan &pl, BlockIO io, hipStream_
         return 0;
     }
     ProfileScope scope(prog, stream, AVDSP_KERNEL_GENERIC); scope.begin();
+    if (prog->done_offer) { a.done_flag = prog->done_offer; a.done_seq = prog->small_seq; prog->done_taken = true; }      /* (the single-frame call's wait) */
 #define AVDSP_LAUNCH_INTERP(F) \
     if (pl.ga_staged) hipLaunchKernelGGL((interp_core<F, true>), grid, block, pl.ga_lds, stream, a); \
     else              hipLaunchKernelGGL((interp_core<F, false>), grid, block, pl.ga_lds, stream, a)
@@ -5336,15 +5349,35 @@ int avdsp_hip_run_block_host(avdsp_hip_prog *prog, int plan, const void *h_in, i
      * pinned area the kernels read and write in place over PCIe -- a handful of words each way. */
     if (in_words + out_words <= avdsp_hip_prog::kSmallWords) {
         if (!prog->h_small) {
-            HIP_TRY(hipHostMalloc((void **)&prog->h_small, (size_t)avdsp_hip_prog::kSmallWords * 4, hipHostMallocMapped));
+            HIP_TRY(hipHostMalloc((void **)&prog->h_small, (size_t)(avdsp_hip_prog::kSmallWords + 16) * 4, hipHostMallocMapped));
             HIP_TRY(hipHostGetDevicePointer((void **)&prog->d_small, prog->h_small, 0));
+            prog->h_small[avdsp_hip_prog::kSmallWords] = 0; prog->small_seq = 0;
         }
         unsigned *hi = prog->h_small, *ho = prog->h_small + in_words;
         memcpy(hi, h_in, in_words * 4);
         memcpy(ho, h_out, out_words * 4);                   /* unstored slots keep their content */
-        if (avdsp_hip_run_block(prog, plan, prog->d_small, in_stride, in_io_base, prog->d_small + in_words, out_stride, out_io_base,
-                                nframes, fir_impl, biquad_impl, nullptr)) return -1;
-        HIP_TRY(hipDeviceSynchronize());
+        static const int flag_us = getenv("AVDSP_SMALL_FLAG") ? atoi(getenv("AVDSP_SMALL_FLAG")) : 2000;
+        const bool use_flag = flag_us > 0 && !prog->overlap;
+        if (use_flag) { ++prog->small_seq; prog->done_offer = prog->d_small + avdsp_hip_prog::kSmallWords; prog->done_taken = false; }
+        const int rc_run = avdsp_hip_run_block(prog, plan, prog->d_small, in_stride, in_io_base, prog->d_small + in_words, out_stride, out_io_base,
+                                               nframes, fir_impl, biquad_impl, nullptr);
+        prog->done_offer = nullptr;
+        if (rc_run) return -1;
+        /* the wait: the "frame done" word (frame_done above) -- not under the overlap mode, whose kernels are on streams of their own */
+        bool seen = false;
+        if (use_flag) {
+            const unsigned seq = prog->small_seq;
+            if (!prog->done_taken) {                         /* (the frame's kernels are several, or of a kind that does not set the word itself) */
+                hipLaunchKernelGGL(frame_done, dim3(1), dim3(1), 0, nullptr, prog->d_small + avdsp_hip_prog::kSmallWords, seq);
+                HIP_TRY(hipGetLastError());
+            }
+            volatile unsigned *flag = prog->h_small + avdsp_hip_prog::kSmallWords;
+            const auto t0 = std::chrono::steady_clock::now();
+            for (unsigned spins = 0; !(seen = *flag == seq); spins++)
+                if ((spins & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(flag_us)) break;
+            std::atomic_thread_fence(std::memory_order_acquire);
+        }
+        if (!seen) HIP_TRY(hipDeviceSynchronize());        /* (a long frame, or no word: the runtime's own wait) */
         READY_CHECK(prog);
         memcpy(h_out, ho, out_words * 4);
         return 0;
