@@ -493,3 +493,40 @@ def test_kernel_timers_sample_every_nth_launch():
         r.run_block(x, C, C)
     assert r.kernel_time(1)[1] == 3
     r.set_option("profile", 0)
+
+
+# ---------------------------------------------------------------------------------------------
+# pageable buffers of 1 MB and more go through the library's pinned chunks (avdsp_kernels.hip copy_from_caller / copy_to_caller)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("frames", [1021, 2051])
+def test_pageable_blocks_of_odd_sizes_cross_in_chunks(frames):
+    """blocks whose bytes are no multiple of the 4-MB chunk (and, 2051 frames, more than two chunks each way, several 1024-frame launches)
+    through dspRuntimeBlock_N with ordinary numpy buffers -- and through buffers the CALLER has pinned (torch's pinned allocator), which the
+    library recognises and copies without the detour: both the oracle's bits; then the state area (1.3 MB: the FIR histories) up and down"""
+    torch = pytest.importorskip("torch")
+    C, S, T = 1027, 2, 320
+    prog = pb.synth_program(6, C, S, T)
+    x = pb.lcg_input(frames, C, True, seed=frames)
+    o = po.OracleProgram(6, prog)
+    want = o.run_block(x, C, C)
+    r = rt.Runtime(6, prog)
+    got = r.run_block(x, C, C)
+    assert (got.view(np.uint32) == want.view(np.uint32)).all()
+    assert (r.sync_state() == o.state).all()
+    r.release()
+    xp = torch.empty(x.shape, dtype=torch.float32, pin_memory=True); xp.numpy()[:] = x
+    yp = torch.zeros((frames, C), dtype=torch.float32, pin_memory=True)
+    r = rt.Runtime(6, prog)
+    got = r.run_block(xp.numpy(), C, C, out=yp.numpy())
+    assert (got.view(np.uint32) == want.view(np.uint32)).all()
+    # state up and down: what the host writes into the data area arrives, byte for byte, and comes back
+    st = r.sync_state()
+    assert st.nbytes > (1 << 20)
+    rng = np.random.default_rng(5)
+    pattern = rng.integers(0, 1 << 31, size=st.size, dtype=np.int64).astype(st.dtype)
+    pattern &= 0x3FFFFFFF                                    # (finite floats, small ints: whatever a later block makes of them is not looked at)
+    st[:] = pattern
+    r.upload_state()
+    st[:] = 0
+    assert (r.sync_state() == pattern).all()
+    r.release()
