@@ -3685,7 +3685,7 @@ void free_plan(Plan &p)
     (void)hipFree(p.d_chains); (void)hipFree(p.d_sec_coef); (void)hipFree(p.d_sec_state);
     for (auto &g : p.bq) {
         (void)hipFree(g.d_ids); (void)hipFree(g.d_rows); (void)hipFree(g.d_lanes); (void)hipFree(g.d_scratch[0]); (void)hipFree(g.d_scratch[1]);
-        for (auto &pc : g.pieces) (void)hipFree(pc.d_ids);
+        for (auto &pc : g.pieces) { (void)hipFree(pc.d_ids); (void)hipFree(pc.d_rows); (void)hipFree(pc.d_lanes); }
     }
     (void)hipFree(p.d_rows_all); (void)hipFree(p.d_lanes_all);
     (void)hipFree(p.d_sops); (void)hipFree(p.d_sargs); (void)hipFree(p.d_lseq); (void)hipFree(p.d_lane_rows);
@@ -4483,13 +4483,18 @@ int avdsp_hip_prog_add_plan(avdsp_hip_prog *prog, const avdsp_plan_desc *d)
         for (int id : e.second) all_fir = all_fir && chains[id].fir_taps != 0;
         Plan::Group g{P, e.first, (int)e.second.size(), nullptr, all_fir, nullptr, nullptr};
         if (upload_vec(&g.d_ids, e.second)) { free_plan(pl); return -1; }
-        if (e.first > 64) {
+        /* ... and in format 6 every cascade of more than 16 sections runs as pieces of up to 16, each a biquad_row launch: the word between two
+         * sections is a float there and a plain LOAD / STORE pair moves it unchanged, so biquad_row takes the pieces as they are; a 16-lane row
+         * per chain wastes no lanes on lengths like 17 or 33 (biquad_pipe: 32 / 64 lanes per chain) and its step is the shorter one --
+         * 4096 chains x 17 / 33 / 48 / 65 / 200 sections: see DESIGN.md 4.1.  (Formats 2 and 4: pieces only beyond 64 sections, through biquad_pipe.) */
+        const int piece_max = d->format == 6 ? 16 : 64;
+        if (e.first > piece_max) {
             /* A cascade of more than 64 sections does not fit a wave's lanes.  biquad_simple (a lane per chain, state in memory) took 81 ms
              * for 4096 chains x 65 sections against 136 us for 64: the chain is CUT instead, into pieces of equal length (+- 1) that run as
              * launches of biquad_pipe one after the other.  The pieces but the last are chain records of their own behind the host's
              * (no FIR, no SAT0DB, one raw store into the scratch column); the last piece is the chain's own record with its input moved
              * to the scratch column (its ring, stores and ready word are the chain's). */
-            const int np = (e.first + 63) / 64, base = e.first / np, extra = e.first % np, n = (int)e.second.size();
+            const int np = (e.first + piece_max - 1) / piece_max, base = e.first / np, extra = e.first % np, n = (int)e.second.size();
             int at = 0;
             for (int k = 0; k < np; k++) {
                 const int len = base + (k < extra ? 1 : 0);
@@ -4504,18 +4509,31 @@ int avdsp_hip_prog_add_plan(avdsp_hip_prog *prog, const avdsp_plan_desc *d)
                         ids[j] = (int)dev_chains.size(); dev_chains.push_back(pc);
                     } else { ids[j] = e.second[j]; dev_chains[e.second[j]] = pc; }
                 }
-                Plan::Group pg{pow2ceil(len), len, n, nullptr, k + 1 == np && all_fir, nullptr, nullptr};
-                if (upload_vec(&pg.d_ids, ids)) { (void)hipFree(g.d_ids); for (auto &x : g.pieces) (void)hipFree(x.d_ids); free_plan(pl); return -1; }
+                Plan::Group pg{len <= 16 ? 16 : pow2ceil(len), len, n, nullptr, k + 1 == np && all_fir, nullptr, nullptr};
+                auto drop = [&]() { (void)hipFree(g.d_ids); (void)hipFree(pg.d_ids); (void)hipFree(pg.d_rows); (void)hipFree(pg.d_lanes);
+                                    for (auto &x : g.pieces) { (void)hipFree(x.d_ids); (void)hipFree(x.d_rows); (void)hipFree(x.d_lanes); } free_plan(pl); };
+                if (upload_vec(&pg.d_ids, ids)) { drop(); return -1; }
+                if (pg.P == 16) {                        /* biquad_row's records of the piece (format 6: kLoadRaw reads as a plain load there, and is one) */
+                    std::vector<RowRec> rows(n);
+                    std::vector<LaneRec> lanes((size_t)n * 16, LaneRec{-1, -1});
+                    for (int j = 0; j < n; j++) {
+                        const avdsp_chain &c = dev_chains[ids[j]];
+                        rows[j] = RowRec{ids[j], c.in_io, c.out_io[0], (c.load_mode & 0xFF) | (c.sat == 1 ? 1 << 8 : 0) | (c.fir_taps ? 1 << 9 : 0) | (c.n_out << 16),
+                                         c.gain_bits, {c.nsec, 0, 0}};
+                        for (int q = 0; q < c.nsec; q++) lanes[(size_t)j * 16 + (16 - c.nsec) + q] = LaneRec{coef[c.sec_base + q], state[c.sec_base + q]};
+                    }
+                    if (upload_vec(&pg.d_rows, rows) || upload_vec(&pg.d_lanes, lanes)) { drop(); return -1; }
+                }
                 g.pieces.push_back(pg);
                 at += len;
             }
             for (int k = 0; k < 2; k++)
                 if (hipMalloc((void **)&g.d_scratch[k], (size_t)kFirChunk * n * sizeof(unsigned)) != hipSuccess) {
-                    (void)hipFree(g.d_ids); (void)hipFree(g.d_scratch[0]); for (auto &x : g.pieces) (void)hipFree(x.d_ids); free_plan(pl);
+                    (void)hipFree(g.d_ids); (void)hipFree(g.d_scratch[0]); for (auto &x : g.pieces) { (void)hipFree(x.d_ids); (void)hipFree(x.d_rows); (void)hipFree(x.d_lanes); } free_plan(pl);
                     return set_err("hipMalloc(scratch of %d long cascades)", n);
                 }
         }
-        if (P == 16) {                                   /* what biquad_row loads instead of walking group -> chain -> section tables */
+        if (P == 16 && g.pieces.empty()) {               /* what biquad_row loads instead of walking group -> chain -> section tables */
             std::vector<RowRec> rows(e.second.size());
             std::vector<LaneRec> lanes(e.second.size() * 16, LaneRec{-1, -1});
             for (size_t i = 0; i < e.second.size(); i++) {
