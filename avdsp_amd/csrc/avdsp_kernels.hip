@@ -903,7 +903,7 @@ __global__ __launch_bounds__(kBlock) void biquad_row(const BiquadArgs a)
 
     unsigned *mylin = &lin[wv][0][row][0];
     typedef unsigned u4 __attribute__((ext_vector_type(4)));
-    auto stage = [&](int buf, unsigned raw) __attribute__((always_inline)) { mylin[buf * 64 + rp] = hand_from_sample<FMT>(raw, c_load_mode, c_gain_bits).y; };
+    auto stage = [&](int buf, unsigned raw) __attribute__((always_inline)) { mylin[buf * 64 + rp] = hand_from_sample_or_raw<FMT>(raw, c_load_mode, c_gain_bits).y; };      /* (kLoadRaw: a piece of a longer cascade) */
     auto take = [&](int buf, unsigned (&x)[16]) __attribute__((always_inline)) {
         const u4 *p = reinterpret_cast<const u4 *>(mylin + buf * 64);
 #pragma unroll
@@ -1215,6 +1215,7 @@ __global__ __launch_bounds__(kBlock) void biquad_row_i64(const BiquadArgs a)
     const int cid = rr.cid;
     const int c_load_mode = rr.flags & 0xFF; const unsigned c_gain_bits = rr.gain_bits;
     const unsigned sh = (rr.flags >> 8 & 1) ? 28u : 0u;          /* SAT0DB: the stored word is acc >> 28 (saturate64_031 of an accumulator the cascade has clamped already), else acc's low word */
+    const unsigned omask = (rr.flags >> 10 & 1) ? 0xFFFFFFFFu : (unsigned)io_l.store_mask;      /* (bit 10, with bit 8: kStoreRaw -- a piece hands acc >> 28 on as it is) */
     const unsigned long long firstmask = 0x0001000100010001ull << (15 - L);
 
     const char *in_bytes = reinterpret_cast<const char *>(io_l.in);
@@ -1239,7 +1240,7 @@ __global__ __launch_bounds__(kBlock) void biquad_row_i64(const BiquadArgs a)
     }
     unsigned *mylin = &lin[wv][0][row][0];
     typedef unsigned u4 __attribute__((ext_vector_type(4)));
-    auto stage = [&](int buf, unsigned raw) __attribute__((always_inline)) { mylin[buf * 64 + rp] = hand_from_sample<2>(raw, c_load_mode, c_gain_bits).y; };
+    auto stage = [&](int buf, unsigned raw) __attribute__((always_inline)) { mylin[buf * 64 + rp] = hand_from_sample_or_raw<2>(raw, c_load_mode, c_gain_bits).y; };
     auto take = [&](int buf, unsigned (&x)[16]) __attribute__((always_inline)) {
         const u4 *p = reinterpret_cast<const u4 *>(mylin + buf * 64);
 #pragma unroll
@@ -1255,7 +1256,7 @@ __global__ __launch_bounds__(kBlock) void biquad_row_i64(const BiquadArgs a)
     const bool q1 = (rp & 1) != 0, q2 = (rp & 2) != 0;
     auto pick = [&](unsigned d0, unsigned d1, unsigned d2, unsigned d3) __attribute__((always_inline)) -> unsigned {
         const unsigned lo = q1 ? d1 : d0, hi = q1 ? d3 : d2;
-        return (q2 ? hi : lo) & (unsigned)io_l.store_mask;
+        return (q2 ? hi : lo) & omask;
     };
     auto flush = [&](int u0, unsigned w) __attribute__((always_inline)) {
         const int n = u0 + rp - (1 + 2 * L);
@@ -3436,7 +3437,8 @@ struct Plan {
                    /* more than 64 sections (round 5): the group as pieces of up to 64, launched one after the other; piece k hands the
                     * word between its last section and piece k + 1's first through column j (the chain's place in the group) of
                     * d_scratch[k & 1], [1024 frames][n] words (kLoadRaw / kStoreRaw) */
-                   std::vector<Group> pieces = {}; unsigned *d_scratch[2] = {nullptr, nullptr}; };
+                   std::vector<Group> pieces = {}; unsigned *d_scratch[2] = {nullptr, nullptr};
+                   bool raw_out = false; };      /* a piece but the last: it stores its last section's result word as it is (biquad_row<4> can) */
     /* round 5: the rows of ALL the plan's 16-lane groups in one table -- runs of one section count, each filled up to whole waves (four
      * rows) with empty rows, the table to whole workgroups -- for ONE biquad_row launch instead of one per section count (nsec 0 in its
      * arguments: every wave takes its rows' count from their records).  Only made when there are two such groups or more. */
@@ -3814,7 +3816,7 @@ int launch_biquad(avdsp_hip_prog *prog, Plan &pl, const Plan::Group &g, const in
         scope.begin();
         hipLaunchKernelGGL(biquad_simple<FMT>, dim3((n + 63) / 64), dim3(64), 0, stream, a);
         if (stop) HIP_TRY(hipEventRecord(stop, stream));
-    } else if (biquad_impl == 1 && g.P == 16 && g.d_rows && (FMT == 2 || FMT == 6 || (FMT == 4 && g.all_fir))) {
+    } else if (biquad_impl == 1 && g.P == 16 && g.d_rows && (FMT == 2 || FMT == 6 || (FMT == 4 && (g.all_fir || g.raw_out)))) {
         /* one 16-lane row per chain: biquad_row (format 4 only where the cascade feeds a FIR -- a format-4 STORE needs all of the
          * accumulator, biquad_row hands on its float), biquad_row_i64 */
         if constexpr (FMT == 2) {
@@ -4487,7 +4489,7 @@ int avdsp_hip_prog_add_plan(avdsp_hip_prog *prog, const avdsp_plan_desc *d)
          * sections is a float there and a plain LOAD / STORE pair moves it unchanged, so biquad_row takes the pieces as they are; a 16-lane row
          * per chain wastes no lanes on lengths like 17 or 33 (biquad_pipe: 32 / 64 lanes per chain) and its step is the shorter one --
          * 4096 chains x 17 / 33 / 48 / 65 / 200 sections: see DESIGN.md 4.1.  (Formats 2 and 4: pieces only beyond 64 sections, through biquad_pipe.) */
-        const int piece_max = d->format == 6 ? 16 : 64;
+        const int piece_max = 16;
         if (e.first > piece_max) {
             /* A cascade of more than 64 sections does not fit a wave's lanes.  biquad_simple (a lane per chain, state in memory) took 81 ms
              * for 4096 chains x 65 sections against 136 us for 64: the chain is CUT instead, into pieces of equal length (+- 1) that run as
@@ -4510,6 +4512,7 @@ int avdsp_hip_prog_add_plan(avdsp_hip_prog *prog, const avdsp_plan_desc *d)
                     } else { ids[j] = e.second[j]; dev_chains[e.second[j]] = pc; }
                 }
                 Plan::Group pg{len <= 16 ? 16 : pow2ceil(len), len, n, nullptr, k + 1 == np && all_fir, nullptr, nullptr};
+                pg.raw_out = k + 1 < np;
                 auto drop = [&]() { (void)hipFree(g.d_ids); (void)hipFree(pg.d_ids); (void)hipFree(pg.d_rows); (void)hipFree(pg.d_lanes);
                                     for (auto &x : g.pieces) { (void)hipFree(x.d_ids); (void)hipFree(x.d_rows); (void)hipFree(x.d_lanes); } free_plan(pl); };
                 if (upload_vec(&pg.d_ids, ids)) { drop(); return -1; }
@@ -4518,8 +4521,11 @@ int avdsp_hip_prog_add_plan(avdsp_hip_prog *prog, const avdsp_plan_desc *d)
                     std::vector<LaneRec> lanes((size_t)n * 16, LaneRec{-1, -1});
                     for (int j = 0; j < n; j++) {
                         const avdsp_chain &c = dev_chains[ids[j]];
-                        rows[j] = RowRec{ids[j], c.in_io, c.out_io[0], (c.load_mode & 0xFF) | (c.sat == 1 ? 1 << 8 : 0) | (c.fir_taps ? 1 << 9 : 0) | (c.n_out << 16),
-                                         c.gain_bits, {c.nsec, 0, 0}};
+                        /* bit 8: SAT0DB in front of the store -- in the int64 kernel "the stored word is acc >> 28", which is also what a piece
+                         * hands on (bit 10 then takes the dither mask off); in the double kernels a piece's word is the float as it is: no bit 8 */
+                        const bool raw = c.sat == kStoreRaw;
+                        rows[j] = RowRec{ids[j], c.in_io, c.out_io[0], (c.load_mode & 0xFF) | ((c.sat == 1 || (raw && d->format == 2)) ? 1 << 8 : 0) | (c.fir_taps ? 1 << 9 : 0) |
+                                         (raw ? 1 << 10 : 0) | (c.n_out << 16), c.gain_bits, {c.nsec, 0, 0}};
                         for (int q = 0; q < c.nsec; q++) lanes[(size_t)j * 16 + (16 - c.nsec) + q] = LaneRec{coef[c.sec_base + q], state[c.sec_base + q]};
                     }
                     if (upload_vec(&pg.d_rows, rows) || upload_vec(&pg.d_lanes, lanes)) { drop(); return -1; }
