@@ -118,13 +118,17 @@ __device__ __forceinline__ unsigned ftz_bits(unsigned u) { return (u & 0x7F80000
  * the reference's 7-step normaliser one step short: mantissa 0, exponent 126, i.e. -0.5.       */
 __device__ __forceinline__ float int_to_float_scaled31(int x)
 {
-    if (x == 0) return 0.0f;
-    unsigned sign = x < 0 ? 0x80000000u : 0u;
-    unsigned mag = x < 0 ? 0u - (unsigned)x : (unsigned)x;
-    if (mag == 0x80000000u) return __uint_as_float(sign | (126u << 23));
-    int p = 31 - __clz((int)mag);
-    mag = p > 23 ? mag >> (p - 23) : mag << (23 - p);
-    return __uint_as_float(sign | ((unsigned)(127 + p - 31) << 23) | (mag & 0x7FFFFFu));
+    /* without a branch (round 5: the cascade's row kernel stages a sample per lane and batch through here, and three branches cost it more
+     * than the conversion -- format 4's 4096 x 16 cascade in front of a FIR 13 us of 118): the magnitude normalised to bit 31, its top 24 bits
+     * the mantissa (truncated), 127 - the leading zeros the exponent.  All 2^32 arguments compared with the branching form on the CPU. */
+    const unsigned sign = (unsigned)x & 0x80000000u;
+    const unsigned mag = x < 0 ? 0u - (unsigned)x : (unsigned)x;
+    const unsigned lz = (unsigned)__clz((int)mag);                                   /* (32 for 0: the result is replaced below) */
+    const unsigned norm = mag << (lz & 31u);
+    unsigned r = sign | ((127u - lz) << 23) | ((norm >> 8) & 0x7FFFFFu);
+    r = mag == 0x80000000u ? (sign | (126u << 23)) : r;
+    r = x == 0 ? 0u : r;
+    return __uint_as_float(r);
 }
 
 /* dsp_ieee754.h:253-298: exact x * 2^-31; INT_MIN mirrors the value the reference's -Ofast build
@@ -191,7 +195,7 @@ __device__ __forceinline__ typename Alu<FMT>::type load_stage(unsigned raw, int 
         return mode == AVDSP_LOAD_GAIN ? s * (long long)(int)gain_bits : s;          /* :571, :593 */
     } else if constexpr (FMT == 4) {
         if (mode == AVDSP_LOAD_GAIN)                                                  /* :596-598 */
-            return mulop(int_to_float_scaled31((int)raw)) * mulop(__uint_as_float(gain_bits));
+            return (double)int_to_float_scaled31((int)raw) * mulop(__uint_as_float(gain_bits));      /* (the sample's float is zero or normal: mulop() of it is its widening) */
         return int_to_double_scaled31((int)raw);                                      /* :575 */
     } else {
         double x = widen_f32(__uint_as_float(raw));                                   /* :580, :603-604 */
@@ -219,6 +223,24 @@ __device__ __forceinline__ unsigned store_stage(typename Alu<FMT>::type X, int s
         if constexpr (FMT == 4) return (unsigned)(s31_from_double(X) & mask);         /* :622-627 */
         else return __float_as_uint(narrow_f32(X));                                   /* :629-630 */
     }
+}
+
+/* store_stage<4> without a branch (biquad_row's ACC form converts once per 16 steps, every lane: three taken branches there cost as much as
+ * the conversion): [saturate_double_0db], s31_from_double -- whose int result is the low word of +-(m >> (n & 63)) --, the dither mask */
+__device__ __forceinline__ unsigned store_word_f4(double X, bool sat, int mask)
+{
+    long long u = __double_as_longlong(X);
+    const int se = (int)(u >> 52);                                                    /* sign and exponent, sign-extended */
+    const bool up = sat && se >= 1023, down = sat && se < 0 && se >= -1025;
+    u = up ? 0x3FF0000000000000ll : down ? (long long)0xBFF0000000000000ull : u;
+    const int e = (int)((u >> 52) & 2047);
+    const unsigned long long m = ((unsigned long long)u & 0xFFFFFFFFFFFFFull) | (1ull << 52);
+    const int n = 1044 - e;
+    unsigned w = (unsigned)(m >> (n & 63));
+    w = n > 21 ? w : 0x7FFFFFFFu;
+    w = e == 0 ? 0u : w;
+    w = u < 0 ? 0u - w : w;
+    return w & (unsigned)mask;
 }
 
 /* XCD-aware block index: hardware deals consecutive workgroups round-robin over the 8 XCDs, so
@@ -847,10 +869,17 @@ __global__ __launch_bounds__(kBlock) void biquad_pipe(const BiquadArgs a)
  *     the steps of the block's fill and drain run the same instructions under EXEC masks with the moves spelled out.
  * Measured (tools/cascade_lab.hip, 4096 chains x 16 sections x 1024 frames): 54 cycles per steady step against 95.
  * ---------------------------------------------------------------------------------------- */
-template <int FMT>
+/* ACC (format 4, round 5): chains that STORE int samples.  A format-4 STORE takes 31 bits out of the accumulator itself (s31_from_double), not out
+ * of the float the next section would get, so the row kernel -- which hands a float on -- was for FIR-feeding chains only and a plain format-4
+ * cascade ran on biquad_pipe (4096 chains x 16 sections: 75.5 us against 34.4 in format 6).  Here the step broadcasts the last section's finished
+ * ACCUMULATOR instead of its float -- one 64-bit v_mov_b64_dpp row_newbcast in place of the 32-bit one, in front of the next step's first product
+ * instead of behind it: the same ten instructions -- and a lane converts the accumulator it ends up holding once per 16 steps (store_word_f4, no
+ * branch).  4096 chains x 16 sections: 75.5 -> 46 us; the rest of the way to format 6's 34 is the int sample's two conversions. */
+template <int FMT, bool ACC = false>
 __global__ __launch_bounds__(kBlock) void biquad_row(const BiquadArgs a)
 {
     static_assert(FMT == 4 || FMT == 6, "double-accumulator models");
+    static_assert(!ACC || FMT == 4, "the accumulator leaves the cascade in format 4 only");
     flush_f32_subnormals_like_the_reference();
     BQ_STAMP(0);
     __shared__ __attribute__((aligned(16))) unsigned lin[4][2][4][16];
@@ -930,7 +959,7 @@ __global__ __launch_bounds__(kBlock) void biquad_row(const BiquadArgs a)
         if (have_chain && n >= 0 && n < B) {
             if (to_ring) ring_put(ring_l, cid, n, w, a.ready != nullptr);
             else {
-                const unsigned v = c_sat ? __float_as_uint(saturate_f32_0db(__uint_as_float(w))) : w;
+                const unsigned v = !ACC && c_sat ? __float_as_uint(saturate_f32_0db(__uint_as_float(w))) : w;      /* (ACC: w is the stored word already) */
                 if (one_store) io_l.out[(size_t)n * io_l.out_stride + (rr.out_io - io_l.out_base)] = v;     /* (the record has the column: no look at the chain) */
                 else {
                     const avdsp_chain oc = a.chains[cid];
@@ -1011,7 +1040,55 @@ __global__ __launch_bounds__(kBlock) void biquad_row(const BiquadArgs a)
             : [hy] "v"(hy), [c0] "v"(cd[0]), [c1] "v"(cd[1]), [c2] "v"(cd[2]), [c3] "v"(cd[3]), [c4] "v"(cd[4]), \
               [x0] "v"(x[k]), [x1] "v"(x[k + 1]), [x2] "v"(x[k + 2]), [x3] "v"(x[k + 3]), [m0] "s"(firstmask) \
             : "vcc")
+    /* ACC: what a lane's 64-bit pick becomes -- the ring's float (a FIR follows) or the int sample (SAT0DB, s31_from_double, dither mask) */
+    [[maybe_unused]] auto word_of_acc = [&](double d0, double d1, double d2, double d3) __attribute__((always_inline)) -> unsigned {
+        const double lo = q1 ? d1 : d0, hi = q1 ? d3 : d2;
+        const double X = q2 ? hi : lo;
+        const unsigned ringw = __float_as_uint(narrow_f32(X)), outw = store_word_f4(X, c_sat, io_l.store_mask);
+        return to_ring ? ringw : outw;
+    };
+/* (one 64-bit v_mov_b64_dpp row_newbcast; two 32-bit broadcasts of the halves -- the accumulator then pinned in v[2:3] like biquad_row_i64's --
+     * measured 2 us slower over cfg3's shape) */
+#define AVDSP_ROW_BCAST64(D, BM) "v_mov_b64_dpp %[" D "], %[an] row_newbcast:15 row_mask:0xf bank_mask:" BM "\n\t"
+    /* the same step with the finished accumulator broadcast (before the next step's first product goes into it) */
+#define AVDSP_ROW_STEP_ACC(X1, X2, YA, YB, XK, HY, O, D, BM) \
+        "v_cndmask_b32_dpp %[t" XK "], %[" HY "], %[" XK "], vcc" AVDSP_ROW_DPP \
+        "v_fma_f64 %[an], %[" X1 "], %[c1], %[an]\n\t" \
+        "v_fma_f64 %[an], %[" X2 "], %[c2], %[an]\n\t" \
+        "v_fma_f64 %[an], %[" YA "], %[c3], %[an]\n\t" \
+        "v_fma_f64 %[an], %[" YB "], %[c4], %[an]\n\t" \
+        "v_cvt_f64_f32 %[" X2 "], %[t" XK "]\n\t" \
+        "v_cvt_f32_f64 %[" O "], %[an]\n\t" \
+        AVDSP_ROW_BCAST64(D, BM) \
+        "v_fma_f64 %[an], %[" X2 "], %[c0], %[an]\n\t" \
+        "v_cvt_f64_f32 %[" YB "], %[" O "]\n\t"
+#define AVDSP_ROW_BLOCK4_ACC(BM) \
+        asm volatile( \
+            "s_mov_b64 vcc, %[m0]\n\t" \
+            AVDSP_ROW_STEP_ACC("xb", "xc", "ya", "yb", "x0", "hy", "o0", "d0", BM) \
+            AVDSP_ROW_STEP_ACC("xa", "xb", "yb", "ya", "x1", "o0", "o1", "d1", BM) \
+            AVDSP_ROW_STEP_ACC("xc", "xa", "ya", "yb", "x2", "o1", "o2", "d2", BM) \
+            AVDSP_ROW_STEP_ACC("xb", "xc", "yb", "ya", "x3", "o2", "o3", "d3", BM) \
+            : [an] "+v"(acc), [xa] "+v"(P), [xb] "+v"(dx1), [xc] "+v"(dx2), [ya] "+v"(dy1), [yb] "+v"(dy2), \
+              [tx0] "=&v"(t0), [tx1] "=&v"(t1), [tx2] "=&v"(t2), [tx3] "=&v"(t3), \
+              [o0] "=&v"(o0), [o1] "=&v"(o1), [o2] "=&v"(o2), [o3] "=&v"(o3), \
+              [d0] "+v"(e0), [d1] "+v"(e1), [d2] "+v"(e2), [d3] "+v"(e3) \
+            : [hy] "v"(hy), [c0] "v"(cd[0]), [c1] "v"(cd[1]), [c2] "v"(cd[2]), [c3] "v"(cd[3]), [c4] "v"(cd[4]), \
+              [x0] "v"(x[k]), [x1] "v"(x[k + 1]), [x2] "v"(x[k + 2]), [x3] "v"(x[k + 3]), [m0] "s"(firstmask) \
+            : "vcc")
     auto steady_steps = [&](const unsigned (&x)[16]) __attribute__((always_inline)) -> unsigned {
+        if constexpr (ACC) {
+            double e0, e1, e2, e3;
+            asm volatile("; e0..e3 start undefined" : "=v"(e0), "=v"(e1), "=v"(e2), "=v"(e3));
+#pragma unroll
+            for (int k = 0; k < 16; k += 4) {
+                unsigned t0, t1, t2, t3, o0, o1, o2, o3;
+                if (k == 0) AVDSP_ROW_BLOCK4_ACC("0x1"); else if (k == 4) AVDSP_ROW_BLOCK4_ACC("0x2"); else if (k == 8) AVDSP_ROW_BLOCK4_ACC("0x4"); else AVDSP_ROW_BLOCK4_ACC("0x8");
+                { const double t = P; P = dx2; dx2 = dx1; dx1 = t; }
+                hy = o3;
+            }
+            return word_of_acc(e0, e1, e2, e3);
+        }
         unsigned d0, d1, d2, d3;                          /* every lane of them is written by one of the four blocks: no initial value */
         asm volatile("; d0..d3 start undefined" : "=v"(d0), "=v"(d1), "=v"(d2), "=v"(d3));
 #pragma unroll
@@ -1053,7 +1130,51 @@ __global__ __launch_bounds__(kBlock) void biquad_row(const BiquadArgs a)
             : "vcc")
     /* section s computes frame u - 1 - 2 s in step u: active while 0 <= u - ustart < B */
     const unsigned ustart = lane_on ? (unsigned)(1 + 2 * sec) : 0x40000000u;
+    /* ... with the accumulator: a copy of it taken while the computing lanes are the active ones, broadcast once everybody is */
+#define AVDSP_ROW_EDGE_ACC(D, BM) \
+        asm volatile( \
+            "s_mov_b64 %[sv], exec\n\t" \
+            "s_mov_b64 vcc, %[m0]\n\t" \
+            "v_cndmask_b32_dpp %[t], %[hy], %[xk], vcc" AVDSP_ROW_DPP \
+            "s_mov_b64 exec, %[cm]\n\t" \
+            "v_fma_f64 %[an], %[x1], %[c1], %[an]\n\t" \
+            "v_fma_f64 %[an], %[x2], %[c2], %[an]\n\t" \
+            "v_fma_f64 %[an], %[y1], %[c3], %[an]\n\t" \
+            "v_fma_f64 %[an], %[y2], %[c4], %[an]\n\t" \
+            "v_cvt_f32_f64 %[hy], %[an]\n\t" \
+            "v_mov_b64 %[ac], %[an]\n\t" \
+            "v_mov_b64 %[x2], %[x1]\n\t" \
+            "v_mov_b64 %[x1], %[p]\n\t" \
+            "v_mov_b64 %[y2], %[y1]\n\t" \
+            "v_cvt_f64_f32 %[y1], %[hy]\n\t" \
+            "s_mov_b64 exec, %[cn]\n\t" \
+            "v_cvt_f64_f32 %[p], %[t]\n\t" \
+            "s_nop 0\n\t" \
+            "v_fma_f64 %[an], %[p], %[c0], %[an]\n\t" \
+            "s_mov_b64 exec, %[sv]\n\t" \
+            "v_mov_b64_dpp %[" D "], %[ac] row_newbcast:15 row_mask:0xf bank_mask:" BM "\n\t" \
+            : [an] "+v"(acc), [p] "+v"(P), [x1] "+v"(dx1), [x2] "+v"(dx2), [y1] "+v"(dy1), [y2] "+v"(dy2), [hy] "+v"(hy), [ac] "+v"(ac), \
+              [t] "=&v"(t), [sv] "=&s"(sv), [d0] "+v"(e0), [d1] "+v"(e1), [d2] "+v"(e2), [d3] "+v"(e3) \
+            : [c0] "v"(cd[0]), [c1] "v"(cd[1]), [c2] "v"(cd[2]), [c3] "v"(cd[3]), [c4] "v"(cd[4]), \
+              [xk] "v"(x[k]), [m0] "s"(firstmask), [cm] "s"(cm), [cn] "s"(cn) \
+            : "vcc")
     auto edge_steps = [&](int u0, const unsigned (&x)[16]) __attribute__((always_inline)) -> unsigned {
+        if constexpr (ACC) {
+            double e0 = 0, e1 = 0, e2 = 0, e3 = 0, ac = 0;
+            const unsigned ph = (unsigned)u0 - ustart;
+            unsigned long long cn = __ballot(ph < (unsigned)B);
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const unsigned long long cm = cn;
+                cn = __ballot(ph + (unsigned)(k + 1) < (unsigned)B);
+                unsigned t; unsigned long long sv;
+                if ((k & 3) == 0) { if (k == 0) AVDSP_ROW_EDGE_ACC("d0", "0x1"); else if (k == 4) AVDSP_ROW_EDGE_ACC("d0", "0x2"); else if (k == 8) AVDSP_ROW_EDGE_ACC("d0", "0x4"); else AVDSP_ROW_EDGE_ACC("d0", "0x8"); }
+                else if ((k & 3) == 1) { if (k == 1) AVDSP_ROW_EDGE_ACC("d1", "0x1"); else if (k == 5) AVDSP_ROW_EDGE_ACC("d1", "0x2"); else if (k == 9) AVDSP_ROW_EDGE_ACC("d1", "0x4"); else AVDSP_ROW_EDGE_ACC("d1", "0x8"); }
+                else if ((k & 3) == 2) { if (k == 2) AVDSP_ROW_EDGE_ACC("d2", "0x1"); else if (k == 6) AVDSP_ROW_EDGE_ACC("d2", "0x2"); else if (k == 10) AVDSP_ROW_EDGE_ACC("d2", "0x4"); else AVDSP_ROW_EDGE_ACC("d2", "0x8"); }
+                else { if (k == 3) AVDSP_ROW_EDGE_ACC("d3", "0x1"); else if (k == 7) AVDSP_ROW_EDGE_ACC("d3", "0x2"); else if (k == 11) AVDSP_ROW_EDGE_ACC("d3", "0x4"); else AVDSP_ROW_EDGE_ACC("d3", "0x8"); }
+            }
+            return word_of_acc(e0, e1, e2, e3);
+        }
         unsigned d0 = 0, d1 = 0, d2 = 0, d3 = 0;
         const unsigned ph = (unsigned)u0 - ustart;
         unsigned long long cn = __ballot(ph < (unsigned)B);
@@ -1160,6 +1281,10 @@ __global__ __launch_bounds__(kBlock) void biquad_row(const BiquadArgs a)
     BQ_STAMP(27);
     for (; b < nb; b++) batch_tail(b);
     BQ_STAMP(28);
+#undef AVDSP_ROW_EDGE_ACC
+#undef AVDSP_ROW_BLOCK4_ACC
+#undef AVDSP_ROW_STEP_ACC
+#undef AVDSP_ROW_BCAST64
 #undef AVDSP_ROW_EDGE
 #undef AVDSP_ROW_BLOCK4
 #undef AVDSP_ROW_STEP
@@ -3816,7 +3941,7 @@ int launch_biquad(avdsp_hip_prog *prog, Plan &pl, const Plan::Group &g, const in
         scope.begin();
         hipLaunchKernelGGL(biquad_simple<FMT>, dim3((n + 63) / 64), dim3(64), 0, stream, a);
         if (stop) HIP_TRY(hipEventRecord(stop, stream));
-    } else if (biquad_impl == 1 && g.P == 16 && g.d_rows && (FMT == 2 || FMT == 6 || (FMT == 4 && (g.all_fir || g.raw_out)))) {
+    } else if (biquad_impl == 1 && g.P == 16 && g.d_rows) {
         /* one 16-lane row per chain: biquad_row (format 4 only where the cascade feeds a FIR -- a format-4 STORE needs all of the
          * accumulator, biquad_row hands on its float), biquad_row_i64 */
         if constexpr (FMT == 2) {
@@ -3830,7 +3955,10 @@ int launch_biquad(avdsp_hip_prog *prog, Plan &pl, const Plan::Group &g, const in
             a.per_xcd = (nblk + 7) / 8;
             /* (under "overlap" `stop` rides on the kernel's own completion signal instead of a marker packet behind it: 7.1 instead of
              * 8.3 us to the start of the kernel that waits for it on another stream, tools/stream_handover_bench.hip) */
-            if (launch_timed(scope, (const void *)biquad_row<FMT>, dim3(a.per_xcd * 8), dim3(kBlock), 0, stream, a, stop)) return -1;
+            /* (format 4: rows that store int samples need the accumulator itself -- the ACC form; FIR-feeding chains and pieces hand a float on) */
+            const void *fn = (const void *)biquad_row<FMT>;
+            if constexpr (FMT == 4) { if (!(g.all_fir || g.raw_out)) fn = (const void *)biquad_row<4, true>; }
+            if (launch_timed(scope, fn, dim3(a.per_xcd * 8), dim3(kBlock), 0, stream, a, stop)) return -1;
         }
     } else {
         const int cpb = kBlock / g.P;
@@ -4174,7 +4302,7 @@ int launch_cascades(avdsp_hip_prog *prog, Plan &pl, BlockIO io, int biquad_impl,
     /* (i) every cascade of up to 16 sections in ONE biquad_row launch, whatever their lengths (the table of all rows, Plan::d_rows_all):
      * 1024 chains with 1 .. 8 sections 248 -> 33 us.  (ii) what that does not cover -- 17 sections and more, or the options that take
      * biquad_row out -- as before, one launch per length, side by side over the streams. */
-    const bool merged = prog->group_fanout && biquad_impl == 1 && pl.d_rows_all && (FMT == 2 || FMT == 6 || (FMT == 4 && pl.rows_all_fir));
+    const bool merged = prog->group_fanout && biquad_impl == 1 && pl.d_rows_all;
     /* one group on one stream: a launch -- or, for cascades of more than 64 sections, the group's pieces one after the other, the words
      * between them through the group's scratch columns */
     auto launch_group = [&](const Plan::Group &g, hipStream_t s, hipEvent_t stop) -> int {
