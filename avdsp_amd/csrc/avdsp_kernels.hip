@@ -211,22 +211,8 @@ __device__ __forceinline__ unsigned narrow_stage(typename Alu<FMT>::type X)
     else return __float_as_uint(narrow_f32(X));
 }
 
-/* [DSP_SAT0DB] + DSP_STORE -> raw 32-bit sample word */
-template <int FMT>
-__device__ __forceinline__ unsigned store_stage(typename Alu<FMT>::type X, int sat, int mask)
-{
-    if constexpr (FMT == 2) {
-        if (sat) X = saturate64_031(X);
-        return (unsigned)((int)X & mask);                                             /* :616-618 */
-    } else {
-        if (sat) X = saturate_double_0db(X);
-        if constexpr (FMT == 4) return (unsigned)(s31_from_double(X) & mask);         /* :622-627 */
-        else return __float_as_uint(narrow_f32(X));                                   /* :629-630 */
-    }
-}
-
-/* store_stage<4> without a branch (biquad_row's ACC form converts once per 16 steps, every lane: three taken branches there cost as much as
- * the conversion): [saturate_double_0db], s31_from_double -- whose int result is the low word of +-(m >> (n & 63)) --, the dither mask */
+/* store_stage<4> without a branch (round 5; biquad_row's ACC form converts once per 16 steps, every lane, and three taken branches there cost as
+ * much as the conversion; the FIR epilogues convert a word per sample): [saturate_double_0db], s31_from_double -- whose int result is the low word of +-(m >> (n & 63)) --, the dither mask */
 __device__ __forceinline__ unsigned store_word_f4(double X, bool sat, int mask)
 {
     long long u = __double_as_longlong(X);
@@ -241,6 +227,20 @@ __device__ __forceinline__ unsigned store_word_f4(double X, bool sat, int mask)
     w = e == 0 ? 0u : w;
     w = u < 0 ? 0u - w : w;
     return w & (unsigned)mask;
+}
+
+/* [DSP_SAT0DB] + DSP_STORE -> raw 32-bit sample word */
+template <int FMT>
+__device__ __forceinline__ unsigned store_stage(typename Alu<FMT>::type X, int sat, int mask)
+{
+    if constexpr (FMT == 2) {
+        if (sat) X = saturate64_031(X);
+        return (unsigned)((int)X & mask);                                             /* :616-618 */
+    } else {
+        if constexpr (FMT == 4) return store_word_f4(X, sat == 1, mask);              /* :622-627 (saturate_double_0db, s31_from_double, the mask) */
+        if (sat) X = saturate_double_0db(X);
+        return __float_as_uint(narrow_f32(X));                                        /* :629-630 */
+    }
 }
 
 /* XCD-aware block index: hardware deals consecutive workgroups round-robin over the 8 XCDs, so
